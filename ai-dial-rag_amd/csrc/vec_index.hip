@@ -1,0 +1,637 @@
+// Host side of the vector index: handle lifetime, workspaces, kernel dispatch.
+// C ABI declared in include/miretr.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "vec_kernels.h"
+
+namespace mir {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int32_t use_device(int32_t device, int *num_cus) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no usable HIP device (hipGetDeviceCount: %s); libmiretr has no CPU fallback",
+                  e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        (void)hipGetLastError();
+        return MIR_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (have %d)", device, count);
+        return MIR_ERR_INVALID;
+    }
+    MIR_HIP(hipSetDevice(device));
+    if (num_cus) {
+        hipDeviceProp_t prop;
+        MIR_HIP(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            set_error("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+            return MIR_ERR_NO_DEVICE;
+        }
+        *num_cus = prop.multiProcessorCount;
+    }
+    return MIR_OK;
+}
+
+// k-steps (16 columns each) the register-resident scan is instantiated for
+static int pad_ksteps(int d) {
+    const int ks = (d + 15) / 16;
+    static const int kInst[] = {1, 2, 4, 8, 16, 24};
+    for (int v : kInst)
+        if (ks <= v) return v;
+    return (ks + 7) / 8 * 8;  // generic kernel: multiple of the ring depth
+}
+
+struct Workspace {
+    hipStream_t stream = nullptr;    // own stream for the host-buffer API
+    hipEvent_t done = nullptr;       // recorded after the last enqueue that used the buffers
+    hipStream_t last_stream = nullptr;
+    bool pending = false;
+    void *buf = nullptr;             // one slab, carved below
+    size_t cap = 0;
+};
+
+}  // namespace mir
+
+using namespace mir;
+
+struct mir_index {
+    int device = 0;
+    int num_cus = 0;
+    int64_t n = 0;
+    int d = 0;
+    int dtype = MIR_DTYPE_F32;
+    int64_t row_offset = 0;
+    int ksteps = 0;
+    uint32_t n_tiles = 0;
+    float *d_orig = nullptr;
+    uint4 *d_split = nullptr;
+    float *d_docsq = nullptr;    // padded to n_tiles*32
+    float *d_invnorm = nullptr;  // padded to n_tiles*32
+    float *d_maxnorm = nullptr;
+    int64_t *d_chunk = nullptr;
+    int32_t *d_doc = nullptr;
+    int64_t hbm_bytes = 0;
+    std::mutex mu;
+    std::vector<Workspace *> pool;
+};
+
+namespace mir {
+
+static void free_index(mir_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    for (Workspace *w : ix->pool) {
+        if (w->pending) (void)hipEventSynchronize(w->done);
+        if (w->buf) (void)hipFree(w->buf);
+        if (w->done) (void)hipEventDestroy(w->done);
+        if (w->stream) (void)hipStreamDestroy(w->stream);
+        delete w;
+    }
+    (void)hipFree(ix->d_orig);
+    (void)hipFree(ix->d_split);
+    (void)hipFree(ix->d_docsq);
+    (void)hipFree(ix->d_invnorm);
+    (void)hipFree(ix->d_maxnorm);
+    (void)hipFree(ix->d_chunk);
+    (void)hipFree(ix->d_doc);
+    delete ix;
+}
+
+// Build the derived device state from ix->d_orig (already filled) on `stream`.
+static int32_t build_derived(mir_index *ix, hipStream_t stream) {
+    const int64_t n = ix->n;
+    const int d = ix->d;
+    ix->ksteps = pad_ksteps(d);
+    ix->n_tiles = (uint32_t)((n + kTileRows - 1) / kTileRows);
+    const size_t split_bytes = (size_t)ix->n_tiles * ix->ksteps * 2048;
+    const size_t aux_bytes = (size_t)ix->n_tiles * kTileRows * sizeof(float);
+    MIR_HIP(hipMalloc(&ix->d_split, std::max<size_t>(split_bytes, 16)));
+    MIR_HIP(hipMalloc(&ix->d_docsq, std::max<size_t>(aux_bytes, 16)));
+    MIR_HIP(hipMalloc(&ix->d_invnorm, std::max<size_t>(aux_bytes, 16)));
+    MIR_HIP(hipMalloc(&ix->d_maxnorm, 16));
+    ix->hbm_bytes += split_bytes + 2 * aux_bytes + 16;
+    MIR_HIP(hipMemsetAsync(ix->d_docsq, 0, std::max<size_t>(aux_bytes, 16), stream));
+    MIR_HIP(hipMemsetAsync(ix->d_invnorm, 0, std::max<size_t>(aux_bytes, 16), stream));
+    MIR_HIP(hipMemsetAsync(ix->d_maxnorm, 0, 16, stream));
+    if (n > 0) {
+        const int64_t total_lanes = (int64_t)ix->n_tiles * ix->ksteps * 64;
+        const int64_t blocks = (total_lanes + 255) / 256;
+        MIR_REQUIRE(blocks < (int64_t)0x7fffffff, "index too large for one pack launch");
+        pack_split_f32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ksteps,
+                                                                              total_lanes, ix->d_split);
+        MIR_HIP(hipGetLastError());
+        row_norms_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(
+            ix->d_orig, n, d, ix->d_docsq, ix->d_invnorm, reinterpret_cast<unsigned int *>(ix->d_maxnorm));
+        MIR_HIP(hipGetLastError());
+    }
+    return MIR_OK;
+}
+
+static int32_t check_create_args(int64_t n, int32_t d, int32_t dtype, mir_index **out) {
+    MIR_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    MIR_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "n=%lld out of range [0, 2^31)", (long long)n);
+    MIR_REQUIRE(d >= 1 && d <= 128 * 4096, "d=%d out of range", d);
+    if (dtype != MIR_DTYPE_F32) {
+        set_error("dtype %d not supported by this build (float32 only)", dtype);
+        return MIR_ERR_UNSUPPORTED;
+    }
+    return MIR_OK;
+}
+
+// carve helper
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <typename T>
+    T *take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+struct SearchBuffers {
+    double *q;       // [b][d]      (host API only)
+    uint4 *qsplit;   // [ngroups][ksteps][2][64]
+    double *q_sq;    // [b]
+    double *q_norm;  // [b]
+    uint64_t *part;  // [ngroups][nwg][32][klist]
+    int32_t *o_doc;  // host API staging of outputs, [b][k]
+    int64_t *o_chunk;
+    int64_t *o_row;
+    double *o_dist;
+    int32_t *o_count;  // [b]
+    int32_t *o_flags;  // [b]
+};
+
+static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int ksteps, int ngroups, int nwg,
+                    int klist, bool host_api) {
+    Carver c{base};
+    sb.q = host_api ? c.take<double>((size_t)b * d) : nullptr;
+    sb.qsplit = c.take<uint4>((size_t)ngroups * ksteps * 128);
+    sb.q_sq = c.take<double>(b);
+    sb.q_norm = c.take<double>(b);
+    sb.part = c.take<uint64_t>((size_t)ngroups * nwg * 32 * klist);
+    if (host_api) {
+        sb.o_doc = c.take<int32_t>((size_t)b * k);
+        sb.o_chunk = c.take<int64_t>((size_t)b * k);
+        sb.o_row = c.take<int64_t>((size_t)b * k);
+        sb.o_dist = c.take<double>((size_t)b * k);
+        sb.o_count = c.take<int32_t>(b);
+        sb.o_flags = c.take<int32_t>(b);
+    } else {
+        sb.o_doc = nullptr; sb.o_chunk = nullptr; sb.o_row = nullptr; sb.o_dist = nullptr;
+        sb.o_count = nullptr; sb.o_flags = nullptr;
+    }
+    return c.off + 256;
+}
+
+// Take a workspace that is safe to enqueue on `stream` (null = use its own).
+static int32_t acquire_ws(mir_index *ix, hipStream_t stream, size_t need, Workspace **out) {
+    Workspace *w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        for (size_t i = 0; i < ix->pool.size(); ++i) {
+            Workspace *c = ix->pool[i];
+            bool ok = !c->pending || (stream && c->last_stream == stream);
+            if (!ok && hipEventQuery(c->done) == hipSuccess) {
+                c->pending = false;
+                ok = true;
+            }
+            if (ok) {
+                w = c;
+                ix->pool.erase(ix->pool.begin() + i);
+                break;
+            }
+        }
+    }
+    if (!w) {
+        w = new (std::nothrow) Workspace();
+        MIR_REQUIRE(w != nullptr, "out of host memory");
+        hipError_t e1 = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+        hipError_t e2 = hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            set_error("workspace stream/event creation failed");
+            delete w;
+            return MIR_ERR_HIP;
+        }
+    }
+    if (w->cap < need) {
+        if (w->pending) {
+            (void)hipEventSynchronize(w->done);
+            w->pending = false;
+        }
+        if (w->buf) (void)hipFree(w->buf);
+        w->buf = nullptr;
+        w->cap = 0;
+        hipError_t e = hipMalloc(&w->buf, need);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) for search workspace failed: %s", need, hipGetErrorString(e));
+            std::lock_guard<std::mutex> lk(ix->mu);
+            ix->pool.push_back(w);
+            return MIR_ERR_HIP;
+        }
+        w->cap = need;
+    }
+    *out = w;
+    return MIR_OK;
+}
+
+static void release_ws(mir_index *ix, Workspace *w, hipStream_t used, bool pending) {
+    w->last_stream = used;
+    w->pending = pending;
+    if (pending) (void)hipEventRecord(w->done, used);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->pool.push_back(w);
+}
+
+template <int KIND>
+static int32_t launch_scan(const mir_index *ix, const uint4 *qsplit_g, int nq, int klist, int nwg,
+                           uint64_t *part_g, hipStream_t stream) {
+    const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
+    const size_t lds = ((size_t)klist * 256 + 32 * (size_t)klist) * 8;
+    const uint32_t n_rows = (uint32_t)ix->n;
+#define MIR_SCAN_CASE(KS)                                                                                    \
+    case KS: {                                                                                               \
+        auto kern = scan_topk_kernel<KS, KIND>;                                                              \
+        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+        kern<<<dim3(nwg), dim3(256), lds, stream>>>(ix->d_split, aux, qsplit_g, n_rows, ix->n_tiles, nq,     \
+                                                    klist, part_g);                                          \
+        break;                                                                                               \
+    }
+    switch (ix->ksteps) {
+        MIR_SCAN_CASE(1)
+        MIR_SCAN_CASE(2)
+        MIR_SCAN_CASE(4)
+        MIR_SCAN_CASE(8)
+        MIR_SCAN_CASE(16)
+        MIR_SCAN_CASE(24)
+        default: {
+            auto kern = scan_topk_generic_kernel<KIND>;
+            MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            kern<<<dim3(nwg), dim3(256), lds, stream>>>(ix->d_split, aux, qsplit_g, ix->ksteps, n_rows,
+                                                        ix->n_tiles, nq, klist, part_g);
+            break;
+        }
+    }
+#undef MIR_SCAN_CASE
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
+static int32_t check_search_args(const mir_index *ix, const void *queries, int32_t b, int32_t k, int32_t metric,
+                                 const int32_t *out_count) {
+    MIR_REQUIRE(ix != nullptr, "index is NULL");
+    MIR_REQUIRE(b >= 0, "b=%d is negative", b);
+    MIR_REQUIRE(b == 0 || queries != nullptr, "queries is NULL");
+    MIR_REQUIRE(k >= 1, "k=%d must be >= 1", k);
+    MIR_REQUIRE(metric >= 0 && metric <= 3, "unknown metric %d", metric);
+    MIR_REQUIRE(b == 0 || out_count != nullptr, "out_count is NULL");
+    return MIR_OK;
+}
+
+// Enqueue prep + scan(s) + finalize for device-resident queries/outputs.
+static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int metric, const SearchBuffers &sb,
+                              int ngroups, int nwg, int klist, int32_t *o_doc, int64_t *o_chunk, int64_t *o_row,
+                              double *o_dist, int32_t *o_count, int32_t *o_flags, hipStream_t stream) {
+    const int d = ix->d;
+    prep_queries_kernel<<<dim3(ngroups * ix->ksteps + b), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, ngroups,
+                                                                               sb.qsplit, sb.q_sq, sb.q_norm);
+    MIR_HIP(hipGetLastError());
+    for (int g = 0; g < ngroups; ++g) {
+        const uint4 *qs = sb.qsplit + (size_t)g * ix->ksteps * 128;
+        uint64_t *pg = sb.part + (size_t)g * nwg * 32 * klist;
+        const int nq = std::min(32, b - 32 * g);
+        int32_t rc;
+        if (metric == MIR_METRIC_INNER_PRODUCT) rc = launch_scan<SCAN_IP>(ix, qs, nq, klist, nwg, pg, stream);
+        else if (metric == MIR_METRIC_COSINE_SIM) rc = launch_scan<SCAN_COS>(ix, qs, nq, klist, nwg, pg, stream);
+        else rc = launch_scan<SCAN_L2>(ix, qs, nq, klist, nwg, pg, stream);
+        if (rc != MIR_OK) return rc;
+    }
+    FinalizeArgs fa;
+    fa.part = sb.part; fa.nwg = nwg; fa.klist = klist; fa.k = k; fa.b = b; fa.d = d; fa.metric = metric;
+    fa.docs = ix->d_orig; fa.doc_sq = ix->d_docsq; fa.max_norm = ix->d_maxnorm;
+    fa.q = dq; fa.q_sq = sb.q_sq; fa.q_norm = sb.q_norm;
+    fa.chunk_ids = ix->d_chunk; fa.doc_ids = ix->d_doc; fa.row_offset = ix->row_offset;
+    fa.out_doc = o_doc; fa.out_chunk = o_chunk; fa.out_row = o_row; fa.out_dist = o_dist;
+    fa.out_count = o_count; fa.out_flags = o_flags;
+    finalize_kernel<<<dim3(b), dim3(256), 0, stream>>>(fa);
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
+static int32_t plan(const mir_index *ix, int b, int k, int *ngroups, int *nwg, int *klist) {
+    if (k + kListMargin > kMaxList && ix->n > (int64_t)(kMaxList)) {
+        set_error("k=%d exceeds the scan's candidate list (max k = %d) for an index of %lld rows", k,
+                  kMaxList - kListMargin, (long long)ix->n);
+        return MIR_ERR_UNSUPPORTED;
+    }
+    *klist = std::min(k + kListMargin, kMaxList);
+    *ngroups = (b + 31) / 32;
+    // one workgroup per CU; never more workgroups than there are 4-tile chunks of work
+    const int64_t want = ((int64_t)ix->n_tiles + 3) / 4;
+    *nwg = (int)std::max<int64_t>(1, std::min<int64_t>(ix->num_cus, want));
+    return MIR_OK;
+}
+
+}  // namespace mir
+
+// ============================================================ C ABI
+
+extern "C" {
+
+int32_t mir_abi_version(void) { return MIR_ABI_VERSION; }
+const char *mir_last_error(void) { return mir::g_err; }
+
+int32_t mir_device_count(int32_t *out_count) {
+    MIR_REQUIRE(out_count != nullptr, "out_count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *out_count = c;
+    return MIR_OK;
+}
+
+static int32_t create_common(const void *emb, bool emb_on_device, int64_t n, int32_t d, int32_t dtype,
+                             const int64_t *chunk_ids, const int32_t *doc_ids, int32_t device,
+                             int64_t row_offset, hipStream_t stream, mir_index **out) {
+    int32_t rc = check_create_args(n, d, dtype, out);
+    if (rc != MIR_OK) return rc;
+    MIR_REQUIRE(n == 0 || emb != nullptr, "embeddings pointer is NULL");
+    int cus = 0;
+    rc = use_device(device, &cus);
+    if (rc != MIR_OK) return rc;
+    mir_index *ix = new (std::nothrow) mir_index();
+    MIR_REQUIRE(ix != nullptr, "out of host memory");
+    ix->device = device; ix->num_cus = cus; ix->n = n; ix->d = d; ix->dtype = dtype; ix->row_offset = row_offset;
+    const hipMemcpyKind kind = emb_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    auto fail = [&](int32_t code) {
+        free_index(ix);
+        return code;
+    };
+#define MIR_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            set_error("%s failed: %s", #call, hipGetErrorString(e_));                              \
+            return fail(MIR_ERR_HIP);                                                              \
+        }                                                                                          \
+    } while (0)
+    const size_t orig_bytes = (size_t)n * d * sizeof(float);
+    MIR_TRY(hipMalloc(&ix->d_orig, std::max<size_t>(orig_bytes, 16)));
+    ix->hbm_bytes += orig_bytes;
+    if (n > 0) MIR_TRY(hipMemcpyAsync(ix->d_orig, emb, orig_bytes, kind, stream));
+    if (chunk_ids && n > 0) {
+        MIR_TRY(hipMalloc(&ix->d_chunk, (size_t)n * 8));
+        MIR_TRY(hipMemcpyAsync(ix->d_chunk, chunk_ids, (size_t)n * 8, kind, stream));
+        ix->hbm_bytes += (size_t)n * 8;
+    }
+    if (doc_ids && n > 0) {
+        MIR_TRY(hipMalloc(&ix->d_doc, (size_t)n * 4));
+        MIR_TRY(hipMemcpyAsync(ix->d_doc, doc_ids, (size_t)n * 4, kind, stream));
+        ix->hbm_bytes += (size_t)n * 4;
+    }
+#undef MIR_TRY
+    rc = build_derived(ix, stream);
+    if (rc != MIR_OK) return fail(rc);
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        set_error("index build failed: %s", hipGetErrorString(e));
+        return fail(MIR_ERR_HIP);
+    }
+    *out = ix;
+    return MIR_OK;
+}
+
+int32_t mir_index_create(const void *emb_host, int64_t n, int32_t d, int32_t dtype, const int64_t *chunk_ids_host,
+                         const int32_t *doc_ids_host, int32_t device, int64_t row_offset, mir_index **out) {
+    return create_common(emb_host, false, n, d, dtype, chunk_ids_host, doc_ids_host, device, row_offset, nullptr, out);
+}
+
+int32_t mir_index_create_from_device(const void *emb_device, int64_t n, int32_t d, int32_t dtype,
+                                     const int64_t *chunk_ids_device, const int32_t *doc_ids_device,
+                                     int32_t device, int64_t row_offset, void *stream, mir_index **out) {
+    return create_common(emb_device, true, n, d, dtype, chunk_ids_device, doc_ids_device, device, row_offset,
+                         static_cast<hipStream_t>(stream), out);
+}
+
+int32_t mir_index_destroy(mir_index *idx) {
+    free_index(idx);
+    return MIR_OK;
+}
+
+int32_t mir_index_info(const mir_index *idx, int64_t *n, int32_t *d, int32_t *dtype, int32_t *device,
+                       int64_t *hbm_bytes) {
+    MIR_REQUIRE(idx != nullptr, "index is NULL");
+    if (n) *n = idx->n;
+    if (d) *d = idx->d;
+    if (dtype) *dtype = idx->dtype;
+    if (device) *device = idx->device;
+    if (hbm_bytes) *hbm_bytes = idx->hbm_bytes;
+    return MIR_OK;
+}
+
+int32_t mir_index_search_device(mir_index *idx, const double *queries_device, int32_t b, int32_t k,
+                                int32_t metric, int32_t *out_doc, int64_t *out_chunk, int64_t *out_row,
+                                double *out_dist, int32_t *out_count, int32_t *out_flags, void *stream_) {
+    int32_t rc = check_search_args(idx, queries_device, b, k, metric, out_count);
+    if (rc != MIR_OK) return rc;
+    if (b == 0) return MIR_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    rc = use_device(idx->device, nullptr);
+    if (rc != MIR_OK) return rc;
+    int ngroups, nwg, klist;
+    rc = plan(idx, b, k, &ngroups, &nwg, &klist);
+    if (rc != MIR_OK) return rc;
+    SearchBuffers sb;
+    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, ngroups, nwg, klist, false);
+    Workspace *w = nullptr;
+    rc = acquire_ws(idx, stream, need, &w);
+    if (rc != MIR_OK) return rc;
+    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, ngroups, nwg, klist, false);
+    rc = enqueue_search(idx, queries_device, b, k, metric, sb, ngroups, nwg, klist, out_doc, out_chunk, out_row,
+                        out_dist, out_count, out_flags, stream);
+    release_ws(idx, w, stream, true);
+    return rc;
+}
+
+int32_t mir_index_search(mir_index *idx, const double *queries_host, int32_t b, int32_t k, int32_t metric,
+                         int32_t *out_doc, int64_t *out_chunk, int64_t *out_row, double *out_dist,
+                         int32_t *out_count, int32_t *out_flags) {
+    int32_t rc = check_search_args(idx, queries_host, b, k, metric, out_count);
+    if (rc != MIR_OK) return rc;
+    if (b == 0) return MIR_OK;
+    rc = use_device(idx->device, nullptr);
+    if (rc != MIR_OK) return rc;
+    int ngroups, nwg, klist;
+    rc = plan(idx, b, k, &ngroups, &nwg, &klist);
+    if (rc != MIR_OK) return rc;
+    SearchBuffers sb;
+    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, ngroups, nwg, klist, true);
+    Workspace *w = nullptr;
+    rc = acquire_ws(idx, nullptr, need, &w);
+    if (rc != MIR_OK) return rc;
+    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, ngroups, nwg, klist, true);
+    hipStream_t s = w->stream;
+    auto bail = [&](int32_t code) {
+        (void)hipStreamSynchronize(s);
+        release_ws(idx, w, s, false);
+        return code;
+    };
+#define MIR_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            set_error("%s failed: %s", #call, hipGetErrorString(e_));                              \
+            return bail(MIR_ERR_HIP);                                                              \
+        }                                                                                          \
+    } while (0)
+    MIR_TRY(hipMemcpyAsync(sb.q, queries_host, (size_t)b * idx->d * sizeof(double), hipMemcpyHostToDevice, s));
+    rc = enqueue_search(idx, sb.q, b, k, metric, sb, ngroups, nwg, klist, out_doc ? sb.o_doc : nullptr,
+                        out_chunk ? sb.o_chunk : nullptr, out_row ? sb.o_row : nullptr,
+                        out_dist ? sb.o_dist : nullptr, sb.o_count, sb.o_flags, s);
+    if (rc != MIR_OK) return bail(rc);
+    const size_t bk = (size_t)b * k;
+    if (out_doc) MIR_TRY(hipMemcpyAsync(out_doc, sb.o_doc, bk * 4, hipMemcpyDeviceToHost, s));
+    if (out_chunk) MIR_TRY(hipMemcpyAsync(out_chunk, sb.o_chunk, bk * 8, hipMemcpyDeviceToHost, s));
+    if (out_row) MIR_TRY(hipMemcpyAsync(out_row, sb.o_row, bk * 8, hipMemcpyDeviceToHost, s));
+    if (out_dist) MIR_TRY(hipMemcpyAsync(out_dist, sb.o_dist, bk * 8, hipMemcpyDeviceToHost, s));
+    MIR_TRY(hipMemcpyAsync(out_count, sb.o_count, (size_t)b * 4, hipMemcpyDeviceToHost, s));
+    if (out_flags) MIR_TRY(hipMemcpyAsync(out_flags, sb.o_flags, (size_t)b * 4, hipMemcpyDeviceToHost, s));
+    MIR_TRY(hipStreamSynchronize(s));
+#undef MIR_TRY
+    release_ws(idx, w, s, false);
+    return MIR_OK;
+}
+
+int32_t mir_index_metric_eval(mir_index *idx, const double *query_host, int32_t metric, double *out_host) {
+    MIR_REQUIRE(idx != nullptr, "index is NULL");
+    MIR_REQUIRE(metric >= 0 && metric <= 3, "unknown metric %d", metric);
+    if (idx->n == 0) return MIR_OK;
+    MIR_REQUIRE(query_host != nullptr && out_host != nullptr, "NULL buffer");
+    int32_t rc = use_device(idx->device, nullptr);
+    if (rc != MIR_OK) return rc;
+    const int d = idx->d;
+    const int64_t n = idx->n;
+    // slab: q[d] | q_sq | q_norm | out[n]
+    Carver c{nullptr};
+    c.take<double>(d); c.take<double>(1); c.take<double>(1); c.take<double>(n);
+    const size_t need = c.off + 256;
+    Workspace *w = nullptr;
+    rc = acquire_ws(idx, nullptr, need, &w);
+    if (rc != MIR_OK) return rc;
+    Carver cc{static_cast<char *>(w->buf)};
+    double *dq = cc.take<double>(d);
+    double *dsq = cc.take<double>(1);
+    double *dnm = cc.take<double>(1);
+    double *dout = cc.take<double>(n);
+    hipStream_t s = w->stream;
+    hipError_t e = hipMemcpyAsync(dq, query_host, (size_t)d * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        // ngroups = 0: only the per-query norm block runs
+        prep_queries_kernel<<<dim3(1), dim3(64), 0, s>>>(dq, 1, d, idx->ksteps, 0, nullptr, dsq, dnm);
+        metric_eval_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(idx->d_orig, idx->d_docsq, n, d, dq,
+                                                                              dsq, dnm, metric, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, dout, (size_t)n * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    else (void)hipStreamSynchronize(s);
+    release_ws(idx, w, s, false);
+    if (e != hipSuccess) {
+        set_error("metric_eval failed: %s", hipGetErrorString(e));
+        return MIR_ERR_HIP;
+    }
+    return MIR_OK;
+}
+
+int32_t mir_metric_eval(const void *docs_host, int64_t n, int32_t d, int32_t dtype, const double *query_host,
+                        int32_t metric, int32_t device, double *out_host) {
+    mir_index *ix = nullptr;
+    int32_t rc = mir_index_create(docs_host, n, d, dtype, nullptr, nullptr, device, 0, &ix);
+    if (rc != MIR_OK) return rc;
+    rc = mir_index_metric_eval(ix, query_host, metric, out_host);
+    mir_index_destroy(ix);
+    return rc;
+}
+
+int32_t mir_topk_merge_device(const double *dist, const int64_t *row, const int32_t *count, int32_t s, int32_t b,
+                              int32_t k, int32_t descending_scores, double *out_dist, int64_t *out_row,
+                              int32_t *out_count, int32_t device, void *stream) {
+    MIR_REQUIRE(s >= 1 && b >= 0 && k >= 1, "bad merge shape s=%d b=%d k=%d", s, b, k);
+    if (b == 0) return MIR_OK;
+    MIR_REQUIRE(dist && row && count && out_dist && out_row && out_count, "NULL buffer");
+    int32_t rc = use_device(device, nullptr);
+    if (rc != MIR_OK) return rc;
+    merge_topk_kernel<<<dim3(b), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
+        dist, row, count, s, b, k, descending_scores, out_dist, out_row, out_count);
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
+int32_t mir_topk_merge_host(const double *dist, const int64_t *row, const int32_t *count, int32_t s, int32_t b,
+                            int32_t k, int32_t descending_scores, double *out_dist, int64_t *out_row,
+                            int32_t *out_count) {
+    MIR_REQUIRE(s >= 1 && b >= 0 && k >= 1, "bad merge shape s=%d b=%d k=%d", s, b, k);
+    if (b == 0) return MIR_OK;
+    MIR_REQUIRE(dist && row && count && out_dist && out_row && out_count, "NULL buffer");
+    struct Item {
+        double d;
+        int64_t r;
+    };
+    std::vector<Item> items;
+    for (int q = 0; q < b; ++q) {
+        items.clear();
+        for (int sh = 0; sh < s; ++sh) {
+            const int c = count[(size_t)sh * b + q];
+            MIR_REQUIRE(c >= 0 && c <= k, "count[%d][%d]=%d out of range", sh, q, c);
+            for (int p = 0; p < c; ++p) {
+                const size_t o = ((size_t)sh * b + q) * k + p;
+                items.push_back({dist[o], row[o]});
+            }
+        }
+        if (!descending_scores) {
+            std::sort(items.begin(), items.end(), [](const Item &a, const Item &c) {
+                const bool na = a.d != a.d, nc = c.d != c.d;
+                if (na || nc) return na == nc ? a.r < c.r : nc;
+                return a.d < c.d || (a.d == c.d && a.r < c.r);
+            });
+        } else {
+            std::sort(items.begin(), items.end(),
+                      [](const Item &a, const Item &c) { return a.d > c.d || (a.d == c.d && a.r > c.r); });
+        }
+        const int kout = (int)std::min<size_t>(items.size(), (size_t)k);
+        for (int p = 0; p < kout; ++p) {
+            out_dist[(size_t)q * k + p] = items[p].d;
+            out_row[(size_t)q * k + p] = items[p].r;
+        }
+        out_count[q] = kout;
+    }
+    return MIR_OK;
+}
+
+}  // extern "C"

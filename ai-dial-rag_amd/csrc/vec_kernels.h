@@ -1,0 +1,702 @@
+// Device code of the vector-search path (gfx950 / CDNA4 only).
+//
+// Replaces, for a batch of queries, the per-query numpy passes of
+//   aidial_rag/retrievers/embeddings_metrics.py:14-50  (metric over [N,d])
+//   aidial_rag/retrievers/embeddings_index.py:51-89    (stable argsort, first k)
+//
+// Data layout in HBM (DESIGN.md "Vector index layout"):
+//   orig   f32 [N][d] row-major            - exact values, gathered only for the
+//                                            few candidates that are re-scored
+//   split  bf16 fragment-major             - what the scan streams.  Rows are
+//          grouped in tiles of 32; a tile holds KS k-steps of 16 columns; each
+//          k-step holds a `hi` and a `lo` block of 1 KiB = 64 lanes x 8 bf16,
+//          lane l = (row l&31, column half l>>5) - exactly the A operand of
+//          v_mfma_f32_32x32x16_bf16, so one coalesced 16-B-per-lane load IS the
+//          fragment.  hi = bf16(x), lo = bf16(x - hi): x = hi + lo to 2^-18.
+//   aux    f32 doc_sq[N] (numpy pairwise order, bit-exact), inv_norm[N]
+//
+// Scan (one pass of the shard per group of 32 queries): each wave owns whole
+// tiles; the 32 queries' fragments live in 2*4*KS VGPRs for the whole kernel;
+// per k-step three MFMAs (hi*hi, hi*lo, lo*hi) give the dot products to
+// ~1.5e-5*|d||q| worst case.  With docs as A and queries as B, the 32x32
+// accumulator puts ONE query on each lane (column = lane&31), so top-k
+// selection is lane-local: a threshold compare per score and a rare insertion
+// into that lane's list in LDS.  No barriers inside the pass.
+//
+// Finalize: per query, the per-workgroup lists are merged to the best `klist`
+// candidates, those rows are re-scored in float64 with the reference's own
+// formulas, ordered by (distance, row) - the reference's stable tie-break -
+// and an a-posteriori bound check proves the candidate set was complete.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mir {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kTileRows = 32;
+constexpr int kMaxList = 64;         // per-lane candidate list cap (LDS: 64*256*8 = 128 KiB)
+constexpr int kListMargin = 8;       // klist = k + margin
+constexpr int kSortN = 8192;         // finalize: LDS bitonic width (64 KiB)
+constexpr double kScanRelErr = 2e-5; // bound on |scan dot - exact dot| / (|d||q|), see DESIGN.md
+
+enum ScanKind { SCAN_IP = 0, SCAN_L2 = 1, SCAN_COS = 2 };
+
+// ---------------------------------------------------------------- helpers
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;  // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
+
+// x -> (hi, lo) bf16 bit patterns with x ~= hi + lo
+__device__ __forceinline__ void split_bf16(float x, uint32_t &hi, uint32_t &lo) {
+    hi = bf16_rne_bits(x);
+    float r = x - bf16_bits_to_float(hi);  // exact in f32
+    lo = bf16_rne_bits(r);
+}
+
+__device__ __forceinline__ uint4 pack8(const uint32_t (&b)[8]) {
+    return make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
+}
+
+// Monotone float -> uint32 (larger float = larger uint).
+__device__ __forceinline__ uint32_t orderable(float v) {
+    uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unorderable(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+// Candidate key: larger is better; among equal values the LOWER row wins
+// (embeddings_index.py:57-58 stable argsort).  0 is the "empty" sentinel.
+__device__ __forceinline__ uint64_t make_key(float v, uint32_t row) {
+    return ((uint64_t)orderable(v) << 32) | (uint64_t)(0xffffffffu - row);
+}
+__device__ __forceinline__ uint32_t key_row(uint64_t key) { return 0xffffffffu - (uint32_t)key; }
+__device__ __forceinline__ float key_value(uint64_t key) { return unorderable((uint32_t)(key >> 32)); }
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// ---------------------------------------------------------------- index build
+
+// f32 [n][d] row-major -> split fragment-major blocks.  One thread per
+// (tile, k-step, lane).  ksteps*16 >= d; columns past d and rows past n are 0.
+__global__ __launch_bounds__(256) void pack_split_f32_kernel(const float *__restrict__ src, int64_t n, int d,
+                                                             int ksteps, int64_t total_lanes,
+                                                             uint4 *__restrict__ dst) {
+    int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_lanes) return;
+    int lane = (int)(gid & 63);
+    int64_t blk = gid >> 6;
+    int s = (int)(blk % ksteps);
+    int64_t tile = blk / ksteps;
+    int64_t row = tile * kTileRows + (lane & 31);
+    int col0 = 16 * s + 8 * (lane >> 5);
+    float x[8];
+    if (row < n && col0 + 8 <= d && (d & 3) == 0) {
+        const float4 *p = reinterpret_cast<const float4 *>(src + row * (int64_t)d + col0);
+        float4 a = p[0], b = p[1];
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+        x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (row < n && col0 + j < d) ? src[row * (int64_t)d + col0 + j] : 0.f;
+    }
+    uint32_t hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_bf16(x[j], hi[j], lo[j]);
+    dst[(blk * 2 + 0) * 64 + lane] = pack8(hi);
+    dst[(blk * 2 + 1) * 64 + lane] = pack8(lo);
+}
+
+// numpy's float32 pairwise sum of squares (numpy/_core/src/umath/loops_utils.h.src
+// `@TYPE@_pairwise_sum`, block size 128, 8 accumulators) so that doc_sq matches
+// `np.sum(docs**2, axis=1)` of embeddings_metrics.py:40 bit for bit.  The library
+// is built with -ffp-contract=off (HIP's *_rn intrinsics are plain operators and
+// would otherwise be fused into fma, which rounds differently); the
+// _rn intrinsics keep the compiler from contracting mul+add into an fma.
+__device__ __forceinline__ float sq_rn(float x) { return __fmul_rn(x, x); }
+
+__device__ inline float np_pairwise_leaf_sq(const float *a, int n) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r = __fadd_rn(r, sq_rn(a[i]));
+        return r;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = sq_rn(a[j]);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], sq_rn(a[i + j]));
+    }
+    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+    for (; i < n; ++i) res = __fadd_rn(res, sq_rn(a[i]));
+    return res;
+}
+template <int DEPTH>
+__device__ inline float np_pairwise_sq(const float *a, int n) {
+    if (n <= 128) return np_pairwise_leaf_sq(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return __fadd_rn(np_pairwise_sq<DEPTH - 1>(a, n2), np_pairwise_sq<DEPTH - 1>(a + n2, n - n2));
+}
+template <>
+__device__ inline float np_pairwise_sq<0>(const float *a, int n) {
+    // d > 128 * 2^12 is rejected on the host; unreachable
+    return np_pairwise_leaf_sq(a, n < 128 ? n : 128);
+}
+
+// One thread per row: doc_sq (f32, numpy order), inv_norm = 1/max(|d|, 1e-8),
+// and the running maximum row norm (for the scan's error bound).
+__global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ src, int64_t n, int d,
+                                                        float *__restrict__ doc_sq,
+                                                        float *__restrict__ inv_norm,
+                                                        unsigned int *__restrict__ max_norm_bits) {
+    int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float nrm = 0.f;
+    if (row < n) {
+        const float *a = src + row * (int64_t)d;
+        doc_sq[row] = np_pairwise_sq<12>(a, d);
+        double s = 0.0;
+        for (int j = 0; j < d; ++j) s += (double)a[j] * (double)a[j];
+        nrm = (float)sqrt(s);
+        nrm = nrm * (1.0f + 1e-6f);  // round up: used as an upper bound
+        inv_norm[row] = 1.0f / fmaxf((float)sqrt(s), 1e-8f);
+    }
+    // wave max, then one atomic per wave (positive floats order as uints)
+    for (int off = 32; off >= 1; off >>= 1) nrm = fmaxf(nrm, __shfl_xor(nrm, off, 64));
+    if ((threadIdx.x & 63) == 0 && nrm > 0.f) atomicMax(max_norm_bits, __float_as_uint(nrm));
+}
+
+// ---------------------------------------------------------------- query prep
+
+// Blocks [0, ngroups*ksteps): write the B-operand fragments of query group g,
+// k-step s (lane l = query 32g + (l&31), columns 16s + 8(l>>5) ..+7).
+// Blocks [ngroups*ksteps, +b): per-query sum of squares and norm in float64.
+__global__ __launch_bounds__(64) void prep_queries_kernel(const double *__restrict__ q, int b, int d, int ksteps,
+                                                          int ngroups, uint4 *__restrict__ qsplit,
+                                                          double *__restrict__ q_sq,
+                                                          double *__restrict__ q_norm) {
+    int lane = threadIdx.x;
+    int blk = blockIdx.x;
+    if (blk < ngroups * ksteps) {
+        int s = blk % ksteps;
+        int g = blk / ksteps;
+        int qi = 32 * g + (lane & 31);
+        int col0 = 16 * s + 8 * (lane >> 5);
+        uint32_t hi[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = (qi < b && col0 + j < d) ? (float)q[(int64_t)qi * d + col0 + j] : 0.f;
+            split_bf16(x, hi[j], lo[j]);
+        }
+        qsplit[((int64_t)blk * 2 + 0) * 64 + lane] = pack8(hi);
+        qsplit[((int64_t)blk * 2 + 1) * 64 + lane] = pack8(lo);
+    } else {
+        int qi = blk - ngroups * ksteps;
+        if (qi >= b) return;
+        double s = 0.0;
+        for (int j = lane; j < d; j += 64) {
+            double x = q[(int64_t)qi * d + j];
+            s += x * x;
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            q_sq[qi] = s;
+            q_norm[qi] = sqrt(s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- scan
+
+// Replace this lane's current worst entry, then find the new worst.
+__device__ __forceinline__ void list_insert(uint64_t *list, int klist, int tid, uint64_t key, uint64_t &minkey,
+                                            int &minpos) {
+    list[minpos * 256 + tid] = key;
+    uint64_t m = ~0ull;
+    int mp = 0;
+    for (int p = 0; p < klist; ++p) {
+        uint64_t x = list[p * 256 + tid];
+        if (x < m) {
+            m = x;
+            mp = p;
+        }
+    }
+    minkey = m;
+    minpos = mp;
+}
+
+// grid = (#CUs), block = 256 (4 waves, one per SIMD, whole register file each).
+// dynamic LDS = (klist*256 + 32*klist) * 8 bytes.
+template <int KSTEPS, int KIND>
+__global__ __launch_bounds__(256, 1) void scan_topk_kernel(const uint4 *__restrict__ docs,
+                                                           const float *__restrict__ aux,
+                                                           const uint4 *__restrict__ qsplit, uint32_t n_rows,
+                                                           uint32_t n_tiles, int nq, int klist,
+                                                           uint64_t *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *list = reinterpret_cast<uint64_t *>(smem);  // [klist][256], lane-private columns
+    uint64_t *stage = list + klist * 256;                 // [32][klist]
+
+    constexpr int R = KSTEPS < 8 ? KSTEPS : 8;  // ring depth in k-steps (2 KiB each)
+    static_assert(KSTEPS % R == 0, "ring slot must be static across tiles");
+    constexpr int TILE_U4 = KSTEPS * 128;  // uint4 per tile (hi+lo)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int h = lane >> 5;
+    const int qj = lane & 31;
+    const uint32_t wave_global = blockIdx.x * 4 + (tid >> 6);
+    const uint32_t total_waves = gridDim.x * 4;
+
+    for (int p = 0; p < klist; ++p) list[p * 256 + tid] = 0;
+    uint64_t minkey = 0;
+    int minpos = 0;
+
+    if (wave_global < n_tiles) {
+        // the 32 queries of this group, as B-operand fragments, for the whole kernel
+        bf16x8 qh[KSTEPS], ql[KSTEPS];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            qh[s] = __builtin_bit_cast(bf16x8, qsplit[(s * 2 + 0) * 64 + lane]);
+            ql[s] = __builtin_bit_cast(bf16x8, qsplit[(s * 2 + 1) * 64 + lane]);
+        }
+
+        uint32_t t = wave_global;
+        const uint4 *tp = docs + (size_t)t * TILE_U4 + lane;
+        uint4 bh[R], bl[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            bh[i] = tp[(2 * i + 0) * 64];
+            bl[i] = tp[(2 * i + 1) * 64];
+        }
+
+        while (true) {
+            const uint32_t tn = t + total_waves;
+            const bool more = tn < n_tiles;
+            // prefetch target for the ring's wrap-around: next tile, or this one again at the end
+            const uint4 *np = docs + (size_t)(more ? tn : t) * TILE_U4 + lane;
+
+            float4 ax[4];
+            if (KIND != SCAN_IP) {
+                const float4 *ap = reinterpret_cast<const float4 *>(aux + (size_t)t * kTileRows);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ax[g] = ap[2 * g + h];
+            }
+
+            f32x16 acc_m = {0}, acc_c = {0};
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int slot = ks % R;
+                bf16x8 ah = __builtin_bit_cast(bf16x8, bh[slot]);
+                bf16x8 al = __builtin_bit_cast(bf16x8, bl[slot]);
+                acc_m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], acc_m, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], acc_c, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[ks], acc_c, 0, 0, 0);
+                if (ks + R < KSTEPS) {
+                    bh[slot] = tp[(2 * (ks + R) + 0) * 64];
+                    bl[slot] = tp[(2 * (ks + R) + 1) * 64];
+                } else {
+                    bh[slot] = np[(2 * (ks + R - KSTEPS) + 0) * 64];
+                    bl[slot] = np[(2 * (ks + R - KSTEPS) + 1) * 64];
+                }
+                // Pin the k-step: without this hipcc sinks each refill next to its
+                // use R steps later (fewer live registers) and the wave ends up with
+                // ~2 loads in flight instead of 2*R.
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            // epilogue: C layout col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            if (qj < nq) {
+                const uint32_t row0 = t * kTileRows + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = r >> 2, i = r & 3;
+                    const uint32_t row = row0 + 8 * g + i;
+                    float dot = acc_m[r] + acc_c[r];
+                    float v;
+                    if (KIND == SCAN_IP) {
+                        v = dot;
+                    } else {
+                        const float a = (i == 0) ? ax[g].x : (i == 1) ? ax[g].y : (i == 2) ? ax[g].z : ax[g].w;
+                        v = (KIND == SCAN_L2) ? fmaf(2.0f, dot, -a) : dot * a;
+                    }
+                    v = (v == v) ? v + 0.0f : -__builtin_inff();  // NaN ranks last; -0 -> +0
+                    const uint64_t key = make_key(v, row);
+                    if (row < n_rows && key > minkey) list_insert(list, klist, tid, key, minkey, minpos);
+                }
+            }
+            if (!more) break;
+            t = tn;
+            tp = np;
+        }
+    }
+
+    // ---- in-workgroup merge: 8 lane lists per query -> one list of klist ----
+    __syncthreads();
+    for (int i = tid; i < 32 * klist; i += 256) stage[i] = 0;
+    __syncthreads();
+    for (int p = 0; p < klist; ++p) {
+        const uint64_t key = list[p * 256 + tid];
+        if (key == 0) continue;
+        int rank = 0;
+        for (int l = 0; l < 8; ++l) {
+            const int t2 = 64 * (l >> 1) + 32 * (l & 1) + qj;
+            for (int p2 = 0; p2 < klist; ++p2) rank += (list[p2 * 256 + t2] > key) ? 1 : 0;
+        }
+        if (rank < klist) stage[qj * klist + rank] = key;  // keys are distinct: ranks are too
+    }
+    __syncthreads();
+    uint64_t *out = part + (size_t)blockIdx.x * 32 * klist;
+    for (int i = tid; i < 32 * klist; i += 256) out[i] = stage[i];
+}
+
+// Generic dimension: query fragments are re-read from L2 each k-step instead of
+// living in registers.  Same tile walk, same epilogue.  ksteps % 8 == 0.
+template <int KIND>
+__global__ __launch_bounds__(256, 1) void scan_topk_generic_kernel(const uint4 *__restrict__ docs,
+                                                                   const float *__restrict__ aux,
+                                                                   const uint4 *__restrict__ qsplit,
+                                                                   int ksteps, uint32_t n_rows,
+                                                                   uint32_t n_tiles, int nq, int klist,
+                                                                   uint64_t *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *list = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *stage = list + klist * 256;
+    constexpr int R = 8;
+    const size_t tile_u4 = (size_t)ksteps * 128;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, qj = lane & 31;
+    const uint32_t wave_global = blockIdx.x * 4 + (tid >> 6);
+    const uint32_t total_waves = gridDim.x * 4;
+    for (int p = 0; p < klist; ++p) list[p * 256 + tid] = 0;
+    uint64_t minkey = 0;
+    int minpos = 0;
+
+    for (uint32_t t = wave_global; t < n_tiles; t += total_waves) {
+        const uint4 *tp = docs + (size_t)t * tile_u4 + lane;
+        const uint4 *qp = qsplit + lane;
+        float4 ax[4];
+        if (KIND != SCAN_IP) {
+            const float4 *ap = reinterpret_cast<const float4 *>(aux + (size_t)t * kTileRows);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ax[g] = ap[2 * g + h];
+        }
+        f32x16 acc_m = {0}, acc_c = {0};
+        for (int k0 = 0; k0 < ksteps; k0 += R) {
+            uint4 dh[R], dl[R], qh[R], ql[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                dh[i] = tp[(2 * (k0 + i) + 0) * 64];
+                dl[i] = tp[(2 * (k0 + i) + 1) * 64];
+                qh[i] = qp[(2 * (k0 + i) + 0) * 64];
+                ql[i] = qp[(2 * (k0 + i) + 1) * 64];
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                bf16x8 ah = __builtin_bit_cast(bf16x8, dh[i]), al = __builtin_bit_cast(bf16x8, dl[i]);
+                bf16x8 bh = __builtin_bit_cast(bf16x8, qh[i]), bl = __builtin_bit_cast(bf16x8, ql[i]);
+                acc_m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc_m, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc_c, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc_c, 0, 0, 0);
+            }
+        }
+        if (qj < nq) {
+            const uint32_t row0 = t * kTileRows + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int g = r >> 2, i = r & 3;
+                const uint32_t row = row0 + 8 * g + i;
+                float dot = acc_m[r] + acc_c[r];
+                float v;
+                if (KIND == SCAN_IP) {
+                    v = dot;
+                } else {
+                    const float a = (i == 0) ? ax[g].x : (i == 1) ? ax[g].y : (i == 2) ? ax[g].z : ax[g].w;
+                    v = (KIND == SCAN_L2) ? fmaf(2.0f, dot, -a) : dot * a;
+                }
+                v = (v == v) ? v + 0.0f : -__builtin_inff();
+                const uint64_t key = make_key(v, row);
+                if (row < n_rows && key > minkey) list_insert(list, klist, tid, key, minkey, minpos);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * klist; i += 256) stage[i] = 0;
+    __syncthreads();
+    for (int p = 0; p < klist; ++p) {
+        const uint64_t key = list[p * 256 + tid];
+        if (key == 0) continue;
+        int rank = 0;
+        for (int l = 0; l < 8; ++l) {
+            const int t2 = 64 * (l >> 1) + 32 * (l & 1) + qj;
+            for (int p2 = 0; p2 < klist; ++p2) rank += (list[p2 * 256 + t2] > key) ? 1 : 0;
+        }
+        if (rank < klist) stage[qj * klist + rank] = key;
+    }
+    __syncthreads();
+    uint64_t *out = part + (size_t)blockIdx.x * 32 * klist;
+    for (int i = tid; i < 32 * klist; i += 256) out[i] = stage[i];
+}
+
+// ---------------------------------------------------------------- exact metric
+
+// The reference's arithmetic for ONE (query, row) pair in float64, computed
+// by a whole wave; every lane returns the same value.
+//   inner_product    embeddings_metrics.py:20     -dot
+//   sqeuclidean_dist embeddings_metrics.py:40-43  doc_sq(f32, numpy order) - 2*dot + q_sq
+//   euclidean_dist   embeddings_metrics.py:50     sqrt of that (NaN if negative, as upstream)
+//   cosine_sim       embeddings_metrics.py:28-31  torch: unit doc row rounded to f32
+//                                                 (norm and division in f32), query unit in f64
+// `rank_value` returns the quantity the scan ranks by, in the scan's units.
+__device__ __forceinline__ double exact_metric_wave(const float *__restrict__ row, const double *__restrict__ q,
+                                                    int d, int metric, float doc_sq32, double q_sq,
+                                                    double q_norm, int lane, double *rank_value) {
+    if (metric == MIR_METRIC_COSINE_SIM) {
+        double s = 0.0;
+        for (int j = lane; j < d; j += 64) {
+            double x = (double)row[j];
+            s += x * x;
+        }
+        s = wave_sum(s);
+        const float dn = fmaxf((float)sqrt(s), 1e-8f);
+        const double qn = fmax(q_norm, 1e-8);
+        double c = 0.0;
+        for (int j = lane; j < d; j += 64) c += (double)__fdiv_rn(row[j], dn) * (q[j] / qn);
+        c = wave_sum(c);
+        *rank_value = c * qn;
+        return -c;
+    }
+    double dot = 0.0;
+    for (int j = lane; j < d; j += 64) dot += (double)row[j] * q[j];
+    dot = wave_sum(dot);
+    if (metric == MIR_METRIC_INNER_PRODUCT) {
+        *rank_value = dot;
+        return -dot;
+    }
+    const double sq = ((double)doc_sq32 - 2.0 * dot) + q_sq;
+    *rank_value = 2.0 * dot - (double)doc_sq32;
+    return metric == MIR_METRIC_SQEUCLIDEAN_DIST ? sq : sqrt(sq);
+}
+
+// (a better than b) under the reference's ordering: distance ascending, NaN
+// last (numpy sort order), then flattened row ascending (stable argsort).
+__device__ __forceinline__ bool dist_before(double da, uint32_t ra, double db, uint32_t rb) {
+    const bool na = da != da, nb = db != db;
+    if (na || nb) return na == nb ? ra < rb : nb;
+    return da < db || (da == db && ra < rb);
+}
+
+// One wave per row: out[row] = metric(query, docs[row]).  grid = ceil(n/4), block 256.
+__global__ __launch_bounds__(256) void metric_eval_kernel(const float *__restrict__ docs,
+                                                          const float *__restrict__ doc_sq, int64_t n, int d,
+                                                          const double *__restrict__ q,
+                                                          const double *__restrict__ q_sq,
+                                                          const double *__restrict__ q_norm, int metric,
+                                                          double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    double rv;
+    double dist = exact_metric_wave(docs + row * (int64_t)d, q, d, metric, doc_sq[row], q_sq[0], q_norm[0], lane, &rv);
+    if (lane == 0) out[row] = dist;
+}
+
+// ---------------------------------------------------------------- finalize
+
+// In-LDS bitonic sort, descending, n = power of two, 256 threads.
+__device__ inline void bitonic_sort_desc(uint64_t *keys, int n, int tid) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = tid; i < (n >> 1); i += 256) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const uint64_t a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct FinalizeArgs {
+    const uint64_t *part;   // [ngroups][nwg][32][klist]
+    int nwg;                // workgroups of the scan
+    int klist;
+    int k;
+    int b;
+    int d;
+    int metric;
+    const float *docs;      // f32 [n][d]
+    const float *doc_sq;    // f32 [n]
+    const float *max_norm;  // 1 float
+    const double *q;        // [b][d]
+    const double *q_sq;     // [b]
+    const double *q_norm;   // [b]
+    const int64_t *chunk_ids;  // [n] or null
+    const int32_t *doc_ids;    // [n] or null
+    int64_t row_offset;
+    int32_t *out_doc;
+    int64_t *out_chunk;
+    int64_t *out_row;
+    double *out_dist;
+    int32_t *out_count;
+    int32_t *out_flags;
+};
+
+// grid = b (one block per query), block = 256, static LDS 64 KiB + small.
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+    __shared__ uint64_t keys[kSortN];
+    __shared__ double c_dist[kMaxList];
+    __shared__ double c_rank[kMaxList];
+    __shared__ uint32_t c_row[kMaxList];
+    __shared__ double s_vk;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = blockIdx.x;
+    const int g = qi >> 5, ql = qi & 31;
+    const int klist = a.klist;
+    const uint64_t *pg = a.part + (size_t)g * a.nwg * 32 * klist;
+    const int m_total = a.nwg * klist;
+
+    // ---- 1. best klist candidate keys over all workgroups (chunked bitonic) ----
+    const int chunk = kSortN - kMaxList;
+    for (int i = tid; i < kMaxList; i += 256) keys[i] = 0;
+    for (int base = 0; base < m_total; base += chunk) {
+        for (int i = tid; i < chunk; i += 256) {
+            const int e = base + i;
+            uint64_t v = 0;
+            if (e < m_total) {
+                const int wg = e / klist, p = e - wg * klist;
+                v = pg[((size_t)wg * 32 + ql) * klist + p];
+            }
+            keys[kMaxList + i] = v;
+        }
+        bitonic_sort_desc(keys, kSortN, tid);  // begins and ends with a barrier
+        // survivors stay in keys[0..klist); clear the rest of the carry window
+        for (int i = klist + tid; i < kMaxList; i += 256) keys[i] = 0;
+        __syncthreads();
+    }
+    int nc = 0;
+    for (int i = 0; i < klist; ++i) nc += keys[i] != 0 ? 1 : 0;  // sorted: valid ones first
+
+    // ---- 2. re-score the candidates exactly (float64, reference formulas) ----
+    const double *q = a.q + (size_t)qi * a.d;
+    for (int c = wave; c < nc; c += 4) {
+        const uint32_t row = key_row(keys[c]);
+        double rv;
+        const double dist = exact_metric_wave(a.docs + (size_t)row * a.d, q, a.d, a.metric, a.doc_sq[row],
+                                              a.q_sq[qi], a.q_norm[qi], lane, &rv);
+        if (lane == 0) {
+            c_dist[c] = dist;
+            c_rank[c] = rv;
+            c_row[c] = row;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. order by (distance, row) and emit the first k ----
+    const int kout = a.k < nc ? a.k : nc;
+    if (tid < nc) {
+        int rank = 0;
+        for (int c = 0; c < nc; ++c)
+            if (c != tid && dist_before(c_dist[c], c_row[c], c_dist[tid], c_row[tid])) ++rank;
+        if (rank < a.k) {
+            const size_t o = (size_t)qi * a.k + rank;
+            const uint32_t row = c_row[tid];
+            if (a.out_row) a.out_row[o] = a.row_offset + (int64_t)row;
+            if (a.out_dist) a.out_dist[o] = c_dist[tid];
+            if (a.out_doc) a.out_doc[o] = a.doc_ids ? a.doc_ids[row] : 0;
+            if (a.out_chunk) a.out_chunk[o] = a.chunk_ids ? a.chunk_ids[row] : (int64_t)row;
+        }
+        if (rank == kout - 1) s_vk = c_rank[tid];
+    }
+    __syncthreads();
+
+    // ---- 4. a-posteriori completeness check ----
+    // Every row NOT among the candidates has scan value <= tau (the worst kept
+    // key); its exact value is <= tau + eps.  If that is below the exact value
+    // of the k-th result, no excluded row can belong to the top k.
+    if (tid == 0) {
+        if (a.out_count) a.out_count[qi] = kout;
+        int flag = 0;
+        if (nc == klist && kout > 0) {
+            const double tau = (double)key_value(keys[klist - 1]);
+            const double qn = a.q_norm[qi];
+            const double mx = (double)a.max_norm[0];
+            double eps = kScanRelErr * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0 : mx);
+            if (a.metric == MIR_METRIC_SQEUCLIDEAN_DIST || a.metric == MIR_METRIC_EUCLIDEAN_DIST) eps *= 2.0;
+            eps += 1e-6 * fabs(tau);
+            const double vk = s_vk;
+            if (!(tau + eps < vk)) flag = MIR_FLAG_UNCERTAIN;
+        }
+        if (a.out_flags) a.out_flags[qi] = flag;
+    }
+}
+
+// ---------------------------------------------------------------- shard merge
+
+// One block of 64 threads per query: merge s lists of <= k (dist, row) into k.
+__global__ __launch_bounds__(64) void merge_topk_kernel(const double *__restrict__ dist,
+                                                        const int64_t *__restrict__ row,
+                                                        const int32_t *__restrict__ count, int s, int b, int k,
+                                                        int descending, double *__restrict__ out_dist,
+                                                        int64_t *__restrict__ out_row,
+                                                        int32_t *__restrict__ out_count) {
+    const int qi = blockIdx.x;
+    int total = 0;
+    for (int sh = 0; sh < s; ++sh) total += count[sh * b + qi];
+    const int kout = total < k ? total : k;
+    // rank by counting; s*k is small (<= 8*64)
+    for (int e = threadIdx.x; e < s * k; e += 64) {
+        const int sh = e / k, p = e - sh * k;
+        if (p >= count[sh * b + qi]) continue;
+        const size_t me = ((size_t)sh * b + qi) * k + p;
+        const double dm = dist[me];
+        const int64_t rm = row[me];
+        int rank = 0;
+        for (int s2 = 0; s2 < s; ++s2) {
+            const int c2 = count[s2 * b + qi];
+            for (int p2 = 0; p2 < c2; ++p2) {
+                const size_t o = ((size_t)s2 * b + qi) * k + p2;
+                if (o == me) continue;
+                const double d2 = dist[o];
+                const int64_t r2 = row[o];
+                bool before;
+                if (!descending) {
+                    const bool n2 = d2 != d2, nm = dm != dm;
+                    if (n2 || nm) before = (n2 == nm) ? r2 < rm : nm;
+                    else before = d2 < dm || (d2 == dm && r2 < rm);
+                } else {
+                    before = d2 > dm || (d2 == dm && r2 > rm);
+                }
+                rank += before ? 1 : 0;
+            }
+        }
+        if (rank < kout) {
+            out_dist[(size_t)qi * k + rank] = dm;
+            out_row[(size_t)qi * k + rank] = rm;
+        }
+    }
+    if (threadIdx.x == 0) out_count[qi] = kout;
+}
+
+}  // namespace mir

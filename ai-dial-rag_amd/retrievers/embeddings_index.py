@@ -1,0 +1,231 @@
+"""Brute-force vector index, same surface as
+aidial_rag/retrievers/embeddings_index.py:14-164.
+
+``EmbeddingsIndex(retrieval_type, indexes, metric, limit).find(query)`` returns
+the same ``List[Document]`` as the reference: the global stable ordering on
+(distance, document position, row position) (embeddings_index.py:51-89).  The
+rows of all ``DocIndex`` objects are flattened in that order into ONE device
+index (``mir_index_create``); per query the GPU scans it once, re-scores the
+surviving candidates in float64 and breaks ties on the flattened row - which is
+exactly the reference's two-level stable argsort.
+
+Added over the reference (it has no batch API): ``find_batch`` and
+``search_arrays`` take B queries per pass; a single-query ``find`` is the B = 1
+case of the same kernels and returns identical results.
+"""
+
+import ctypes as C
+import threading
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import numpy.typing as npt
+
+from .. import _native as nat
+from ..index_record import Document, RetrievalType, to_metadata_doc
+from .embeddings_metrics import ENUM_TO_METRIC, Metric  # noqa: F401  (re-exported like upstream)
+
+
+class DocIndex:
+    """embeddings_index.py:14-30."""
+
+    chunk_ids: npt.NDArray[np.int64]
+    embeddings: np.ndarray
+
+    def __init__(self, chunk_ids: Optional[np.ndarray] = None, embeddings: Optional[np.ndarray] = None):
+        self.chunk_ids = chunk_ids if chunk_ids is not None else np.array([], dtype=np.int64)
+        self.embeddings = embeddings if embeddings is not None else np.array([], dtype=np.float32)
+
+
+class DeviceIndex:
+    """Owner of one ``mir_index`` handle (a flattened shard resident in HBM)."""
+
+    def __init__(self, handle: C.c_void_p, n: int, d: int, device: int):
+        self._h = handle
+        self.n, self.d, self.device = n, d, device
+
+    @classmethod
+    def from_host(cls, emb: np.ndarray, chunk_ids=None, doc_ids=None, device: int = 0, row_offset: int = 0):
+        emb = np.ascontiguousarray(emb, dtype=np.float32)
+        if emb.ndim != 2:
+            raise ValueError(f"embeddings must be [n, d], got {emb.shape}")
+        n, d = emb.shape
+        ci = None if chunk_ids is None else np.ascontiguousarray(chunk_ids, dtype=np.int64)
+        di = None if doc_ids is None else np.ascontiguousarray(doc_ids, dtype=np.int32)
+        h = C.c_void_p()
+        nat.check(nat.lib.mir_index_create(nat.ptr(emb), n, d, nat.DTYPE_F32, nat.ptr(ci), nat.ptr(di), device, row_offset, C.byref(h)))
+        return cls(h, n, d, device)
+
+    @classmethod
+    def from_device_ptr(cls, emb_ptr: int, n: int, d: int, device: int, row_offset: int = 0, chunk_ids_ptr: int = 0,
+                        doc_ids_ptr: int = 0, stream: int = 0):
+        """Build from a float32 [n, d] matrix already in HBM (e.g. ``tensor.data_ptr()``)."""
+        h = C.c_void_p()
+        nat.check(nat.lib.mir_index_create_from_device(emb_ptr or None, n, d, nat.DTYPE_F32, chunk_ids_ptr or None,
+                                                       doc_ids_ptr or None, device, row_offset, stream or None, C.byref(h)))
+        return cls(h, n, d, device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def hbm_bytes(self) -> int:
+        b = C.c_int64(0)
+        nat.check(nat.lib.mir_index_info(self._h, None, None, None, None, C.byref(b)))
+        return int(b.value)
+
+    def search(self, queries: np.ndarray, k: int, metric) -> Tuple[np.ndarray, ...]:
+        """-> (doc_ids[b,k] i32, chunk_ids[b,k] i64, rows[b,k] i64, dist[b,k] f64, count[b] i32, flags[b] i32)"""
+        q = nat.as_f64_queries(queries, self.d)
+        b = q.shape[0]
+        code = nat.METRIC_CODES[Metric(metric).value]
+        doc = np.zeros((b, k), np.int32)
+        chunk = np.zeros((b, k), np.int64)
+        row = np.zeros((b, k), np.int64)
+        dist = np.zeros((b, k), np.float64)
+        cnt = np.zeros(b, np.int32)
+        flg = np.zeros(b, np.int32)
+        nat.check(nat.lib.mir_index_search(self._h, nat.ptr(q), b, k, code, nat.ptr(doc), nat.ptr(chunk), nat.ptr(row),
+                                           nat.ptr(dist), nat.ptr(cnt), nat.ptr(flg)))
+        return doc, chunk, row, dist, cnt, flg
+
+    def search_device(self, q_ptr: int, b: int, k: int, metric, out_row_ptr: int, out_dist_ptr: int, out_count_ptr: int,
+                      out_flags_ptr: int = 0, out_doc_ptr: int = 0, out_chunk_ptr: int = 0, stream: int = 0) -> None:
+        """Asynchronous search with every buffer in HBM (pointers as ints)."""
+        code = nat.METRIC_CODES[Metric(metric).value]
+        nat.check(nat.lib.mir_index_search_device(self._h, q_ptr, b, k, code, out_doc_ptr or None, out_chunk_ptr or None,
+                                                  out_row_ptr or None, out_dist_ptr or None, out_count_ptr,
+                                                  out_flags_ptr or None, stream or None))
+
+    def metric_eval(self, query: np.ndarray, metric) -> np.ndarray:
+        q = nat.as_f64_queries(query, self.d)[0]
+        out = np.empty(self.n, np.float64)
+        nat.check(nat.lib.mir_index_metric_eval(self._h, nat.ptr(q), nat.METRIC_CODES[Metric(metric).value], nat.ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            nat.lib.mir_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class EmbeddingsIndex:
+    """embeddings_index.py:33-89."""
+
+    retrieval_type: RetrievalType
+    doc_indexes: List[DocIndex]
+    metric: str
+    limit: int
+
+    def __init__(self, retrieval_type: RetrievalType, indexes: List[DocIndex], metric: Metric = Metric.SQEUCLIDEAN_DIST,
+                 limit: int = 1, device: int = 0):
+        self.retrieval_type = retrieval_type
+        self.metric = metric
+        self.limit = limit
+        self.doc_indexes = indexes
+        self.device = device
+        self._dev: Optional[DeviceIndex] = None
+        self._lock = threading.Lock()
+
+    def _device_index(self) -> Optional[DeviceIndex]:
+        """Flatten non-empty documents in order (embeddings_index.py:67-69) and upload once."""
+        with self._lock:
+            if self._dev is None:
+                embs, chunk_ids, doc_ids = [], [], []
+                for i, doc in enumerate(self.doc_indexes):
+                    if len(doc.embeddings) == 0:
+                        continue
+                    e = np.asarray(doc.embeddings, dtype=np.float32)
+                    embs.append(e)
+                    chunk_ids.append(np.asarray(doc.chunk_ids, dtype=np.int64))
+                    doc_ids.append(np.full(len(e), i, dtype=np.int32))
+                if not embs:
+                    return None
+                self._dev = DeviceIndex.from_host(np.concatenate(embs), np.concatenate(chunk_ids), np.concatenate(doc_ids), self.device)
+            return self._dev
+
+    def search_arrays(self, queries: np.ndarray):
+        """B queries -> (doc_ids, chunk_ids, dist, count, flags) arrays, best first."""
+        Metric(self.metric)  # unknown metric -> ValueError, as embeddings_index.py:54
+        dev = self._device_index()
+        if dev is None:
+            q = np.atleast_2d(np.asarray(queries))
+            b = q.shape[0]
+            z = np.zeros((b, 0))
+            return z.astype(np.int32), z.astype(np.int64), z, np.zeros(b, np.int32), np.zeros(b, np.int32)
+        doc, chunk, _row, dist, cnt, flg = dev.search(queries, self.limit, self.metric)
+        return doc, chunk, dist, cnt, flg
+
+    def find_batch(self, queries: np.ndarray) -> List[List[Document]]:
+        doc, chunk, _dist, cnt, _ = self.search_arrays(queries)
+        return [
+            [to_metadata_doc(int(doc[b, j]), int(chunk[b, j]), retrieval_type=self.retrieval_type) for j in range(int(cnt[b]))]
+            for b in range(len(cnt))
+        ]
+
+    def find(self, query: np.ndarray) -> List[Document]:
+        return self.find_batch(np.asarray(query)[None, :])[0]
+
+
+def _get_page_index(chunk) -> int:
+    # embeddings_index.py:92-94: page numbers are 1-based
+    return chunk.metadata["page_number"] - 1
+
+
+def _item_rows(item) -> np.ndarray:
+    """Rows of one MultiEmbeddings item: an ``.embeddings`` attribute (docarray ItemEmbeddings) or a bare array."""
+    return np.asarray(getattr(item, "embeddings", item))
+
+
+def create_index_by_page(chunks: Sequence, pages_embeddings: Optional[Sequence]) -> DocIndex:
+    """embeddings_index.py:101-118."""
+    if pages_embeddings is None:
+        return DocIndex()
+    ids: List[int] = []
+    rows: List[np.ndarray] = []
+    for i, chunk in enumerate(chunks):
+        emb = _item_rows(pages_embeddings[_get_page_index(chunk)])
+        ids.extend([i] * len(emb))
+        rows.extend(emb)
+    return DocIndex(chunk_ids=np.array(ids, dtype=np.int64), embeddings=np.array(rows, dtype=np.float32))
+
+
+def create_index_by_chunk(chunks_embeddings: Optional[Sequence]) -> DocIndex:
+    """embeddings_index.py:121-136."""
+    if chunks_embeddings is None:
+        return DocIndex()
+    ids: List[int] = []
+    rows: List[np.ndarray] = []
+    for i, item in enumerate(chunks_embeddings):
+        emb = _item_rows(item)
+        ids.extend([i] * len(emb))
+        rows.extend(emb)
+    return DocIndex(chunk_ids=np.array(ids, dtype=np.int64), embeddings=np.array(rows))
+
+
+class ItemEmbeddings:
+    """document_record.py:34-39: the embeddings of one chunk or page, [m, d] float32."""
+
+    __slots__ = ("embeddings",)
+
+    def __init__(self, embeddings: np.ndarray):
+        self.embeddings = embeddings
+
+
+def pack_multi_embeddings(indexes: List[int], embeddings: Iterable[np.ndarray], number_of_pages: int) -> List[ItemEmbeddings]:
+    """embeddings_index.py:139-153."""
+    pages: List[list] = [[] for _ in range(number_of_pages)]
+    for page_index, e in zip(indexes, embeddings):
+        pages[page_index].append(e)
+    return [ItemEmbeddings(np.array(p, dtype=np.float32)) for p in pages]
+
+
+def pack_simple_embeddings(embeddings: Iterable[np.ndarray]) -> List[ItemEmbeddings]:
+    """embeddings_index.py:156-164."""
+    return [ItemEmbeddings(np.array([e], dtype=np.float32)) for e in embeddings]

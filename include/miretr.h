@@ -1,0 +1,144 @@
+/*
+ * miretr.h - C ABI of libmiretr.so: the MI355X (gfx950) retrieval hot path of
+ * epam/ai-dial-rag, built from scratch in HIP.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only: no torch, no
+ * C++ types.  The reference is pure Python and dictates no FFI of its own
+ * (SURVEY.md 8(b)); every entry point below names the reference interface it
+ * replaces (paths relative to the upstream repo root), and INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns an int32 status (MIR_OK == 0) and never aborts;
+ *     mir_last_error() returns a thread-local message for the last failure.
+ *   - "host" pointers are ordinary process memory, borrowed for the call.
+ *     "_device" entry points take HBM pointers valid on the index's device
+ *     and enqueue on the given hipStream_t (passed as void*); they do not
+ *     synchronise.
+ *   - handles are opaque, thread-safe and re-entrant: concurrent searches on
+ *     one handle are allowed (the reference calls `find` from several
+ *     executor threads at once, semantic_retriever.py:54-56).
+ *   - the library sets the device it needs per call (never relies on the
+ *     ambient device).
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute
+ *     entry point fails with MIR_ERR_NO_DEVICE.
+ */
+#ifndef MIRETR_H
+#define MIRETR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIR_ABI_VERSION 1
+
+/* status codes */
+#define MIR_OK 0
+#define MIR_ERR_INVALID 1     /* bad argument (maps to ValueError) */
+#define MIR_ERR_HIP 2         /* HIP runtime failure */
+#define MIR_ERR_NO_DEVICE 3   /* no usable GPU */
+#define MIR_ERR_EMPTY 4       /* "Text index is empty." (bm25_retriever.py:75-76) */
+#define MIR_ERR_UNSUPPORTED 5 /* valid request outside what this build handles */
+
+/* aidial_rag/retrievers/embeddings_metrics.py:7-11 (Metric), same order as
+ * the string values are listed there.  All metrics are "smaller is better". */
+#define MIR_METRIC_COSINE_SIM 0
+#define MIR_METRIC_EUCLIDEAN_DIST 1
+#define MIR_METRIC_SQEUCLIDEAN_DIST 2
+#define MIR_METRIC_INNER_PRODUCT 3
+
+/* element type of the stored embedding matrix */
+#define MIR_DTYPE_F32 0
+#define MIR_DTYPE_F16 1
+
+/* per-query result flags (out_flags) */
+#define MIR_FLAG_UNCERTAIN 1 /* the a-posteriori exactness check could not prove
+                                the candidate set complete (exact ties at the
+                                cut, or scores denser than the scan's error
+                                bound); results are still the best found */
+
+int32_t mir_abi_version(void);
+const char *mir_last_error(void);
+int32_t mir_device_count(int32_t *out_count);
+
+/* ------------------------------------------------------------------------
+ * Vector index: replaces EmbeddingsIndex / DocIndex
+ * (aidial_rag/retrievers/embeddings_index.py:14-89).
+ *
+ * One handle holds the flattened rows of all DocIndex objects of one
+ * EmbeddingsIndex, in (doc_index, row) order - the order that defines the
+ * reference's tie-break (stable argsort per document, then across documents,
+ * embeddings_index.py:57-58,81).  `doc_ids[i]` / `chunk_ids[i]` are the
+ * (doc_id, chunk_id) pair `to_metadata_doc` would receive for row i
+ * (index_record.py:29-38).  NULL chunk_ids means 0..n-1, NULL doc_ids means 0.
+ * `row_offset` is the global index of local row 0 when the handle is one
+ * row-shard of a larger index (multi-GPU); returned row numbers include it.
+ * ---------------------------------------------------------------------- */
+typedef struct mir_index mir_index;
+
+int32_t mir_index_create(const void *emb_host, int64_t n, int32_t d, int32_t dtype,
+                         const int64_t *chunk_ids_host, const int32_t *doc_ids_host,
+                         int32_t device, int64_t row_offset, mir_index **out);
+
+/* Same, from a matrix already in HBM on `device` (e.g. the encoder's output).
+ * The matrix is copied; the caller keeps ownership of its buffers. */
+int32_t mir_index_create_from_device(const void *emb_device, int64_t n, int32_t d, int32_t dtype,
+                                     const int64_t *chunk_ids_device, const int32_t *doc_ids_device,
+                                     int32_t device, int64_t row_offset, void *stream, mir_index **out);
+
+int32_t mir_index_destroy(mir_index *idx);
+
+/* n rows, dimension, dtype, device, bytes of HBM held */
+int32_t mir_index_info(const mir_index *idx, int64_t *n, int32_t *d, int32_t *dtype, int32_t *device,
+                       int64_t *hbm_bytes);
+
+/* EmbeddingsIndex.find for a batch of queries (embeddings_index.py:62-89).
+ * queries_host: double[b][d] - the live path hands a float64 query
+ * (semantic_retriever.py:49,53); a float32 caller widens exactly.
+ * Outputs, each [b][k], filled for the first out_count[q] entries of row q:
+ *   out_doc / out_chunk : the (doc_id, chunk_id) pairs, best first
+ *   out_row             : global flattened row (row_offset + local row)
+ *   out_dist            : the metric value in float64 (reference promotion)
+ * out_count[q] = min(k, n).  out_flags may be NULL.
+ * Any of out_doc / out_chunk / out_row / out_dist may be NULL. */
+int32_t mir_index_search(mir_index *idx, const double *queries_host, int32_t b, int32_t k, int32_t metric,
+                         int32_t *out_doc, int64_t *out_chunk, int64_t *out_row, double *out_dist,
+                         int32_t *out_count, int32_t *out_flags);
+
+/* The same with every buffer in HBM, asynchronous on `stream`. */
+int32_t mir_index_search_device(mir_index *idx, const double *queries_device, int32_t b, int32_t k,
+                                int32_t metric, int32_t *out_doc, int64_t *out_chunk, int64_t *out_row,
+                                double *out_dist, int32_t *out_count, int32_t *out_flags, void *stream);
+
+/* ENUM_TO_METRIC[metric](query, docs) -> float64[n]
+ * (embeddings_metrics.py:53-58) over all rows of the index, on the GPU.
+ * query_host: double[d]; out_host: double[n]. */
+int32_t mir_index_metric_eval(mir_index *idx, const double *query_host, int32_t metric, double *out_host);
+
+/* One-shot form of the same for a host matrix that is not an index
+ * (the reference's metric functions are called on bare arrays in its tests). */
+int32_t mir_metric_eval(const void *docs_host, int64_t n, int32_t d, int32_t dtype, const double *query_host,
+                        int32_t metric, int32_t device, double *out_host);
+
+/* ------------------------------------------------------------------------
+ * Cross-shard merge: the step after the all-gather of per-shard partial
+ * top-k (does not exist in the reference; it is the second stable argsort of
+ * embeddings_index.py:81 applied across shards).  Inputs are [s][b][k]
+ * (shard-major) with counts [s][b]; ordering is (dist ascending, NaN last,
+ * row ascending).  For BM25 pass descending_scores = 1: ordering becomes
+ * (score descending, row DESCENDING), the reversed stable argsort of
+ * bm25_retriever.py:84.
+ * ---------------------------------------------------------------------- */
+int32_t mir_topk_merge_device(const double *dist, const int64_t *row, const int32_t *count, int32_t s,
+                              int32_t b, int32_t k, int32_t descending_scores, double *out_dist,
+                              int64_t *out_row, int32_t *out_count, int32_t device, void *stream);
+int32_t mir_topk_merge_host(const double *dist, const int64_t *row, const int32_t *count, int32_t s,
+                            int32_t b, int32_t k, int32_t descending_scores, double *out_dist,
+                            int64_t *out_row, int32_t *out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRETR_H */

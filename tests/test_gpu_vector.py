@@ -1,0 +1,282 @@
+"""GPU parity: the HIP vector path (through the C ABI) against the CPU oracle,
+the golden vectors recorded from the reference, and the reference's own
+known-answer / tie-break cases.  Tolerances: ids identical (bit-exact index
+work); distances within 1e-4 as north_star states (observed ~1e-12 on the
+float64 path, asserted tighter where the arithmetic allows)."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+METRICS = ["cosine_sim", "euclidean_dist", "sqeuclidean_dist", "inner_product"]
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from aidial_rag_amd import _native
+    from aidial_rag_amd.index_record import RetrievalType, to_metadata_doc
+    from aidial_rag_amd.retrievers import embeddings_index as ei
+    from aidial_rag_amd.retrievers import embeddings_metrics as em
+
+    assert _native.device_count() >= 1, "no GPU visible: the product path has no CPU fallback"
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.nat, ns.ei, ns.em, ns.RetrievalType, ns.to_metadata_doc = _native, ei, em, RetrievalType, to_metadata_doc
+    return ns
+
+
+def unit(x):
+    return (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(np.float32)
+
+
+# cosine only: the reference normalises float32 doc rows in float32 through torch, whose norm
+# reduction order is CPU-specific; its own scores carry ~1e-7 noise (see test_oracle_metrics),
+# so ids are compared up to ties within that noise.  Every other metric: ids identical.
+COS_NOISE = 2e-7
+
+
+def assert_same_ids(metric, got_rows, want_rows, oracle_dist_of_row, msg=""):
+    got_rows, want_rows = np.asarray(got_rows), np.asarray(want_rows)
+    assert len(got_rows) == len(want_rows), msg
+    if metric != "cosine_sim":
+        np.testing.assert_array_equal(got_rows, want_rows, err_msg=msg)
+        return
+    for g, w in zip(got_rows, want_rows):
+        if g != w:
+            assert abs(oracle_dist_of_row(g) - oracle_dist_of_row(w)) <= COS_NOISE, f"{msg}: {g} vs {w}"
+
+
+# ---------------------------------------------------------------- metrics
+
+def test_metric_known_answers(amd, golden_dir):
+    data = json.load(open(os.path.join(golden_dir, "metrics_known.json")))
+    for c in data["cases"]:
+        q = np.array(c["query"], dtype=c["query_dtype"])
+        d = np.array(c["docs"], dtype=c["docs_dtype"])
+        out = amd.em.ENUM_TO_METRIC[amd.em.Metric(c["metric"])](q, d)
+        np.testing.assert_allclose(out, np.array(c["asserted"]), rtol=1e-7, atol=0)
+        assert str(out.dtype) == c["reference_dtype"]
+    with pytest.raises(ValueError):
+        amd.em.Metric("bad")
+
+
+@pytest.mark.parametrize("tag", ["384", "1024"])
+@pytest.mark.parametrize("metric", METRICS)
+def test_metric_random_vs_reference_golden(amd, golden_dir, tag, metric):
+    z = np.load(os.path.join(golden_dir, "metrics_random.npz"))
+    docs, qs = z[f"docs{tag}"], z[f"q{tag}"]
+    f = amd.em.ENUM_TO_METRIC[amd.em.Metric(metric)]
+    scale = 1.0 if tag == "384" else 1024.0
+    for i, q in enumerate(qs):
+        o64 = f(q.astype(np.float64), docs)
+        assert o64.dtype == np.float64
+        atol = 1.5e-7 if metric == "cosine_sim" else 1e-11 * scale
+        np.testing.assert_allclose(o64, z[f"{metric}_{tag}_f64"][i], rtol=0, atol=atol)
+        o32 = f(q, docs)
+        assert o32.dtype == np.float32
+        np.testing.assert_allclose(o32, z[f"{metric}_{tag}_f32"][i], rtol=0, atol=1e-4 * scale)
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_metric_ties_nan_zero(amd, golden_dir, metric):
+    z = np.load(os.path.join(golden_dir, "metrics_ties.npz"))
+    docs, queries = z["docs"], z["queries"]
+    f = amd.em.ENUM_TO_METRIC[amd.em.Metric(metric)]
+    for i, q in enumerate(queries):
+        o = f(q.astype(np.float64), docs)
+        ref = z[f"{metric}_f64"][i]
+        np.testing.assert_array_equal(np.isnan(o), np.isnan(ref))
+        # euclid: sqrt amplifies the 1e-16 summation-order noise of a ~1e-8 squared distance
+        atol = {"cosine_sim": 1.5e-7, "euclidean_dist": 1e-10}.get(metric, 1e-12)
+        np.testing.assert_allclose(o, ref, rtol=0, atol=atol, equal_nan=True)
+
+
+def test_doc_sq_is_numpy_bit_exact(amd):
+    """sqeuclid with a zero query is exactly float64(np.sum(docs**2, axis=1))."""
+    rng = np.random.default_rng(11)
+    for d in (3, 7, 8, 13, 100, 128, 129, 384, 1000, 1024):
+        docs = rng.standard_normal((77, d)).astype(np.float32)
+        out = amd.em.ENUM_TO_METRIC[amd.em.Metric.SQEUCLIDEAN_DIST](np.zeros(d), docs)
+        np.testing.assert_array_equal(out, np.sum(docs**2, axis=1).astype(np.float64))
+
+
+# ---------------------------------------------------------------- index
+
+def test_reference_index_cases(amd, golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "index_cases.json")))
+    docs = {
+        k: amd.ei.DocIndex(np.array(v["chunk_ids"], dtype=np.int64), np.array(v["embeddings"], dtype=np.float32))
+        for k, v in cases["docs"].items()
+    }
+    for case in cases["cases"]:
+        for metric in cases["metrics"]:
+            ix = amd.ei.EmbeddingsIndex(
+                amd.RetrievalType.TEXT, [docs[d] for d in case["doc_order"]], metric=amd.em.Metric(metric), limit=case["limit"]
+            )
+            got = ix.find(np.array(case["query"]))
+            want = [amd.to_metadata_doc(a, b, amd.RetrievalType.TEXT) for a, b in case["expected"]]
+            assert got == want, (case["name"], metric, got)
+
+
+def test_unknown_metric_raises(amd):
+    ix = amd.ei.EmbeddingsIndex(amd.RetrievalType.TEXT, [amd.ei.DocIndex(np.array([0]), np.ones((1, 3), np.float32))], metric="bad", limit=1)
+    with pytest.raises(ValueError):
+        ix.find(np.ones(3))
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_ties_resolve_like_stable_argsort(amd, golden_dir, metric):
+    from oracle import embeddings_index as oi
+
+    z = np.load(os.path.join(golden_dir, "metrics_ties.npz"))
+    docs, queries = z["docs"], z["queries"]
+    dev = amd.ei.DeviceIndex.from_host(docs)
+    for k in (1, 3, 10, 40, 56):
+        _, _, rows, dist, cnt, _ = dev.search(queries.astype(np.float64), k, metric)
+        for i, q in enumerate(queries):
+            with np.errstate(invalid="ignore"):
+                wrows, wdist = oi.find_flat(q.astype(np.float64), docs, metric, k)
+            n_ok = int(cnt[i])
+            assert n_ok == len(wrows)
+            if metric == "cosine_sim" and i == 3:
+                continue  # zero query: every cosine is +-0, order is by row; checked below
+            with np.errstate(invalid="ignore"):
+                alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](q.astype(np.float64), docs)
+            assert_same_ids(metric, rows[i, :n_ok], wrows, lambda r: alld[r], f"{metric} k={k} q={i}")
+            np.testing.assert_allclose(dist[i, :n_ok], wdist, rtol=0, atol=2e-7, equal_nan=True)
+    # all-equal distances (zero query under cosine) come back in row order
+    _, _, rows, dist, cnt, _ = dev.search(np.zeros((1, 384)), 10, "cosine_sim")
+    np.testing.assert_array_equal(rows[0], np.arange(10))
+    assert (dist[0] == 0).all()
+
+
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("n,d", [(1, 3), (5, 3), (31, 16), (33, 17), (1000, 100), (4097, 384), (700, 1024), (300, 520)])
+def test_shapes_vs_oracle(amd, metric, n, d):
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(n * 1000 + d)
+    docs = rng.standard_normal((n, d)).astype(np.float32)
+    if metric in ("cosine_sim", "inner_product") or n % 2:
+        docs = unit(docs)
+    qs = rng.standard_normal((5, d))
+    dev = amd.ei.DeviceIndex.from_host(docs)
+    for k in (1, 7, 10):
+        _, chunk, rows, dist, cnt, flags = dev.search(qs, k, metric)
+        for i, q in enumerate(qs):
+            wrows, wdist = oi.find_flat(q, docs, metric, k)
+            assert cnt[i] == len(wrows) == min(k, n)
+            alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](q, docs)
+            assert_same_ids(metric, rows[i, : cnt[i]], wrows, lambda r: alld[r], f"{metric} n={n} d={d} k={k}")
+            np.testing.assert_array_equal(chunk[i, : cnt[i]], rows[i, : cnt[i]])
+            np.testing.assert_allclose(dist[i, : cnt[i]], wdist, rtol=1e-9, atol=1e-4)
+            np.testing.assert_allclose(dist[i, : cnt[i]], wdist, rtol=1e-6, atol=2e-7 * d)
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_many_documents_pairs_vs_oracle(amd, metric):
+    """(doc_id, chunk_id) pairs over 300 ragged documents incl. empty ones and a page-style index with repeated chunk ids."""
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(42)
+    sizes = rng.integers(0, 40, 300)
+    parts = [unit(rng.standard_normal((m, 384))) if m else np.zeros((0, 384), np.float32) for m in sizes]
+    parts[7][3] = parts[2][0]
+    parts[200][1] = parts[2][0]
+    chunk_ids = [np.sort(rng.integers(0, max(1, m // 2 + 1), m)).astype(np.int64) for m in sizes]  # repeats
+    mine = [amd.ei.DocIndex(c, p) if len(p) else amd.ei.DocIndex() for c, p in zip(chunk_ids, parts)]
+    theirs = [oi.DocIndex(c, p) if len(p) else oi.DocIndex() for c, p in zip(chunk_ids, parts)]
+    qs = np.concatenate([parts[2][0][None].astype(np.float64), rng.standard_normal((7, 384))])
+    ix = amd.ei.EmbeddingsIndex(amd.RetrievalType.IMAGE, mine, metric=metric, limit=7)
+    got = ix.find_batch(qs)
+    single = [ix.find(q) for q in qs]
+    assert got == single  # B=1 and B=8 passes agree
+    for q, res in zip(qs, got):
+        with np.errstate(invalid="ignore"):
+            want, _ = oi.find(q, theirs, metric, 7)
+        assert [(d.metadata["doc_id"], d.metadata["chunk_id"]) for d in res] == want
+        assert all(d.metadata["retrieval_type"] == amd.RetrievalType.IMAGE for d in res)
+        assert all(d.page_content == f'{d.metadata["doc_id"]}_{d.metadata["chunk_id"]}' for d in res)
+
+
+def test_batches_larger_than_a_query_group(amd):
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(3)
+    docs = unit(rng.standard_normal((20000, 384)))
+    qs = unit(rng.standard_normal((70, 384))).astype(np.float64)
+    dev = amd.ei.DeviceIndex.from_host(docs)
+    _, _, rows, dist, cnt, flags = dev.search(qs, 10, "sqeuclidean_dist")
+    assert (cnt == 10).all() and (flags == 0).all()
+    for i in range(70):
+        wrows, wdist = oi.find_flat(qs[i], docs, "sqeuclidean_dist", 10)
+        np.testing.assert_array_equal(rows[i], wrows)
+        np.testing.assert_allclose(dist[i], wdist, rtol=0, atol=1e-12)
+
+
+def test_k_above_list_capacity_is_refused_not_wrong(amd):
+    rng = np.random.default_rng(4)
+    dev = amd.ei.DeviceIndex.from_host(unit(rng.standard_normal((500, 32))))
+    with pytest.raises(NotImplementedError):
+        dev.search(rng.standard_normal((1, 32)), 100, "inner_product")
+    small = amd.ei.DeviceIndex.from_host(unit(rng.standard_normal((40, 32))))
+    _, _, rows, _, cnt, _ = small.search(rng.standard_normal((1, 32)), 100, "inner_product")
+    assert cnt[0] == 40 and sorted(rows[0, :40]) == list(range(40))
+
+
+def test_concurrent_searches_share_a_handle(amd):
+    import threading
+
+    rng = np.random.default_rng(8)
+    docs = unit(rng.standard_normal((30000, 384)))
+    dev = amd.ei.DeviceIndex.from_host(docs)
+    qs = rng.standard_normal((16, 384))
+    want = dev.search(qs, 7, "cosine_sim")[2]
+    out = [None] * 8
+
+    def work(t):
+        out[t] = [dev.search(qs[2 * t : 2 * t + 2], 7, "cosine_sim")[2] for _ in range(5)]
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for t in range(8):
+        for r in out[t]:
+            np.testing.assert_array_equal(r, want[2 * t : 2 * t + 2])
+
+
+def test_merge_device_matches_host(amd):
+    import ctypes as C
+
+    import torch
+
+    rng = np.random.default_rng(9)
+    s, b, k = 4, 6, 5
+    dist = np.round(rng.standard_normal((s, b, k)), 1)
+    dist[1, 2, 3] = np.nan
+    dist.sort(axis=2)
+    row = rng.permutation(s * b * k).reshape(s, b, k).astype(np.int64)
+    cnt = rng.integers(0, k + 1, (s, b)).astype(np.int32)
+    for desc in (0, 1):
+        hd, hr, hc = np.zeros((b, k)), np.zeros((b, k), np.int64), np.zeros(b, np.int32)
+        amd.nat.check(amd.nat.lib.mir_topk_merge_host(amd.nat.ptr(dist), amd.nat.ptr(row), amd.nat.ptr(cnt), s, b, k, desc,
+                                                      amd.nat.ptr(hd), amd.nat.ptr(hr), amd.nat.ptr(hc)))
+        td, tr, tc = (torch.from_numpy(x).cuda() for x in (dist, row, cnt))
+        od = torch.zeros((b, k), dtype=torch.float64, device="cuda")
+        orow = torch.zeros((b, k), dtype=torch.int64, device="cuda")
+        oc = torch.zeros(b, dtype=torch.int32, device="cuda")
+        amd.nat.check(amd.nat.lib.mir_topk_merge_device(td.data_ptr(), tr.data_ptr(), tc.data_ptr(), s, b, k, desc,
+                                                        od.data_ptr(), orow.data_ptr(), oc.data_ptr(), 0,
+                                                        torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(oc.cpu().numpy(), hc)
+        for q in range(b):
+            np.testing.assert_array_equal(orow.cpu().numpy()[q, : hc[q]], hr[q, : hc[q]])
+            np.testing.assert_array_equal(od.cpu().numpy()[q, : hc[q]], hd[q, : hc[q]])
