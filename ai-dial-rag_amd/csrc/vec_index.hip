@@ -90,6 +90,11 @@ struct mir_index {
     int64_t hbm_bytes = 0;
     std::mutex mu;
     std::vector<Workspace *> pool;
+    // benchmark instrumentation (mir_index_profile)
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    int64_t prof_launches = 0;
+    double prof_ms = 0.0;
 };
 
 namespace mir {
@@ -103,6 +108,10 @@ static void free_index(mir_index *ix) {
         if (w->done) (void)hipEventDestroy(w->done);
         if (w->stream) (void)hipStreamDestroy(w->stream);
         delete w;
+    }
+    for (auto &pr : ix->prof_events) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
     }
     (void)hipFree(ix->d_orig);
     (void)hipFree(ix->d_split);
@@ -320,6 +329,12 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                                                                                sb.qsplit, sb.q_sq, sb.q_norm);
     MIR_HIP(hipGetLastError());
     for (int g = 0; g < ngroups; ++g) {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (ix->profiling) {
+            MIR_HIP(hipEventCreate(&ev0));
+            MIR_HIP(hipEventCreate(&ev1));
+            MIR_HIP(hipEventRecord(ev0, stream));
+        }
         const uint4 *qs = sb.qsplit + (size_t)g * ix->ksteps * 128;
         uint64_t *pg = sb.part + (size_t)g * nwg * 32 * klist;
         const int nq = std::min(32, b - 32 * g);
@@ -327,6 +342,11 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         if (metric == MIR_METRIC_INNER_PRODUCT) rc = launch_scan<SCAN_IP>(ix, qs, nq, klist, nwg, pg, stream);
         else if (metric == MIR_METRIC_COSINE_SIM) rc = launch_scan<SCAN_COS>(ix, qs, nq, klist, nwg, pg, stream);
         else rc = launch_scan<SCAN_L2>(ix, qs, nq, klist, nwg, pg, stream);
+        if (ev1) {
+            (void)hipEventRecord(ev1, stream);
+            std::lock_guard<std::mutex> lk(ix->mu);
+            ix->prof_events.emplace_back(ev0, ev1);
+        }
         if (rc != MIR_OK) return rc;
     }
     FinalizeArgs fa;
@@ -455,6 +475,47 @@ int32_t mir_index_info(const mir_index *idx, int64_t *n, int32_t *d, int32_t *dt
     return MIR_OK;
 }
 
+int32_t mir_index_profile(mir_index *idx, int32_t enable) {
+    MIR_REQUIRE(idx != nullptr, "index is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->profiling = enable != 0;
+    return MIR_OK;
+}
+
+int32_t mir_index_profile_read(mir_index *idx, int32_t reset, int64_t *launches, double *total_ms) {
+    MIR_REQUIRE(idx != nullptr, "index is NULL");
+    int32_t rc = use_device(idx->device, nullptr);
+    if (rc != MIR_OK) return rc;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);
+        ev.swap(idx->prof_events);
+    }
+    double ms = 0.0;
+    for (auto &pr : ev) {
+        float t = 0.f;
+        hipError_t e = hipEventSynchronize(pr.second);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, pr.first, pr.second);
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+        if (e != hipSuccess) {
+            set_error("profile read failed: %s", hipGetErrorString(e));
+            return MIR_ERR_HIP;
+        }
+        ms += t;
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->prof_launches += (int64_t)ev.size();
+    idx->prof_ms += ms;
+    if (launches) *launches = idx->prof_launches;
+    if (total_ms) *total_ms = idx->prof_ms;
+    if (reset) {
+        idx->prof_launches = 0;
+        idx->prof_ms = 0.0;
+    }
+    return MIR_OK;
+}
+
 int32_t mir_index_search_device(mir_index *idx, const double *queries_device, int32_t b, int32_t k,
                                 int32_t metric, int32_t *out_doc, int64_t *out_chunk, int64_t *out_row,
                                 double *out_dist, int32_t *out_count, int32_t *out_flags, void *stream_) {
@@ -579,26 +640,36 @@ int32_t mir_metric_eval(const void *docs_host, int64_t n, int32_t d, int32_t dty
     return rc;
 }
 
-int32_t mir_topk_merge_device(const double *dist, const int64_t *row, const int32_t *count, int32_t s, int32_t b,
-                              int32_t k, int32_t descending_scores, double *out_dist, int64_t *out_row,
-                              int32_t *out_count, int32_t device, void *stream) {
+int32_t mir_topk_merge_device(const double *dist, const int64_t *row, const int32_t *count, int32_t s,
+                              int64_t shard_stride_bytes, int32_t b, int32_t k, int32_t descending_scores,
+                              double *out_dist, int64_t *out_row, int32_t *out_count, int32_t device,
+                              void *stream) {
     MIR_REQUIRE(s >= 1 && b >= 0 && k >= 1, "bad merge shape s=%d b=%d k=%d", s, b, k);
+    MIR_REQUIRE(shard_stride_bytes >= 0 && shard_stride_bytes % 8 == 0, "shard stride must be a multiple of 8");
     if (b == 0) return MIR_OK;
     MIR_REQUIRE(dist && row && count && out_dist && out_row && out_count, "NULL buffer");
     int32_t rc = use_device(device, nullptr);
     if (rc != MIR_OK) return rc;
+    const int64_t sd = shard_stride_bytes ? shard_stride_bytes : (int64_t)b * k * 8;
+    const int64_t sr = shard_stride_bytes ? shard_stride_bytes : (int64_t)b * k * 8;
+    const int64_t sc = shard_stride_bytes ? shard_stride_bytes : (int64_t)b * 4;
     merge_topk_kernel<<<dim3(b), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
-        dist, row, count, s, b, k, descending_scores, out_dist, out_row, out_count);
+        reinterpret_cast<const char *>(dist), reinterpret_cast<const char *>(row),
+        reinterpret_cast<const char *>(count), s, sd, sr, sc, b, k, descending_scores, out_dist, out_row, out_count);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }
 
-int32_t mir_topk_merge_host(const double *dist, const int64_t *row, const int32_t *count, int32_t s, int32_t b,
-                            int32_t k, int32_t descending_scores, double *out_dist, int64_t *out_row,
-                            int32_t *out_count) {
+int32_t mir_topk_merge_host(const double *dist, const int64_t *row, const int32_t *count, int32_t s,
+                            int64_t shard_stride_bytes, int32_t b, int32_t k, int32_t descending_scores,
+                            double *out_dist, int64_t *out_row, int32_t *out_count) {
     MIR_REQUIRE(s >= 1 && b >= 0 && k >= 1, "bad merge shape s=%d b=%d k=%d", s, b, k);
+    MIR_REQUIRE(shard_stride_bytes >= 0 && shard_stride_bytes % 8 == 0, "shard stride must be a multiple of 8");
     if (b == 0) return MIR_OK;
     MIR_REQUIRE(dist && row && count && out_dist && out_row && out_count, "NULL buffer");
+    const int64_t sd = shard_stride_bytes ? shard_stride_bytes : (int64_t)b * k * 8;
+    const int64_t sr = shard_stride_bytes ? shard_stride_bytes : (int64_t)b * k * 8;
+    const int64_t sc = shard_stride_bytes ? shard_stride_bytes : (int64_t)b * 4;
     struct Item {
         double d;
         int64_t r;
@@ -607,12 +678,11 @@ int32_t mir_topk_merge_host(const double *dist, const int64_t *row, const int32_
     for (int q = 0; q < b; ++q) {
         items.clear();
         for (int sh = 0; sh < s; ++sh) {
-            const int c = count[(size_t)sh * b + q];
+            const int c = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(count) + sh * sc)[q];
             MIR_REQUIRE(c >= 0 && c <= k, "count[%d][%d]=%d out of range", sh, q, c);
-            for (int p = 0; p < c; ++p) {
-                const size_t o = ((size_t)sh * b + q) * k + p;
-                items.push_back({dist[o], row[o]});
-            }
+            const double *dp = reinterpret_cast<const double *>(reinterpret_cast<const char *>(dist) + sh * sd);
+            const int64_t *rp = reinterpret_cast<const int64_t *>(reinterpret_cast<const char *>(row) + sh * sr);
+            for (int p = 0; p < c; ++p) items.push_back({dp[(size_t)q * k + p], rp[(size_t)q * k + p]});
         }
         if (!descending_scores) {
             std::sort(items.begin(), items.end(), [](const Item &a, const Item &c) {

@@ -223,21 +223,72 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const double *__restri
 
 // ---------------------------------------------------------------- scan
 
-// Replace this lane's current worst entry, then find the new worst.
+// Replace this lane's current worst entry, then find the new worst.  The rescan
+// reads 8 entries at a time before comparing, so the LDS latency is paid once
+// per 8 entries instead of once per entry (klist is a multiple of 2, padded
+// reads past klist see the ~0 sentinel rows of the caller's allocation: no -
+// they are masked by the bound check below).
 __device__ __forceinline__ void list_insert(uint64_t *list, int klist, int tid, uint64_t key, uint64_t &minkey,
                                             int &minpos) {
     list[minpos * 256 + tid] = key;
     uint64_t m = ~0ull;
     int mp = 0;
-    for (int p = 0; p < klist; ++p) {
-        uint64_t x = list[p * 256 + tid];
-        if (x < m) {
-            m = x;
-            mp = p;
+    for (int p0 = 0; p0 < klist; p0 += 8) {
+        uint64_t x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (p0 + j < klist) ? list[(p0 + j) * 256 + tid] : ~0ull;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (x[j] < m) {
+                m = x[j];
+                mp = p0 + j;
+            }
         }
     }
     minkey = m;
     minpos = mp;
+}
+
+// Epilogue of one 32x32 tile for this lane's query: 16 scores (C layout: row =
+// (r&3) + 8*(r>>2) + 4*(lane>>5)).  A 16-bit mask marks the scores that beat the
+// lane's current worst entry; each lane then walks ITS OWN set bits, so the
+// wave runs max-over-lanes(popcount) insertions instead of one (exec-masked)
+// insertion per register position that any lane needs, and the insertion code
+// exists once instead of 16 times.
+template <int KIND>
+__device__ __forceinline__ void tile_epilogue(const f32x16 &acc_m, const f32x16 &acc_c, const float4 (&ax)[4],
+                                              uint32_t row0, uint32_t n_rows, uint64_t *list, int klist, int tid,
+                                              uint64_t &minkey, int &minpos) {
+    float v[16];
+    uint32_t mask = 0;
+    const float vmin = key_value(minkey);  // minkey == 0 decodes to NaN: compare below is then false -> use flag
+    const bool open = minkey == 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = r >> 2, i = r & 3;
+        const float dot = acc_m[r] + acc_c[r];
+        float x;
+        if (KIND == SCAN_IP) {
+            x = dot;
+        } else {
+            const float a = (i == 0) ? ax[g].x : (i == 1) ? ax[g].y : (i == 2) ? ax[g].z : ax[g].w;
+            x = (KIND == SCAN_L2) ? fmaf(2.0f, dot, -a) : dot * a;
+        }
+        x = (x == x) ? x + 0.0f : -__builtin_inff();  // NaN ranks last; -0 -> +0
+        v[r] = x;
+        const uint32_t row = row0 + 8 * g + i;
+        if (row < n_rows && (open || x >= vmin)) mask |= 1u << r;
+    }
+    while (mask) {
+        const int r = __builtin_ctz(mask);
+        mask &= mask - 1;
+        float x = v[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) x = (r == j) ? v[j] : x;
+        const uint32_t row = row0 + 8 * (r >> 2) + (r & 3);
+        const uint64_t key = make_key(x, row);
+        if (key > minkey) list_insert(list, klist, tid, key, minkey, minpos);
+    }
 }
 
 // grid = (#CUs), block = 256 (4 waves, one per SIMD, whole register file each).
@@ -320,26 +371,7 @@ __global__ __launch_bounds__(256, 1) void scan_topk_kernel(const uint4 *__restri
                 __builtin_amdgcn_sched_barrier(0);
             }
 
-            // epilogue: C layout col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-            if (qj < nq) {
-                const uint32_t row0 = t * kTileRows + 4 * h;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int g = r >> 2, i = r & 3;
-                    const uint32_t row = row0 + 8 * g + i;
-                    float dot = acc_m[r] + acc_c[r];
-                    float v;
-                    if (KIND == SCAN_IP) {
-                        v = dot;
-                    } else {
-                        const float a = (i == 0) ? ax[g].x : (i == 1) ? ax[g].y : (i == 2) ? ax[g].z : ax[g].w;
-                        v = (KIND == SCAN_L2) ? fmaf(2.0f, dot, -a) : dot * a;
-                    }
-                    v = (v == v) ? v + 0.0f : -__builtin_inff();  // NaN ranks last; -0 -> +0
-                    const uint64_t key = make_key(v, row);
-                    if (row < n_rows && key > minkey) list_insert(list, klist, tid, key, minkey, minpos);
-                }
-            }
+            if (qj < nq) tile_epilogue<KIND>(acc_m, acc_c, ax, t * kTileRows + 4 * h, n_rows, list, klist, tid, minkey, minpos);
             if (!more) break;
             t = tn;
             tp = np;
@@ -414,25 +446,7 @@ __global__ __launch_bounds__(256, 1) void scan_topk_generic_kernel(const uint4 *
                 acc_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc_c, 0, 0, 0);
             }
         }
-        if (qj < nq) {
-            const uint32_t row0 = t * kTileRows + 4 * h;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int g = r >> 2, i = r & 3;
-                const uint32_t row = row0 + 8 * g + i;
-                float dot = acc_m[r] + acc_c[r];
-                float v;
-                if (KIND == SCAN_IP) {
-                    v = dot;
-                } else {
-                    const float a = (i == 0) ? ax[g].x : (i == 1) ? ax[g].y : (i == 2) ? ax[g].z : ax[g].w;
-                    v = (KIND == SCAN_L2) ? fmaf(2.0f, dot, -a) : dot * a;
-                }
-                v = (v == v) ? v + 0.0f : -__builtin_inff();
-                const uint64_t key = make_key(v, row);
-                if (row < n_rows && key > minkey) list_insert(list, klist, tid, key, minkey, minpos);
-            }
-        }
+        if (qj < nq) tile_epilogue<KIND>(acc_m, acc_c, ax, t * kTileRows + 4 * h, n_rows, list, klist, tid, minkey, minpos);
     }
     __syncthreads();
     for (int i = tid; i < 32 * klist; i += 256) stage[i] = 0;
@@ -655,31 +669,35 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
 // ---------------------------------------------------------------- shard merge
 
 // One block of 64 threads per query: merge s lists of <= k (dist, row) into k.
-__global__ __launch_bounds__(64) void merge_topk_kernel(const double *__restrict__ dist,
-                                                        const int64_t *__restrict__ row,
-                                                        const int32_t *__restrict__ count, int s, int b, int k,
-                                                        int descending, double *__restrict__ out_dist,
+// Shard sh's arrays start `sh * stride` bytes after the base pointers.
+__global__ __launch_bounds__(64) void merge_topk_kernel(const char *__restrict__ dist_b,
+                                                        const char *__restrict__ row_b,
+                                                        const char *__restrict__ count_b, int s,
+                                                        int64_t stride_d, int64_t stride_r, int64_t stride_c,
+                                                        int b, int k, int descending,
+                                                        double *__restrict__ out_dist,
                                                         int64_t *__restrict__ out_row,
                                                         int32_t *__restrict__ out_count) {
     const int qi = blockIdx.x;
+    auto cnt = [&](int sh) { return reinterpret_cast<const int32_t *>(count_b + sh * stride_c)[qi]; };
+    auto dst = [&](int sh, int p) { return reinterpret_cast<const double *>(dist_b + sh * stride_d)[(size_t)qi * k + p]; };
+    auto rw = [&](int sh, int p) { return reinterpret_cast<const int64_t *>(row_b + sh * stride_r)[(size_t)qi * k + p]; };
     int total = 0;
-    for (int sh = 0; sh < s; ++sh) total += count[sh * b + qi];
+    for (int sh = 0; sh < s; ++sh) total += cnt(sh);
     const int kout = total < k ? total : k;
     // rank by counting; s*k is small (<= 8*64)
     for (int e = threadIdx.x; e < s * k; e += 64) {
         const int sh = e / k, p = e - sh * k;
-        if (p >= count[sh * b + qi]) continue;
-        const size_t me = ((size_t)sh * b + qi) * k + p;
-        const double dm = dist[me];
-        const int64_t rm = row[me];
+        if (p >= cnt(sh)) continue;
+        const double dm = dst(sh, p);
+        const int64_t rm = rw(sh, p);
         int rank = 0;
         for (int s2 = 0; s2 < s; ++s2) {
-            const int c2 = count[s2 * b + qi];
+            const int c2 = cnt(s2);
             for (int p2 = 0; p2 < c2; ++p2) {
-                const size_t o = ((size_t)s2 * b + qi) * k + p2;
-                if (o == me) continue;
-                const double d2 = dist[o];
-                const int64_t r2 = row[o];
+                if (s2 == sh && p2 == p) continue;
+                const double d2 = dst(s2, p2);
+                const int64_t r2 = rw(s2, p2);
                 bool before;
                 if (!descending) {
                     const bool n2 = d2 != d2, nm = dm != dm;

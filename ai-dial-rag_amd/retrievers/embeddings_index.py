@@ -97,6 +97,15 @@ class DeviceIndex:
                                                   out_row_ptr or None, out_dist_ptr or None, out_count_ptr,
                                                   out_flags_ptr or None, stream or None))
 
+    def profile(self, enable: bool) -> None:
+        nat.check(nat.lib.mir_index_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self, reset: bool = True) -> Tuple[int, float]:
+        """-> (scan launches, summed scan-kernel milliseconds) since the last reset."""
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        nat.check(nat.lib.mir_index_profile_read(self._h, 1 if reset else 0, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
     def metric_eval(self, query: np.ndarray, metric) -> np.ndarray:
         q = nat.as_f64_queries(query, self.d)[0]
         out = np.empty(self.n, np.float64)

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: retrieval QPS over a 10M x 384 float32 index (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of B synthetic queries: the
+fused scan + top-k over this rank's row shard, float64 re-score, and (N > 1)
+one RCCL all-gather of per-shard partial top-k plus a local merge.  The index
+and the queries are resident in HBM before the timed region.  The total index
+is fixed at --rows as N grows ("strong" scaling: the shard is rows / N).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the scan)
+from HIP events recorded on its launch stream inside the timed region;
+`cpu_baseline` times the CPU oracle (numpy restatement of the reference path,
+float64 query exactly as the live path) on a bounded sample on the host cores.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CHUNK_ROWS = 500_000   # corpus is generated in fixed global chunks so every N sees the same rows
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--batch", type=int, default=128, help="queries per step (B)")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", default="sqeuclidean_dist")
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-queries", type=int, default=4)
+    return ap.parse_args()
+
+
+def gen_rows(torch, device, lo, hi, dim):
+    """Unit-norm float32 rows [lo, hi) of the global synthetic corpus, generated on the GPU."""
+    out = torch.empty((hi - lo, dim), dtype=torch.float32, device=device)
+    c0, c1 = lo // CHUNK_ROWS, (hi - 1) // CHUNK_ROWS
+    for c in range(c0, c1 + 1):
+        g = torch.Generator(device=device)
+        g.manual_seed(1234 + c)
+        x = torch.randn((CHUNK_ROWS, dim), generator=g, dtype=torch.float32, device=device)
+        x /= x.norm(dim=1, keepdim=True)
+        a, b = max(lo, c * CHUNK_ROWS), min(hi, (c + 1) * CHUNK_ROWS)
+        out[a - lo : b - lo] = x[a - c * CHUNK_ROWS : b - c * CHUNK_ROWS]
+        del x
+    return out
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from aidial_rag_amd import _native as nat
+    from aidial_rag_amd.retrievers.embeddings_index import DeviceIndex
+    from aidial_rag_amd.retrievers.sharded_index import ShardedSearcher, shard_bounds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if nat.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n, d, B, k = args.rows, args.dim, args.batch, args.k
+    lo, hi = shard_bounds(n, world, rank)
+
+    # ---- index build (untimed here; reported as a side number) ----
+    t0 = time.time()
+    shard = gen_rows(torch, device, lo, hi, d)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    t0 = time.time()
+    index = DeviceIndex.from_device_ptr(shard.data_ptr(), hi - lo, d, local_rank, row_offset=lo,
+                                        stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    sample_rows = min(args.cpu_rows, hi - lo) if rank == 0 and world == 1 else 0
+    sample = shard[:sample_rows].cpu().numpy() if sample_rows else None
+    del shard
+    torch.cuda.empty_cache()
+
+    g = torch.Generator(device=device)
+    g.manual_seed(4321)
+    nq_pool = max(4096, B)
+    q32 = torch.randn((nq_pool, d), generator=g, dtype=torch.float32, device=device)
+    q32 /= q32.norm(dim=1, keepdim=True)
+    queries = q32.double().contiguous()  # the live path hands float64 queries (semantic_retriever.py:49,53)
+
+    searcher = ShardedSearcher(local_index=index)
+
+    def step(i):
+        s = (i * B) % (nq_pool - B + 1)
+        return searcher.search(queries[s : s + B], k, args.metric)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    index.profile(True)  # before the warm-up: the first hipEventCreate is slow and must not be timed
+    for i in range(max(args.warmup, 1)):
+        step(i)
+    barrier()
+    index.profile_read(reset=True)
+    flags_total = torch.zeros((), dtype=torch.int64, device=device)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+        flags_total += out[3].sum()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    index.profile(False)
+    launches, scan_ms = index.profile_read(reset=True)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(flags_total, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    qps = B * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (scan), per launch ----
+    # algorithmic bytes per launch: shard rows * d * 4 (the bf16 hi+lo image is
+    # the same 4 B/element) + 4 B/row norm column (sqeuclid/cosine) + the 32-query tile + its results
+    n_loc = hi - lo
+    aux = 0 if args.metric == "inner_product" else 4 * n_loc
+    bytes_launch = n_loc * d * 4 + aux + 32 * d * 4 + 32 * k * 12
+    avg_ms = scan_ms / max(launches, 1)
+    achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("rows_per_launch") == n_loc and tj.get("dim") == d:
+            traffic = tj.get("hbm_bytes_per_launch")
+
+    result = {
+        "metric": "retrieval_qps_10Mx384",
+        "value": round(qps, 1),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32 (bf16x3 MFMA scan, f64 re-score)",
+        "data": "synthetic",
+        "config": {
+            "workload": f"brute-force top-k over {n}x{d} float32 unit-norm rows, {args.metric}, k={k}",
+            "queries_per_step": B,
+            "rows_per_gpu": n_loc,
+            "parallelism": f"row-shard x{world}, all-gather of partial top-k",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "scan_topk_kernel",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "bytes_per_launch": bytes_launch,
+            "avg_launch_ms": round(avg_ms, 4),
+            "launches": launches,
+        },
+        "uncertain_queries": int(flags_total.item()),
+        "index_build_s": {"generate": round(t_gen, 2), "upload_pack_norms": round(t_build, 2)},
+    }
+
+    if rank == 0 and world == 1 and sample is not None and len(sample):
+        result["cpu_baseline"] = cpu_baseline(np, sample, queries[: args.cpu_queries].cpu().numpy(), args, DeviceIndex)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(np, sample, qs, args, DeviceIndex):
+    """The oracle (numpy restatement of embeddings_metrics.py + embeddings_index.py) on the host cores,
+    float64 query as on the live path, full stable argsort - and a parity check of the GPU on the same rows."""
+    from oracle import embeddings_index as oracle_index
+
+    t0 = time.perf_counter()
+    want = [oracle_index.find_flat(q, sample, args.metric, args.k) for q in qs]
+    dt = time.perf_counter() - t0
+    dev = DeviceIndex.from_host(sample)
+    _, _, rows, dist_, cnt, flags = dev.search(qs, args.k, args.metric)
+    ids_equal = all(np.array_equal(rows[i, : cnt[i]], want[i][0]) for i in range(len(qs)))
+    max_err = max(float(np.max(np.abs(dist_[i, : cnt[i]] - want[i][1]))) for i in range(len(qs)))
+    dev.close()
+    qps = len(qs) / dt
+    return {
+        "value": round(qps, 4),
+        "unit": "queries/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": f"{len(qs)} float64 queries over the first {len(sample)} of {args.rows} rows "
+                  f"(cost is linear in rows: ~{qps * len(sample) / args.rows:.4f} queries/s at full size)",
+        "gpu_ids_identical_on_sample": bool(ids_equal),
+        "gpu_max_abs_dist_err_on_sample": max_err,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -112,6 +112,13 @@ int32_t mir_index_search_device(mir_index *idx, const double *queries_device, in
                                 int32_t metric, int32_t *out_doc, int64_t *out_chunk, int64_t *out_row,
                                 double *out_dist, int32_t *out_count, int32_t *out_flags, void *stream);
 
+/* Benchmark instrumentation: when enabled, every launch of the scan kernel (the
+ * dominant, HBM-streaming kernel) is bracketed by HIP events on the stream it
+ * is launched on.  mir_index_profile_read waits for those launches, returns
+ * their number and summed duration in milliseconds, and optionally resets. */
+int32_t mir_index_profile(mir_index *idx, int32_t enable);
+int32_t mir_index_profile_read(mir_index *idx, int32_t reset, int64_t *launches, double *total_ms);
+
 /* ENUM_TO_METRIC[metric](query, docs) -> float64[n]
  * (embeddings_metrics.py:53-58) over all rows of the index, on the GPU.
  * query_host: double[d]; out_host: double[n]. */
@@ -127,16 +134,21 @@ int32_t mir_metric_eval(const void *docs_host, int64_t n, int32_t d, int32_t dty
  * top-k (does not exist in the reference; it is the second stable argsort of
  * embeddings_index.py:81 applied across shards).  Inputs are [s][b][k]
  * (shard-major) with counts [s][b]; ordering is (dist ascending, NaN last,
- * row ascending).  For BM25 pass descending_scores = 1: ordering becomes
+ * row ascending).  `shard_stride_bytes` is the distance between consecutive
+ * shards' blocks in each of the three arrays (0 = densely packed: b*k*8,
+ * b*k*8 and b*4 bytes) - an all-gather of one per-rank blob holding
+ * {dist[b][k], row[b][k], count[b]} is merged in place by passing the three
+ * base pointers of shard 0 and the blob size.  For BM25 pass descending_scores = 1: ordering becomes
  * (score descending, row DESCENDING), the reversed stable argsort of
  * bm25_retriever.py:84.
  * ---------------------------------------------------------------------- */
 int32_t mir_topk_merge_device(const double *dist, const int64_t *row, const int32_t *count, int32_t s,
-                              int32_t b, int32_t k, int32_t descending_scores, double *out_dist,
-                              int64_t *out_row, int32_t *out_count, int32_t device, void *stream);
+                              int64_t shard_stride_bytes, int32_t b, int32_t k, int32_t descending_scores,
+                              double *out_dist, int64_t *out_row, int32_t *out_count, int32_t device,
+                              void *stream);
 int32_t mir_topk_merge_host(const double *dist, const int64_t *row, const int32_t *count, int32_t s,
-                            int32_t b, int32_t k, int32_t descending_scores, double *out_dist,
-                            int64_t *out_row, int32_t *out_count);
+                            int64_t shard_stride_bytes, int32_t b, int32_t k, int32_t descending_scores,
+                            double *out_dist, int64_t *out_row, int32_t *out_count);
 
 #ifdef __cplusplus
 }

@@ -266,13 +266,13 @@ def test_merge_device_matches_host(amd):
     cnt = rng.integers(0, k + 1, (s, b)).astype(np.int32)
     for desc in (0, 1):
         hd, hr, hc = np.zeros((b, k)), np.zeros((b, k), np.int64), np.zeros(b, np.int32)
-        amd.nat.check(amd.nat.lib.mir_topk_merge_host(amd.nat.ptr(dist), amd.nat.ptr(row), amd.nat.ptr(cnt), s, b, k, desc,
+        amd.nat.check(amd.nat.lib.mir_topk_merge_host(amd.nat.ptr(dist), amd.nat.ptr(row), amd.nat.ptr(cnt), s, 0, b, k, desc,
                                                       amd.nat.ptr(hd), amd.nat.ptr(hr), amd.nat.ptr(hc)))
         td, tr, tc = (torch.from_numpy(x).cuda() for x in (dist, row, cnt))
         od = torch.zeros((b, k), dtype=torch.float64, device="cuda")
         orow = torch.zeros((b, k), dtype=torch.int64, device="cuda")
         oc = torch.zeros(b, dtype=torch.int32, device="cuda")
-        amd.nat.check(amd.nat.lib.mir_topk_merge_device(td.data_ptr(), tr.data_ptr(), tc.data_ptr(), s, b, k, desc,
+        amd.nat.check(amd.nat.lib.mir_topk_merge_device(td.data_ptr(), tr.data_ptr(), tc.data_ptr(), s, 0, b, k, desc,
                                                         od.data_ptr(), orow.data_ptr(), oc.data_ptr(), 0,
                                                         torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
