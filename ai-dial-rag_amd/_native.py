@@ -68,6 +68,14 @@ def _load():
         "mir_metric_eval": ([vp, i64, i32, i32, vp, i32, i32, vp], i32),
         "mir_topk_merge_device": ([vp, vp, vp, i32, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),
         "mir_topk_merge_host": ([vp, vp, vp, i32, i64, i32, i32, i32, vp, vp, vp], i32),
+        "mir_bm25_create": ([vp, vp, i64, i32, C.c_double, C.c_double, C.c_double, vp, C.c_double, i32, i64, vp], i32),
+        "mir_bm25_destroy": ([vp], i32),
+        "mir_bm25_info": ([vp, vp, vp, vp, vp, vp, vp], i32),
+        "mir_bm25_idf": ([vp, vp], i32),
+        "mir_bm25_scores": ([vp, vp, i32, vp], i32),
+        "mir_bm25_search": ([vp, vp, vp, i32, i32, vp, vp, vp], i32),
+        "mir_bm25_workspace_bytes": ([vp, i32, i32], i64),
+        "mir_bm25_search_device": ([vp, vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -1,0 +1,189 @@
+"""BM25 keyword retriever, same surface as aidial_rag/retrievers/bm25_retriever.py:26-114.
+
+``BM25Retriever.from_doc_records(doc_records, k)`` flattens every document's
+``text_index`` (items with ``chunk_index`` and ``tokenized_text``) in document
+order, raises ``ValueError("Text index is empty.")`` when there is no token,
+and builds the model; ``_get_relevant_documents(query)`` returns the top-k
+``Document`` list.  The model lives on the GPU (``mir_bm25_create``): the host
+keeps only the str -> term-id vocabulary; scoring and top-k are HIP kernels
+with float64 arithmetic bit-identical to rank-bm25's.
+
+Added over the reference: ``get_relevant_documents_batch`` (B queries per
+launch); a single query is the B = 1 case of the same kernels.
+"""
+
+import asyncio
+import ctypes as C
+from typing import Callable, Dict, Hashable, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .. import _native as nat
+from ..index_record import Document, RetrievalType, to_metadata_doc
+
+
+class DeviceBM25:
+    """Owner of one ``mir_bm25`` handle over token-id documents."""
+
+    def __init__(self, handle, n_docs: int, vocab: int, device: int):
+        self._h, self.n_docs, self.vocab, self.device = handle, n_docs, vocab, device
+
+    @classmethod
+    def from_token_ids(cls, indptr: np.ndarray, term_ids: np.ndarray, vocab: int, k1: float = 1.5, b: float = 0.75,
+                       epsilon: float = 0.25, idf: Optional[np.ndarray] = None, avgdl: float = 0.0, device: int = 0,
+                       doc_offset: int = 0):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        term_ids = np.ascontiguousarray(term_ids, dtype=np.int32)
+        idf_c = None if idf is None else np.ascontiguousarray(idf, dtype=np.float64)
+        if idf_c is not None and len(idf_c) != vocab:
+            raise ValueError("idf override must have `vocab` entries")
+        h = C.c_void_p()
+        nat.check(nat.lib.mir_bm25_create(nat.ptr(indptr), nat.ptr(term_ids) if len(term_ids) else None, len(indptr) - 1,
+                                          vocab, k1, b, epsilon, nat.ptr(idf_c), avgdl, device, doc_offset, C.byref(h)))
+        return cls(h, len(indptr) - 1, vocab, device)
+
+    def info(self) -> dict:
+        n, v, p = C.c_int64(), C.c_int32(), C.c_int64()
+        a, ai, hb = C.c_double(), C.c_double(), C.c_int64()
+        nat.check(nat.lib.mir_bm25_info(self._h, C.byref(n), C.byref(v), C.byref(p), C.byref(a), C.byref(ai), C.byref(hb)))
+        return {"n_docs": n.value, "vocab": v.value, "n_postings": p.value, "avgdl": a.value, "average_idf": ai.value,
+                "hbm_bytes": hb.value}
+
+    def idf(self) -> np.ndarray:
+        out = np.zeros(self.vocab, np.float64)
+        nat.check(nat.lib.mir_bm25_idf(self._h, nat.ptr(out)))
+        return out
+
+    def get_scores(self, query_ids: Sequence[int]) -> np.ndarray:
+        q = np.ascontiguousarray(query_ids, dtype=np.int32)
+        out = np.zeros(self.n_docs, np.float64)
+        nat.check(nat.lib.mir_bm25_scores(self._h, nat.ptr(q) if len(q) else None, len(q), nat.ptr(out)))
+        return out
+
+    def search(self, queries_ids: Sequence[Sequence[int]], k: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """-> (idx[b,k] i64, score[b,k] f64, count[b] i32), best first."""
+        b = len(queries_ids)
+        ptr = np.zeros(b + 1, np.int32)
+        ptr[1:] = np.cumsum([len(q) for q in queries_ids])
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(q, np.int32) for q in queries_ids]) if ptr[-1] else np.zeros(0, np.int32))
+        idx = np.zeros((b, k), np.int64)
+        sc = np.zeros((b, k), np.float64)
+        cnt = np.zeros(b, np.int32)
+        nat.check(nat.lib.mir_bm25_search(self._h, nat.ptr(flat) if len(flat) else None, nat.ptr(ptr), b, k, nat.ptr(idx),
+                                          nat.ptr(sc), nat.ptr(cnt)))
+        return idx, sc, cnt
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            nat.lib.mir_bm25_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TextIndexItem:
+    """index_record.py:9-15: one chunk's token list."""
+
+    __slots__ = ("chunk_index", "tokenized_text")
+
+    def __init__(self, chunk_index: int, tokenized_text: List[str]):
+        self.chunk_index = chunk_index
+        self.tokenized_text = tokenized_text
+
+
+def _build_text_index_chunks(chunks, preprocess: Callable[[str], List[str]]) -> List[TextIndexItem]:
+    # bm25_retriever.py:30-39
+    return [TextIndexItem(chunk_index=i, tokenized_text=preprocess(chunk.text)) for i, chunk in enumerate(chunks)]
+
+
+class BM25Retriever:
+    """bm25_retriever.py:42-114 (langchain BaseRetriever upstream; the retrieval methods keep their names)."""
+
+    def __init__(self, text_indexes: List[Tuple[int, int]], k: int, bm25: DeviceBM25, vocab: Dict[Hashable, int],
+                 preprocess: Optional[Callable[[str], List[str]]] = None):
+        self.text_indexes = text_indexes  # flat index -> (doc_index, chunk_index)
+        self.k = k
+        self.bm25 = bm25
+        self.vocab = vocab
+        self._preprocess = preprocess
+
+    @staticmethod
+    def _get_text_index_gen(doc_records) -> Iterable[Tuple[int, object]]:
+        # bm25_retriever.py:47-54
+        for i, doc in enumerate(doc_records):
+            if doc.text_index is not None:
+                for item in doc.text_index:
+                    yield i, item
+
+    @staticmethod
+    def has_index(document_records) -> bool:
+        # bm25_retriever.py:56-62
+        return sum(len(item.tokenized_text) for _, item in BM25Retriever._get_text_index_gen(document_records)) > 0
+
+    @classmethod
+    def from_doc_records(cls, doc_records, k: int = 4, device: int = 0,
+                         preprocess: Optional[Callable[[str], List[str]]] = None) -> "BM25Retriever":
+        # bm25_retriever.py:64-79
+        text_indexes, lens, flat = [], [], []
+        vocab: Dict[Hashable, int] = {}
+        for i, item in cls._get_text_index_gen(doc_records):
+            text_indexes.append((i, item.chunk_index))
+            toks = item.tokenized_text
+            lens.append(len(toks))
+            for t in toks:
+                flat.append(vocab.setdefault(t, len(vocab)))
+        if sum(lens) == 0:
+            raise ValueError("Text index is empty.")
+        indptr = np.zeros(len(lens) + 1, np.int64)
+        indptr[1:] = np.cumsum(lens)
+        bm25 = DeviceBM25.from_token_ids(indptr, np.asarray(flat, np.int32), max(1, len(vocab)), device=device)
+        return cls(text_indexes=text_indexes, k=k, bm25=bm25, vocab=vocab, preprocess=preprocess)
+
+    def _ids(self, tokens: Sequence[Hashable]) -> List[int]:
+        return [self.vocab.get(t, -1) for t in tokens]
+
+    def _get_top_n_indexes(self, query: List[str], n: int = 5) -> np.ndarray:
+        # bm25_retriever.py:81-84
+        idx, _, cnt = self.bm25.search([self._ids(query)], n)
+        return idx[0, : cnt[0]]
+
+    def get_metadata_doc(self, index: int) -> Document:
+        doc_index, chunk_index = self.text_indexes[index]
+        return to_metadata_doc(doc_index, chunk_index, RetrievalType.TEXT)
+
+    def _processed(self, query: str) -> List[str]:
+        if self._preprocess is not None:
+            return self._preprocess(query)
+        from ..keywords_search import keywords_preprocess
+
+        return keywords_preprocess(query)
+
+    def _get_relevant_documents(self, query: str, *args, **kwargs) -> List[Document]:
+        # bm25_retriever.py:92-97
+        top_n = self._get_top_n_indexes(self._processed(query), self.k)
+        return [self.get_metadata_doc(int(i)) for i in top_n]
+
+    async def _aget_relevant_documents(self, query: str, *args, **kwargs) -> List[Document]:
+        # bm25_retriever.py:99-104
+        return await asyncio.get_running_loop().run_in_executor(None, self._get_relevant_documents, query)
+
+    def get_relevant_documents_batch(self, queries: Sequence[str]) -> List[List[Document]]:
+        idx, _, cnt = self.bm25.search([self._ids(self._processed(q)) for q in queries], self.k)
+        return [[self.get_metadata_doc(int(i)) for i in idx[b, : cnt[b]]] for b in range(len(queries))]
+
+    invoke = _get_relevant_documents
+
+    @staticmethod
+    async def build_index(chunks, stageio=None, preprocess: Optional[Callable[[str], List[str]]] = None) -> List[TextIndexItem]:
+        # bm25_retriever.py:106-114 (runs on the indexing CPU pool upstream; tokenisation is host work)
+        if preprocess is None:
+            from ..keywords_search import keywords_preprocess as preprocess
+        return await asyncio.get_running_loop().run_in_executor(None, _build_text_index_chunks, chunks, preprocess)

@@ -150,6 +150,49 @@ int32_t mir_topk_merge_host(const double *dist, const int64_t *row, const int32_
                             int64_t shard_stride_bytes, int32_t b, int32_t k, int32_t descending_scores,
                             double *out_dist, int64_t *out_row, int32_t *out_count);
 
+/* ------------------------------------------------------------------------
+ * BM25: replaces the rank_bm25.BM25Okapi model that BM25Retriever builds and
+ * queries (aidial_rag/retrievers/bm25_retriever.py:64-84; third-party
+ * rank-bm25 0.2.2, k1 = 1.5, b = 0.75, epsilon = 0.25 by default).
+ *
+ * Documents are token-id lists: indptr[i]..indptr[i+1] slices term_ids (text
+ * order, repeats kept) for document i, in the flattened (doc_record, chunk)
+ * order of from_doc_records (bm25_retriever.py:68-72).  The str -> id
+ * vocabulary lives on the host side of the boundary.  Scores are float64 in
+ * the package's operation order (bit-identical), ties - the all-zero scores
+ * included - go to the HIGHEST index (`argsort(stable)[::-1]`, :84).
+ * mir_bm25_create fails with MIR_ERR_EMPTY ("Text index is empty.", :75-76)
+ * when there is no token at all.  For a document-sharded corpus pass the
+ * GLOBAL idf[vocab] and average length as overrides and the shard's first
+ * global document index as doc_offset; otherwise pass NULL / 0.
+ * ---------------------------------------------------------------------- */
+typedef struct mir_bm25 mir_bm25;
+
+int32_t mir_bm25_create(const int64_t *indptr_host, const int32_t *term_ids_host, int64_t n_docs, int32_t vocab,
+                        double k1, double b, double epsilon, const double *idf_override_host,
+                        double avgdl_override, int32_t device, int64_t doc_offset, mir_bm25 **out);
+int32_t mir_bm25_destroy(mir_bm25 *h);
+int32_t mir_bm25_info(const mir_bm25 *h, int64_t *n_docs, int32_t *vocab, int64_t *n_postings, double *avgdl,
+                      double *average_idf, int64_t *hbm_bytes);
+/* the model's idf table, float64[vocab] (0 for terms that never occur) */
+int32_t mir_bm25_idf(const mir_bm25 *h, double *out_idf_host);
+
+/* BM25Okapi.get_scores(query) -> float64[n_docs] (bm25_retriever.py:83).
+ * Unknown ids (< 0 or >= vocab) contribute 0, repeated ids count again. */
+int32_t mir_bm25_scores(mir_bm25 *h, const int32_t *q_terms_host, int32_t nq, double *out_scores_host);
+
+/* _get_top_n_indexes (bm25_retriever.py:81-84) for b queries; q_ptr[b+1]
+ * slices q_terms.  Outputs [b][k]: out_idx = doc_offset + local document
+ * index, best first; out_count[q] = min(k, n_docs).  k <= 64. */
+int32_t mir_bm25_search(mir_bm25 *h, const int32_t *q_terms_host, const int32_t *q_ptr_host, int32_t b,
+                        int32_t k, int64_t *out_idx, double *out_score, int32_t *out_count);
+/* Same with every buffer in HBM, asynchronous on `stream`; `workspace` holds
+ * mir_bm25_workspace_bytes(h, b, k) bytes of HBM. */
+int64_t mir_bm25_workspace_bytes(const mir_bm25 *h, int32_t b, int32_t k);
+int32_t mir_bm25_search_device(mir_bm25 *h, const int32_t *q_terms_device, const int32_t *q_ptr_device,
+                               int32_t b, int32_t k, int64_t *out_idx, double *out_score, int32_t *out_count,
+                               void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,79 @@
+"""No GPU needed: the C-ABI library loads here, exports every symbol include/miretr.h declares,
+refuses compute loudly without a device (no CPU fallback), and its host-only logic (shard merge) is right."""
+
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from aidial_rag_amd import _native
+
+    return _native
+
+
+def declared_in_header():
+    text = open(os.path.join(ROOT, "include", "miretr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mir_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(nat):
+    names = declared_in_header()
+    assert "mir_index_search" in names and "mir_topk_merge_host" in names
+    out = subprocess.run(["nm", "-D", "--defined-only", nat.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (mir_[a-z0-9_]+)", out))
+    assert set(names) <= exported, sorted(set(names) - exported)
+    assert sorted(nat.DECLARED_SYMBOLS) == names  # the ctypes binding covers the whole header
+    assert nat.lib.mir_abi_version() == nat.ABI_VERSION
+
+
+def test_no_silent_cpu_fallback(nat):
+    if nat.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from aidial_rag_amd.retrievers.embeddings_index import DeviceIndex
+    from aidial_rag_amd.retrievers.embeddings_metrics import ENUM_TO_METRIC, Metric
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DeviceIndex.from_host(np.ones((4, 8), np.float32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ENUM_TO_METRIC[Metric.INNER_PRODUCT](np.ones(8), np.ones((4, 8), np.float32))
+
+
+def test_argument_errors_map_to_valueerror(nat):
+    import ctypes as C
+
+    h = C.c_void_p()
+    with pytest.raises(ValueError):
+        nat.check(nat.lib.mir_index_create(None, -1, 8, 0, None, None, 0, 0, C.byref(h)))
+    with pytest.raises(ValueError):
+        nat.check(nat.lib.mir_index_create(None, 1, 0, 0, None, None, 0, 0, C.byref(h)))
+    with pytest.raises(NotImplementedError):
+        nat.check(nat.lib.mir_index_create(None, 1, 8, 7, None, None, 0, 0, C.byref(h)))
+    assert "dtype" in nat.last_error()
+
+
+def test_merge_host_orderings(nat):
+    s, b, k = 3, 2, 4
+    dist = np.full((s, b, k), 9.0)
+    row = np.zeros((s, b, k), np.int64)
+    cnt = np.zeros((s, b), np.int32)
+    # query 0: ties across shards resolve to the lower row; NaN sorts last
+    dist[0, 0, :3] = [0.1, 0.5, np.nan]; row[0, 0, :3] = [7, 8, 9]; cnt[0, 0] = 3
+    dist[1, 0, :2] = [0.1, 0.2]; row[1, 0, :2] = [3, 40]; cnt[1, 0] = 2
+    dist[2, 0, :1] = [0.5]; row[2, 0, :1] = [2]; cnt[2, 0] = 1
+    # query 1: fewer candidates than k in total
+    dist[2, 1, :2] = [1.0, 2.0]; row[2, 1, :2] = [5, 6]; cnt[2, 1] = 2
+    od, orow, oc = np.zeros((b, k)), np.zeros((b, k), np.int64), np.zeros(b, np.int32)
+    nat.check(nat.lib.mir_topk_merge_host(nat.ptr(dist), nat.ptr(row), nat.ptr(cnt), s, 0, b, k, 0, nat.ptr(od), nat.ptr(orow), nat.ptr(oc)))
+    assert list(oc) == [4, 2]
+    assert list(orow[0]) == [3, 7, 40, 2] and list(od[0]) == [0.1, 0.1, 0.2, 0.5]
+    assert list(orow[1, :2]) == [5, 6]
+    # BM25 ordering: score descending, ties to the HIGHER row
+    nat.check(nat.lib.mir_topk_merge_host(nat.ptr(dist), nat.ptr(row), nat.ptr(cnt), s, 0, 1, k, 1, nat.ptr(od), nat.ptr(orow), nat.ptr(oc)))

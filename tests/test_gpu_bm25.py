@@ -1,0 +1,143 @@
+"""GPU parity of the BM25 path (C ABI -> HIP) against the oracle restatement of rank-bm25 0.2.2.
+Scores are compared BIT-EXACT (float64, same operation order); top-n compared exactly, including the
+reference's reversed stable tie-break."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bm25 as ob  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def br():
+    from aidial_rag_amd import _native
+    from aidial_rag_amd.retrievers import bm25_retriever
+
+    assert _native.device_count() >= 1
+    return bm25_retriever
+
+
+CORPUS = [
+    ["hello", "there", "good", "man"],
+    ["it", "is", "quite", "windy", "in", "london"],
+    ["how", "is", "the", "weather", "today"],
+    [],
+    ["is", "is", "is", "london"],
+]
+
+
+class Rec:
+    def __init__(self, docs):
+        self.text_index = None if docs is None else [type("I", (), {"chunk_index": i, "tokenized_text": t})() for i, t in enumerate(docs)]
+
+
+def test_small_corpus_scores_and_topn(br):
+    r = br.BM25Retriever.from_doc_records([Rec(CORPUS[:2]), Rec(None), Rec(CORPUS[2:])], k=3, preprocess=str.split)
+    o = ob.build(CORPUS)
+    info = r.bm25.info()
+    assert info["n_docs"] == 5 and info["avgdl"] == o.avgdl and info["average_idf"] == o.average_idf
+    for w, i in r.vocab.items():
+        assert r.bm25.idf()[i] == o.idf[w]
+    for q in (["windy", "london", "nope", "london"], ["is"], ["absent"], [], ["london"], ["is", "is", "hello"]):
+        got = r.bm25.get_scores(r._ids(q))
+        np.testing.assert_array_equal(got, o.get_scores(q))
+        for n in (1, 3, 5, 9):
+            np.testing.assert_array_equal(r._get_top_n_indexes(q, n), ob.top_n_indexes(o.get_scores(q), n))
+    docs = r._get_relevant_documents("absent words only")
+    assert [(d.metadata["doc_id"], d.metadata["chunk_id"]) for d in docs] == [(2, 2), (2, 1), (2, 0)]
+    assert r.get_relevant_documents_batch(["london is", "hello"]) == [r._get_relevant_documents("london is"), r._get_relevant_documents("hello")]
+
+
+def test_empty_index_raises_like_reference(br):
+    with pytest.raises(ValueError, match="Text index is empty."):
+        br.BM25Retriever.from_doc_records([Rec([[], []]), Rec(None)], k=3)
+    assert br.BM25Retriever.has_index([Rec([[], []])]) is False
+    assert br.BM25Retriever.has_index([Rec(CORPUS)]) is True
+
+
+def synth(n, vocab, seed, mean_len=150):
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.round(rng.normal(mean_len, mean_len * 0.27, n)), 1, 400).astype(np.int64)
+    lens[rng.random(n) < 0.001] = 0
+    lens[::5003] = 0
+    indptr = np.concatenate(([0], np.cumsum(lens)))
+    toks = np.minimum(rng.zipf(1.07, int(lens.sum())) - 1, vocab - 1).astype(np.int32)
+    return indptr, toks
+
+
+def queries(vocab, nq, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(nq):
+        q = list(rng.integers(0, vocab, rng.integers(2, 9)))
+        if i % 2:
+            q = list(rng.integers(50, min(vocab, 5000), len(q)))  # mid-frequency band
+        if i % 20 == 3:
+            q[0] = vocab + 7  # out of vocabulary
+        if i % 20 == 5:
+            q.append(q[0])  # repeated term
+        if i % 20 == 7:
+            q = [0, 1]  # very frequent terms (negative-idf floor)
+        out.append([int(t) for t in q])
+    return out
+
+
+@pytest.mark.parametrize("n,vocab", [(3000, 500), (20000, 5000), (100_000, 50_000)])
+def test_synthetic_vs_oracle_bit_exact(br, n, vocab):
+    indptr, toks = synth(n, vocab, 777 + n)
+    dev = br.DeviceBM25.from_token_ids(indptr, toks, vocab)
+    o = ob.BM25OkapiCSR(indptr, toks, vocab)
+    assert dev.info()["avgdl"] == o.avgdl and dev.info()["average_idf"] == o.average_idf
+    np.testing.assert_array_equal(dev.idf(), o.idf)
+    qs = queries(vocab, 40, 778)
+    idx, sc, cnt = dev.search(qs, 10)
+    for i, q in enumerate(qs):
+        want = o.get_scores(q)
+        if i < 6:
+            np.testing.assert_array_equal(dev.get_scores(q), want)
+        top = ob.top_n_indexes(want, 10)
+        assert cnt[i] == 10
+        np.testing.assert_array_equal(idx[i], top, err_msg=f"query {i} {q}")
+        np.testing.assert_array_equal(sc[i], want[top])
+    # k larger than a tile's population and than the corpus
+    small = br.DeviceBM25.from_token_ids(indptr[:8], toks[: indptr[7]], vocab)
+    i2, s2, c2 = small.search([qs[0]], 64)
+    assert c2[0] == 7
+    with pytest.raises(NotImplementedError):
+        dev.search(qs[:1], 65)
+
+
+def test_dict_loop_oracle_agrees_on_token_ids(br):
+    indptr, toks = synth(400, 200, 5, mean_len=30)
+    corpus = [toks[indptr[i] : indptr[i + 1]].tolist() for i in range(400)]
+    o = ob.BM25Okapi(corpus)
+    dev = br.DeviceBM25.from_token_ids(indptr, toks, 200)
+    for q in ([0], [1, 5, 9], [3, 3, 150], [199, 7, 250, -1]):
+        np.testing.assert_array_equal(dev.get_scores(q), o.get_scores(q))
+
+
+def test_sharded_stats_override(br):
+    """Two document shards with GLOBAL idf / avgdl reproduce the unsharded model."""
+    indptr, toks = synth(20000, 3000, 9)
+    full = br.DeviceBM25.from_token_ids(indptr, toks, 3000)
+    idf, avgdl = full.idf(), full.info()["avgdl"]
+    cut = 9000
+    a = br.DeviceBM25.from_token_ids(indptr[: cut + 1], toks[: indptr[cut]], 3000, idf=idf, avgdl=avgdl)
+    b = br.DeviceBM25.from_token_ids(indptr[cut:] - indptr[cut], toks[indptr[cut] :], 3000, idf=idf, avgdl=avgdl, doc_offset=cut)
+    qs = queries(3000, 12, 10)
+    for q in qs:
+        np.testing.assert_array_equal(np.concatenate([a.get_scores(q), b.get_scores(q)]), full.get_scores(q))
+    ia, sa, ca = a.search(qs, 10)
+    ib, sb, cb = b.search(qs, 10)
+    fi, fs, fc = full.search(qs, 10)
+    from aidial_rag_amd import _native as nat
+
+    dist = np.ascontiguousarray(np.stack([sa, sb]))
+    rows = np.ascontiguousarray(np.stack([ia, ib]))
+    cnts = np.ascontiguousarray(np.stack([ca, cb]))
+    od, orow, oc = np.zeros_like(sa), np.zeros_like(ia), np.zeros_like(ca)
+    nat.check(nat.lib.mir_topk_merge_host(nat.ptr(dist), nat.ptr(rows), nat.ptr(cnts), 2, 0, len(qs), 10, 1, nat.ptr(od), nat.ptr(orow), nat.ptr(oc)))
+    np.testing.assert_array_equal(orow, fi)
+    np.testing.assert_array_equal(od, fs)
