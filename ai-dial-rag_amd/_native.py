@@ -76,6 +76,7 @@ def _load():
         "mir_bm25_search": ([vp, vp, vp, i32, i32, vp, vp, vp], i32),
         "mir_bm25_workspace_bytes": ([vp, i32, i32], i64),
         "mir_bm25_search_device": ([vp, vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
+        "mir_rrf_fuse": ([vp, vp, vp, i32, i32, vp, vp, vp], i32),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -1,0 +1,58 @@
+// Weighted reciprocal-rank fusion of the retrievers' result lists (host code).
+//
+// Replaces langchain 0.3.21 EnsembleRetriever.weighted_reciprocal_rank as wired
+// at aidial_rag/retrieval_chain.py:239-245 (weights all 1.0, c = 60): at most
+// 4 lists x 7 items, so this is host logic, not a kernel.
+// Restated in oracle/fusion.py: score[key] += w / (rank + c), rank from 1, over
+// every list in order (an item repeated inside a list is credited again);
+// unique keys in first-seen order over the chained lists; stable sort by score,
+// descending.
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <numeric>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+
+extern "C" int32_t mir_rrf_fuse(const int64_t *keys, const int32_t *list_ptr, const double *weights, int32_t n_lists,
+                                int32_t c, int64_t *out_keys, double *out_scores, int32_t *out_count) {
+    MIR_REQUIRE(n_lists >= 0 && list_ptr && out_count, "bad arguments");
+    MIR_REQUIRE(n_lists == 0 || weights, "weights is NULL");
+    MIR_REQUIRE(list_ptr[0] == 0, "list_ptr[0] must be 0");
+    for (int l = 0; l < n_lists; ++l) MIR_REQUIRE(list_ptr[l + 1] >= list_ptr[l], "list_ptr not monotone");
+    const int total = list_ptr[n_lists];
+    MIR_REQUIRE(total == 0 || (keys && out_keys && out_scores), "NULL buffer");
+    typedef std::pair<int64_t, int64_t> Key;
+    std::map<Key, int> slot;       // key -> position in first-seen order
+    std::vector<Key> uniq;
+    std::vector<double> score;
+    for (int l = 0; l < n_lists; ++l) {
+        for (int i = list_ptr[l]; i < list_ptr[l + 1]; ++i) {
+            const Key k(keys[2 * i], keys[2 * i + 1]);
+            auto it = slot.find(k);
+            int s;
+            if (it == slot.end()) {
+                s = (int)uniq.size();
+                slot.emplace(k, s);
+                uniq.push_back(k);
+                score.push_back(0.0);
+            } else {
+                s = it->second;
+            }
+            const int rank = i - list_ptr[l] + 1;
+            score[s] += weights[l] / (double)(rank + c);
+        }
+    }
+    std::vector<int> order(uniq.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return score[a] > score[b]; });
+    for (size_t r = 0; r < order.size(); ++r) {
+        out_keys[2 * r] = uniq[order[r]].first;
+        out_keys[2 * r + 1] = uniq[order[r]].second;
+        out_scores[r] = score[order[r]];
+    }
+    *out_count = (int32_t)order.size();
+    return MIR_OK;
+}

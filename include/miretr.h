@@ -193,6 +193,17 @@ int32_t mir_bm25_search_device(mir_bm25 *h, const int32_t *q_terms_device, const
                                int32_t b, int32_t k, int64_t *out_idx, double *out_score, int32_t *out_count,
                                void *workspace, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Rank fusion: langchain EnsembleRetriever.weighted_reciprocal_rank as wired
+ * at aidial_rag/retrieval_chain.py:239-245 (weights 1.0, c = 60).  Host code:
+ * at most 4 lists x 7 items.  keys[total][2] are the (doc_id, chunk_id) pairs
+ * of every list back to back (the reference keys items by page_content =
+ * "{doc_id}_{chunk_id}", index_record.py:33-34); list_ptr[n_lists+1] slices
+ * them.  Outputs hold the unique keys, best first, and their scores.
+ * ---------------------------------------------------------------------- */
+int32_t mir_rrf_fuse(const int64_t *keys, const int32_t *list_ptr, const double *weights, int32_t n_lists,
+                     int32_t c, int64_t *out_keys, double *out_scores, int32_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif

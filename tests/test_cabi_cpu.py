@@ -77,3 +77,21 @@ def test_merge_host_orderings(nat):
     assert list(orow[1, :2]) == [5, 6]
     # BM25 ordering: score descending, ties to the HIGHER row
     nat.check(nat.lib.mir_topk_merge_host(nat.ptr(dist), nat.ptr(row), nat.ptr(cnt), s, 0, 1, k, 1, nat.ptr(od), nat.ptr(orow), nat.ptr(oc)))
+
+
+def test_rrf_fuse_matches_oracle(nat):
+    """Host-only entry point: runs without a GPU.  Random overlapping lists incl. in-list duplicates."""
+    from aidial_rag_amd.index_record import RetrievalType, to_metadata_doc
+    from aidial_rag_amd.retrievers.ensemble_retriever import weighted_reciprocal_rank
+    from oracle import fusion as of
+
+    rng = np.random.default_rng(1)
+    for trial in range(50):
+        nl = int(rng.integers(1, 5))
+        lists = [[(int(rng.integers(0, 3)), int(rng.integers(0, 6))) for _ in range(int(rng.integers(0, 8)))] for _ in range(nl)]
+        weights = [1.0] * nl if trial % 2 else [float(w) for w in rng.random(nl)]
+        docs = [[to_metadata_doc(a, b, RetrievalType.TEXT) for a, b in l] for l in lists]
+        got = [(d.metadata["doc_id"], d.metadata["chunk_id"]) for d in weighted_reciprocal_rank(docs, weights)]
+        assert got == of.weighted_reciprocal_rank(lists, weights)
+    with pytest.raises(ValueError):
+        weighted_reciprocal_rank([[]], [1.0, 1.0])
