@@ -76,6 +76,12 @@ def _load():
         "mir_bm25_search": ([vp, vp, vp, i32, i32, vp, vp, vp], i32),
         "mir_bm25_workspace_bytes": ([vp, i32, i32], i64),
         "mir_bm25_search_device": ([vp, vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
+        "mir_encoder_create": ([i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp], i32),
+        "mir_encoder_destroy": ([vp], i32),
+        "mir_encoder_info": ([vp, vp, vp, vp], i32),
+        "mir_encoder_encode": ([vp, vp, vp, i32, i32, vp], i32),
+        "mir_encoder_encode_to_device": ([vp, vp, vp, i32, i32, vp, vp], i32),
+        "mir_encoder_debug_hidden": ([vp, vp, vp, i32, i32, vp, vp, i64], i32),
         "mir_rrf_fuse": ([vp, vp, vp, i32, i32, vp, vp, vp], i32),
     }
     for name, (args, res) in sig.items():

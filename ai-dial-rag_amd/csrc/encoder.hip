@@ -1,0 +1,314 @@
+// Host side of the bge-small-en encoder: weight packing, batching, launches.
+// C ABI in include/miretr.h; device code in encoder_kernels.h.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "encoder_kernels.h"
+
+using namespace mir;
+using namespace mir::enc;
+
+namespace {
+
+constexpr int kMaxTilesPerPass = 4096;  // 131 072 tokens per pass: ~0.5 GB of activations
+
+// Pack a Hugging Face Linear weight W[out][in] (y = x W^T + b) into MFMA A-fragment
+// order for out^T = W x^T: block (nt, ks) = 64 lanes x 8 halfs, lane (row = l&31,
+// h = l>>5) element j = W[32*nt + row][32*(ks>>1) + fi(8*(ks&1) + j, h)].
+void pack_block(const float *W, int in_dim, int nt, int ks, _Float16 *dst /*512 halfs*/) {
+    for (int l = 0; l < 64; ++l) {
+        const int row = 32 * nt + (l & 31), h = l >> 5;
+        for (int j = 0; j < 8; ++j) {
+            const int r = 8 * (ks & 1) + j;
+            const int kf = 32 * (ks >> 1) + ((r & 3) + 8 * (r >> 2) + 4 * h);
+            dst[l * 8 + j] = (_Float16)W[(size_t)row * in_dim + kf];
+        }
+    }
+}
+
+struct Layer {
+    uint4 *wqkv = nullptr;        // [36][24][64]
+    float *bqkv = nullptr;        // [1152]
+    uint4 *wo = nullptr;          // [12][24][64]
+    float *attn_params = nullptr; // bo | gamma | beta  [3*384]
+    unsigned char *wffn = nullptr;// [48][48 KiB]
+    float *ffn_params = nullptr;  // b1 | b2 | gamma | beta
+};
+
+}  // namespace
+
+struct mir_encoder {
+    int device = 0;
+    int layers = 0;
+    int vocab = 0, max_pos = 0;
+    float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+    std::vector<Layer> L;
+    int64_t hbm_bytes = 0;
+    std::mutex mu;  // one encode at a time per handle (the reference runs its encoder on 1-thread pools, cpu_pools.py:25-34)
+    hipStream_t stream = nullptr;
+    void *ws = nullptr;
+    size_t ws_cap = 0;
+};
+
+namespace {
+
+void free_encoder(mir_encoder *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipFree(e->word); (void)hipFree(e->pos); (void)hipFree(e->type0); (void)hipFree(e->emb_g); (void)hipFree(e->emb_b);
+    for (Layer &l : e->L) {
+        (void)hipFree(l.wqkv); (void)hipFree(l.bqkv); (void)hipFree(l.wo); (void)hipFree(l.attn_params);
+        (void)hipFree(l.wffn); (void)hipFree(l.ffn_params);
+    }
+    (void)hipFree(e->ws);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+hipError_t upload(mir_encoder *e, void **dst, const void *src, size_t bytes) {
+    hipError_t er = hipMalloc(dst, bytes);
+    if (er != hipSuccess) return er;
+    e->hbm_bytes += (int64_t)bytes;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+}
+
+struct Batch {
+    std::vector<int32_t> ids;        // [n_tiles*32], 0-padded
+    std::vector<TileInfo> tiles;     // [n_tiles]
+    std::vector<int32_t> seq_first;  // [n_seq]
+};
+
+// Sequences [s0, s1) -> padded tiles.
+void build_batch(const int32_t *token_ids, const int64_t *offs, const int32_t *lens, int s0, int s1, Batch &b) {
+    b.ids.clear(); b.tiles.clear(); b.seq_first.clear();
+    for (int s = s0; s < s1; ++s) {
+        const int len = lens[s];
+        const int nt = (len + 31) / 32;
+        const int first = (int)b.tiles.size();
+        b.seq_first.push_back(first);
+        for (int t = 0; t < nt; ++t) b.tiles.push_back(TileInfo{first, nt, len, s - s0});
+        const size_t base = b.ids.size();
+        b.ids.resize(base + (size_t)nt * 32, 0);
+        std::memcpy(b.ids.data() + base, token_ids + offs[s], sizeof(int32_t) * len);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_t intermediate, int32_t vocab,
+                           int32_t max_pos, const float *word_emb, const float *pos_emb, const float *type_emb,
+                           const float *emb_ln_gamma, const float *emb_ln_beta, const float *const *layer_tensors,
+                           int32_t device, mir_encoder **out) {
+    MIR_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    if (hidden != H || heads != NH || intermediate != FF) {
+        set_error("encoder build is specialised for bge-small-en (hidden 384, 12 heads, FFN 1536); got %d/%d/%d",
+                  hidden, heads, intermediate);
+        return MIR_ERR_UNSUPPORTED;
+    }
+    MIR_REQUIRE(layers >= 1 && layers <= 64 && vocab >= 1 && max_pos >= 1, "bad encoder shape");
+    MIR_REQUIRE(word_emb && pos_emb && type_emb && emb_ln_gamma && emb_ln_beta && layer_tensors, "NULL weight pointer");
+    for (int i = 0; i < layers * 16; ++i) MIR_REQUIRE(layer_tensors[i] != nullptr, "layer tensor %d is NULL", i);
+    int32_t rc = use_device(device, nullptr);
+    if (rc != MIR_OK) return rc;
+    mir_encoder *e = new (std::nothrow) mir_encoder();
+    MIR_REQUIRE(e != nullptr, "out of host memory");
+    e->device = device; e->layers = layers; e->vocab = vocab; e->max_pos = max_pos;
+    auto fail = [&](int32_t code) { free_encoder(e); return code; };
+#define MIR_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            set_error("%s failed: %s", #call, hipGetErrorString(e_));                              \
+            return fail(MIR_ERR_HIP);                                                              \
+        }                                                                                          \
+    } while (0)
+    MIR_TRY(upload(e, (void **)&e->word, word_emb, (size_t)vocab * H * 4));
+    // position table padded to 512 rows so the kernel's clamp is always in range
+    {
+        std::vector<float> p((size_t)512 * H, 0.f);
+        std::memcpy(p.data(), pos_emb, sizeof(float) * (size_t)std::min(max_pos, 512) * H);
+        MIR_TRY(upload(e, (void **)&e->pos, p.data(), p.size() * 4));
+    }
+    MIR_TRY(upload(e, (void **)&e->type0, type_emb, (size_t)H * 4));  // token_type 0 only
+    MIR_TRY(upload(e, (void **)&e->emb_g, emb_ln_gamma, (size_t)H * 4));
+    MIR_TRY(upload(e, (void **)&e->emb_b, emb_ln_beta, (size_t)H * 4));
+
+    e->L.resize(layers);
+    std::vector<_Float16> buf;
+    for (int li = 0; li < layers; ++li) {
+        const float *const *t = layer_tensors + (size_t)li * 16;
+        // order: q.w q.b k.w k.b v.w v.b ao.w ao.b aln.g aln.b i.w i.b o.w o.b oln.g oln.b
+        Layer &l = e->L[li];
+        // QKV: 36 tiles x 24 k-steps
+        buf.assign((size_t)36 * KS_H * 512, (_Float16)0);
+        for (int tile = 0; tile < 36; ++tile) {
+            const float *W = t[(tile / 12) * 2];
+            for (int ks = 0; ks < KS_H; ++ks) pack_block(W, H, tile % 12, ks, buf.data() + ((size_t)tile * KS_H + ks) * 512);
+        }
+        MIR_TRY(upload(e, (void **)&l.wqkv, buf.data(), buf.size() * 2));
+        {
+            std::vector<float> b(3 * H);
+            for (int p = 0; p < 3; ++p) std::memcpy(b.data() + p * H, t[p * 2 + 1], sizeof(float) * H);
+            MIR_TRY(upload(e, (void **)&l.bqkv, b.data(), b.size() * 4));
+        }
+        // attention output projection: [nt][ks]
+        buf.assign((size_t)NFB * KS_H * 512, (_Float16)0);
+        for (int nt = 0; nt < NFB; ++nt)
+            for (int ks = 0; ks < KS_H; ++ks) pack_block(t[6], H, nt, ks, buf.data() + ((size_t)nt * KS_H + ks) * 512);
+        MIR_TRY(upload(e, (void **)&l.wo, buf.data(), buf.size() * 2));
+        {
+            std::vector<float> p(3 * H);
+            std::memcpy(p.data(), t[7], sizeof(float) * H);
+            std::memcpy(p.data() + H, t[8], sizeof(float) * H);
+            std::memcpy(p.data() + 2 * H, t[9], sizeof(float) * H);
+            MIR_TRY(upload(e, (void **)&l.attn_params, p.data(), p.size() * 4));
+        }
+        // FFN stages: [ht][48 pieces]: 0..23 W1 (out tile ht, k-step ks), 24..47 W2 (out tile nt, k-step 2*ht + s2)
+        buf.assign((size_t)NHT * 48 * 512, (_Float16)0);
+        for (int ht = 0; ht < NHT; ++ht) {
+            _Float16 *st = buf.data() + (size_t)ht * 48 * 512;
+            for (int ks = 0; ks < KS_H; ++ks) pack_block(t[10], H, ht, ks, st + (size_t)ks * 512);
+            for (int nt = 0; nt < NFB; ++nt)
+                for (int s2 = 0; s2 < 2; ++s2) pack_block(t[12], FF, nt, 2 * ht + s2, st + (size_t)(24 + 2 * nt + s2) * 512);
+        }
+        MIR_TRY(upload(e, (void **)&l.wffn, buf.data(), buf.size() * 2));
+        {
+            std::vector<float> p(FFN_PARAM_FLOATS);
+            std::memcpy(p.data(), t[11], sizeof(float) * FF);
+            std::memcpy(p.data() + FF, t[13], sizeof(float) * H);
+            std::memcpy(p.data() + FF + H, t[14], sizeof(float) * H);
+            std::memcpy(p.data() + FF + 2 * H, t[15], sizeof(float) * H);
+            MIR_TRY(upload(e, (void **)&l.ffn_params, p.data(), p.size() * 4));
+        }
+    }
+    MIR_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    {
+        auto kern = ffn_ln_kernel;
+        MIR_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * FFN_STAGE_BYTES + FFN_PARAM_FLOATS * 4));
+    }
+#undef MIR_TRY
+    *out = e;
+    return MIR_OK;
+}
+
+int32_t mir_encoder_destroy(mir_encoder *e) {
+    free_encoder(e);
+    return MIR_OK;
+}
+
+int32_t mir_encoder_info(const mir_encoder *e, int32_t *layers, int32_t *hidden, int64_t *hbm_bytes) {
+    MIR_REQUIRE(e != nullptr, "handle is NULL");
+    if (layers) *layers = e->layers;
+    if (hidden) *hidden = H;
+    if (hbm_bytes) *hbm_bytes = e->hbm_bytes;
+    return MIR_OK;
+}
+
+// Core: encode sequences; out (device or host) float32 [n_seq][384].
+// run_layers < 0 = all.  hidden_out (host, optional): unpacked hidden states of the LAST pass'
+// padded tokens after `run_layers` layers, for tests.
+static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32_t *seq_lens, int32_t n_seq,
+                           int32_t normalize, float *out, bool out_on_device, hipStream_t user_stream,
+                           int32_t run_layers, float *hidden_out, int64_t hidden_cap_tokens) {
+    MIR_REQUIRE(e != nullptr, "handle is NULL");
+    MIR_REQUIRE(n_seq >= 0, "n_seq is negative");
+    if (n_seq == 0) return MIR_OK;
+    MIR_REQUIRE(token_ids && seq_lens && out, "NULL buffer");
+    std::vector<int64_t> offs(n_seq + 1, 0);
+    for (int s = 0; s < n_seq; ++s) {
+        MIR_REQUIRE(seq_lens[s] >= 1 && seq_lens[s] <= 512, "sequence %d has length %d (must be 1..512)", s, seq_lens[s]);
+        offs[s + 1] = offs[s] + seq_lens[s];
+    }
+    for (int64_t i = 0; i < offs[n_seq]; ++i)
+        MIR_REQUIRE(token_ids[i] >= 0 && token_ids[i] < e->vocab, "token id %d at %lld outside the vocabulary", token_ids[i], (long long)i);
+    int32_t rc = use_device(e->device, nullptr);
+    if (rc != MIR_OK) return rc;
+    std::lock_guard<std::mutex> lk(e->mu);
+    hipStream_t s = out_on_device ? user_stream : e->stream;
+    const int nl = run_layers < 0 ? e->layers : std::min(run_layers, e->layers);
+
+    Batch b;
+    int s0 = 0;
+    while (s0 < n_seq) {
+        // greedy pass: as many sequences as fit in kMaxTilesPerPass tiles
+        int s1 = s0, tiles = 0;
+        while (s1 < n_seq && tiles + (seq_lens[s1] + 31) / 32 <= kMaxTilesPerPass) { tiles += (seq_lens[s1] + 31) / 32; ++s1; }
+        build_batch(token_ids, offs.data(), seq_lens, s0, s1, b);
+        const int nt = (int)b.tiles.size();
+        const size_t act_b = (size_t)nt * NFB * 2 * 64 * 16;
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_ids = take(b.ids.size() * 4), o_ti = take(b.tiles.size() * sizeof(TileInfo)), o_sf = take(b.seq_first.size() * 4);
+        const size_t o_a = take(act_b), o_b = take(act_b), o_q = take(act_b), o_k = take(act_b), o_v = take(act_b);
+        const size_t o_out = take((size_t)(s1 - s0) * H * 4);
+        const size_t o_hid = hidden_out ? take((size_t)nt * 32 * H * 4) : 0;
+        if (e->ws_cap < off) {
+            if (e->ws) { (void)hipStreamSynchronize(s); (void)hipFree(e->ws); }
+            e->ws = nullptr; e->ws_cap = 0;
+            MIR_HIP(hipMalloc(&e->ws, off));
+            e->ws_cap = off;
+        }
+        char *w = static_cast<char *>(e->ws);
+        MIR_HIP(hipMemcpyAsync(w + o_ids, b.ids.data(), b.ids.size() * 4, hipMemcpyHostToDevice, s));
+        MIR_HIP(hipMemcpyAsync(w + o_ti, b.tiles.data(), b.tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice, s));
+        MIR_HIP(hipMemcpyAsync(w + o_sf, b.seq_first.data(), b.seq_first.size() * 4, hipMemcpyHostToDevice, s));
+        // the staging vectors are reused by the next pass: the copies above must have left host memory
+        MIR_HIP(hipStreamSynchronize(s));
+        const int32_t *d_ids = reinterpret_cast<int32_t *>(w + o_ids);
+        const TileInfo *d_ti = reinterpret_cast<TileInfo *>(w + o_ti);
+        uint4 *a0 = reinterpret_cast<uint4 *>(w + o_a), *a1 = reinterpret_cast<uint4 *>(w + o_b);
+        uint4 *qf = reinterpret_cast<uint4 *>(w + o_q), *kf = reinterpret_cast<uint4 *>(w + o_k), *vf = reinterpret_cast<uint4 *>(w + o_v);
+        const dim3 g4((nt + 3) / 4), blk(256);
+        embed_ln_kernel<<<g4, blk, 0, s>>>(d_ids, d_ti, nt, e->word, e->pos, e->type0, e->emb_g, e->emb_b, a0);
+        for (int li = 0; li < nl; ++li) {
+            const Layer &l = e->L[li];
+            qkv_kernel<<<g4, blk, 0, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
+            attn_out_ln_kernel<<<g4, blk, 0, s>>>(qf, kf, vf, d_ti, nt, l.wo, l.attn_params, l.attn_params + H,
+                                                  l.attn_params + 2 * H, a0, a1);
+            ffn_ln_kernel<<<g4, blk, 2 * FFN_STAGE_BYTES + FFN_PARAM_FLOATS * 4, s>>>(a1, nt, l.wffn, l.ffn_params, a0);
+        }
+        MIR_HIP(hipGetLastError());
+        float *d_out = out_on_device ? out + (size_t)s0 * H : reinterpret_cast<float *>(w + o_out);
+        pool_normalize_kernel<<<dim3(s1 - s0), dim3(64), 0, s>>>(a0, reinterpret_cast<int32_t *>(w + o_sf), s1 - s0, normalize, d_out);
+        MIR_HIP(hipGetLastError());
+        if (!out_on_device)
+            MIR_HIP(hipMemcpyAsync(out + (size_t)s0 * H, d_out, (size_t)(s1 - s0) * H * 4, hipMemcpyDeviceToHost, s));
+        if (hidden_out) {
+            MIR_REQUIRE((int64_t)nt * 32 <= hidden_cap_tokens, "hidden_out too small: need %d tokens", nt * 32);
+            act_unpack_kernel<<<dim3(nt), dim3(64), 0, s>>>(a0, nt, reinterpret_cast<float *>(w + o_hid));
+            MIR_HIP(hipMemcpyAsync(hidden_out, w + o_hid, (size_t)nt * 32 * H * 4, hipMemcpyDeviceToHost, s));
+        }
+        // the workspace is reused by the next pass (and by the next call)
+        MIR_HIP(hipStreamSynchronize(s));
+        s0 = s1;
+    }
+    return MIR_OK;
+}
+
+int32_t mir_encoder_encode(mir_encoder *e, const int32_t *token_ids_host, const int32_t *seq_lens_host, int32_t n_seq,
+                           int32_t normalize, float *out_host) {
+    return encode_impl(e, token_ids_host, seq_lens_host, n_seq, normalize, out_host, false, nullptr, -1, nullptr, 0);
+}
+
+int32_t mir_encoder_encode_to_device(mir_encoder *e, const int32_t *token_ids_host, const int32_t *seq_lens_host,
+                                     int32_t n_seq, int32_t normalize, float *out_device, void *stream) {
+    return encode_impl(e, token_ids_host, seq_lens_host, n_seq, normalize, out_device, true,
+                       static_cast<hipStream_t>(stream), -1, nullptr, 0);
+}
+
+int32_t mir_encoder_debug_hidden(mir_encoder *e, const int32_t *token_ids_host, const int32_t *seq_lens_host,
+                                 int32_t n_seq, int32_t run_layers, float *pooled_out_host, float *hidden_out_host,
+                                 int64_t hidden_capacity_tokens) {
+    return encode_impl(e, token_ids_host, seq_lens_host, n_seq, 0, pooled_out_host, false, nullptr, run_layers,
+                       hidden_out_host, hidden_capacity_tokens);
+}
+
+}  // extern "C"

@@ -1,0 +1,436 @@
+// Device code of the bge-small-en (BERT-small) encoder for gfx950.
+//
+// Replaces the sentence-transformers forward behind
+//   aidial_rag/embeddings/embeddings.py:52-108  (bge_embedding_impl, aembed_*)
+// 12 layers, hidden 384, 12 heads x 32, FFN 1536, CLS pooling, L2 normalise.
+// float16 operands, float32 accumulation (the reference's own CUDA path is
+// float16 + SDPA, embeddings.py:43-48).
+//
+// Design: tokens live on MFMA *columns* (lanes), features on rows (registers).
+// Every product is computed transposed, out^T = W^T * x^T, with
+// v_mfma_f32_32x32x16_f16: the weight tile is the A operand, 32 tokens' features
+// the B operand.  Consequences:
+//   * a 32-token tile's activations are 24 B-fragments (96 VGPRs) that stay in
+//     registers for a whole kernel; weights are pre-packed on the host into
+//     A-fragment order, so a weight k-step is ONE coalesced 1-KiB load (or one
+//     LDS-DMA piece) with no transpose, no swizzle, no bank conflict;
+//   * the 32x32 accumulator has lane = token, registers = 16 features, which is
+//     already the B fragment of the NEXT product up to a fixed permutation of k
+//     that is folded into the host-side weight packing ("acc-native" order:
+//     element j of lane-half h <-> feature 16*s + 8*(j>>2) + 4*h + (j&3));
+//     no LDS round trip between GEMMs, ever;
+//   * bias, GELU, softmax statistics, residual and LayerNorm are per-token =
+//     per-lane: reductions run over registers plus ONE cross-half shuffle.
+//
+// Activation layout ACT (float16): [token tile][feature block of 32][s2][64 lanes][8]:
+// lane (ti = l&31, h = l>>5), element j of block (fb, s2) = feature
+// 32*fb + 16*s2 + 8*(j>>2) + 4*h + (j&3) of token 32*tile + ti.  This is the
+// accumulator's own register order, so stores and loads are 16-byte per lane,
+// fully coalesced.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mir {
+namespace enc {
+
+typedef _Float16 __attribute__((ext_vector_type(8))) f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int H = 384;        // hidden
+constexpr int NH = 12;        // heads
+constexpr int HD = 32;        // head dim
+constexpr int FF = 1536;      // intermediate
+constexpr int NFB = H / 32;   // 12 feature blocks
+constexpr int KS_H = H / 16;  // 24 k-steps over the hidden dim
+constexpr int NHT = FF / 32;  // 48 intermediate tiles
+constexpr float LN_EPS = 1e-12f;
+
+// feature (row) index inside a 32-row accumulator tile for register r of lane-half h
+__device__ __forceinline__ int fi(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    const _Float16 x = (_Float16)a, y = (_Float16)b;
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+// registers 8*s2 .. 8*s2+7 of an accumulator -> one float16 fragment
+__device__ __forceinline__ uint4 acc_to_frag(const f32x16 &a, int s2) {
+    const int o = 8 * s2;
+    return make_uint4(pack2(a[o + 0], a[o + 1]), pack2(a[o + 2], a[o + 3]), pack2(a[o + 4], a[o + 5]),
+                      pack2(a[o + 6], a[o + 7]));
+}
+__device__ __forceinline__ void frag_to_floats(uint4 f, float (&out)[8]) {
+    const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        out[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] & 0xffffu));
+        out[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] >> 16));
+    }
+}
+
+__device__ __forceinline__ float half_sum(float x) { return x + __shfl_xor(x, 32, 64); }
+__device__ __forceinline__ float half_max(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
+
+// exact-erf GELU (HF "gelu"), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
+__device__ __forceinline__ float gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = 1.0f - p * __expf(-z * z);
+    const float erf_v = x < 0.f ? -e : e;
+    return 0.5f * x * (1.0f + erf_v);
+}
+
+// Per-tile bookkeeping: which sequence a 32-token tile belongs to.
+struct TileInfo {
+    int seq_first_tile;  // first tile of the tile's sequence
+    int seq_tiles;       // tiles of that sequence
+    int seq_len;         // real tokens of that sequence
+    int seq_index;
+};
+
+// y[12] (+bias) + residual -> LayerNorm -> ACT store.  `y` rows are features.
+__device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 *__restrict__ resid_tile,
+                                                  const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                  const float *__restrict__ beta, uint4 *__restrict__ out_tile,
+                                                  int lane, bool store) {
+    const int h = lane >> 5;
+    float sum = 0.f;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float rv[8];
+            frag_to_floats(resid_tile[(fb * 2 + s2) * 64 + lane], rv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s2 + j;
+                const float v = y[fb][r] + bias[32 * fb + fi(r, h)] + rv[j];
+                y[fb][r] = v;
+                sum += v;
+            }
+        }
+    }
+    const float mean = half_sum(sum) * (1.0f / H);
+    float sq = 0.f;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dlt = y[fb][r] - mean;
+            sq = fmaf(dlt, dlt, sq);
+        }
+    const float rstd = rsqrtf(half_sum(sq) * (1.0f / H) + LN_EPS);
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * fb + fi(r, h);
+            y[fb][r] = fmaf((y[fb][r] - mean) * rstd, gamma[f], beta[f]);
+        }
+        if (store) {
+            out_tile[(fb * 2 + 0) * 64 + lane] = acc_to_frag(y[fb], 0);
+            out_tile[(fb * 2 + 1) * 64 + lane] = acc_to_frag(y[fb], 1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- E1: embeddings + LN
+// one wave per token tile; block = 256 (4 tiles)
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict__ ids, const TileInfo *__restrict__ ti,
+                                                       int n_tiles, const float *__restrict__ word,
+                                                       const float *__restrict__ pos, const float *__restrict__ type0,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       uint4 *__restrict__ act) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, t_in = lane & 31;
+    const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tt >= n_tiles) return;
+    const TileInfo info = ti[tt];
+    const int p = 32 * (tt - info.seq_first_tile) + t_in;
+    const int id = ids[tt * 32 + t_in];
+    const float *wrow = word + (size_t)id * H;
+    const float *prow = pos + (size_t)(p < 512 ? p : 511) * H;
+    float v[NFB][16];
+    float sum = 0.f;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 32 * fb + 8 * g + 4 * h;  // registers 4g..4g+3 are 4 consecutive features
+            const float4 a = *reinterpret_cast<const float4 *>(wrow + f0);
+            const float4 b = *reinterpret_cast<const float4 *>(prow + f0);
+            const float4 c = *reinterpret_cast<const float4 *>(type0 + f0);
+            v[fb][4 * g + 0] = a.x + b.x + c.x;
+            v[fb][4 * g + 1] = a.y + b.y + c.y;
+            v[fb][4 * g + 2] = a.z + b.z + c.z;
+            v[fb][4 * g + 3] = a.w + b.w + c.w;
+            sum += v[fb][4 * g] + v[fb][4 * g + 1] + v[fb][4 * g + 2] + v[fb][4 * g + 3];
+        }
+    const float mean = half_sum(sum) * (1.0f / H);
+    float sq = 0.f;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dlt = v[fb][r] - mean;
+            sq = fmaf(dlt, dlt, sq);
+        }
+    const float rstd = rsqrtf(half_sum(sq) * (1.0f / H) + LN_EPS);
+    uint4 *out = act + (size_t)tt * (NFB * 2 * 64);
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+        float o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * fb + fi(r, h);
+            o[r] = fmaf((v[fb][r] - mean) * rstd, gamma[f], beta[f]);
+        }
+        out[(fb * 2 + 0) * 64 + lane] = make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
+        out[(fb * 2 + 1) * 64 + lane] = make_uint4(pack2(o[8], o[9]), pack2(o[10], o[11]), pack2(o[12], o[13]), pack2(o[14], o[15]));
+    }
+}
+
+// ---------------------------------------------------------------- E2: QKV projection
+// One wave per token tile (4 per block, no barriers).  wqkv: 36 tiles x 24 k-steps
+// of 1-KiB fragments: tiles 0-11 = Q heads, 12-23 = K heads, 24-35 = V heads.
+// Q, K come out as W^T x^T (rows = head features, lanes = tokens); V as x W
+// (rows = tokens, lanes = head features) so that each is directly the operand
+// the attention kernel needs.  Output fragment buffers: [tile][head][s2][64].
+__global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ act, int n_tiles,
+                                                     const uint4 *__restrict__ wqkv, const float *__restrict__ bqkv,
+                                                     uint4 *__restrict__ qf, uint4 *__restrict__ kf,
+                                                     uint4 *__restrict__ vf) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tt >= n_tiles) return;
+    const uint4 *xin = act + (size_t)tt * (NFB * 2 * 64) + lane;
+    uint4 x[KS_H];
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) x[ks] = xin[ks * 64];
+
+    constexpr int R = 8;
+    const uint4 *wp = wqkv + lane;
+    uint4 ring[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) ring[i] = wp[i * 64];
+    for (int tile = 0; tile < 36; ++tile) {
+        const bool is_v = tile >= 24;
+        const uint4 *np = wqkv + (size_t)(tile + 1 < 36 ? tile + 1 : tile) * (KS_H * 64) + lane;
+        f32x16 acc = {0};
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) {
+            const int slot = ks % R;
+            acc = is_v ? mfma(x[ks], ring[slot], acc) : mfma(ring[slot], x[ks], acc);
+            ring[slot] = (ks + R < KS_H) ? wp[(ks + R) * 64] : np[(ks + R - KS_H) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wp = np;
+        const int head = tile % 12;
+        const float *b = bqkv + tile * 32;
+        if (is_v) {
+            const float bv = b[lane & 31];  // column = head feature
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += bv;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += b[fi(r, h)];
+        }
+        uint4 *dst = (tile < 12 ? qf : tile < 24 ? kf : vf) + ((size_t)(tt * NH + head) * 2) * 64 + lane;
+        dst[0] = acc_to_frag(acc, 0);
+        dst[64] = acc_to_frag(acc, 1);
+    }
+}
+
+// ---------------------------------------------------------------- E3: attention + output projection + LN
+// One wave per query tile.  Per head: S^T = K Q^T (keys on rows), online softmax
+// per lane (= per query), O^T += V^T P^T, then y^T += Wo^T[:, head] ctx^T.
+__global__ __launch_bounds__(256, 1) void attn_out_ln_kernel(const uint4 *__restrict__ qf, const uint4 *__restrict__ kf,
+                                                             const uint4 *__restrict__ vf,
+                                                             const TileInfo *__restrict__ ti, int n_tiles,
+                                                             const uint4 *__restrict__ wo, const float *__restrict__ bo,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta,
+                                                             const uint4 *__restrict__ act_in,
+                                                             uint4 *__restrict__ act_out) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tt >= n_tiles) return;
+    const TileInfo info = ti[tt];
+    const float scale_log2e = 0.17677669529663688f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e)
+    f32x16 y[NFB];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) y[fb] = f32x16{0};
+
+    for (int head = 0; head < NH; ++head) {
+        const uint4 *qp = qf + ((size_t)(tt * NH + head) * 2) * 64 + lane;
+        const uint4 q0 = qp[0], q1 = qp[64];
+        f32x16 o = {0};
+        float m = -__builtin_inff(), l = 0.f;
+        for (int kt = 0; kt < info.seq_tiles; ++kt) {
+            const size_t kb = ((size_t)((info.seq_first_tile + kt) * NH + head) * 2) * 64 + lane;
+            const uint4 k0 = kf[kb], k1 = kf[kb + 64];
+            const uint4 v0 = vf[kb], v1 = vf[kb + 64];
+            f32x16 s = {0};
+            s = mfma(k0, q0, s);
+            s = mfma(k1, q1, s);
+            const int key0 = 32 * kt;
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool valid = key0 + fi(r, h) < info.seq_len;
+                s[r] = valid ? s[r] * scale_log2e : -__builtin_inff();
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = half_max(mx);
+            const float m_new = fmaxf(m, mx);
+            const float alpha = exp2f(m - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = exp2f(s[r] - m_new);
+                ps += s[r];
+            }
+            l = fmaf(l, alpha, half_sum(ps));
+            m = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+            o = mfma(v0, acc_to_frag(s, 0), o);
+            o = mfma(v1, acc_to_frag(s, 1), o);
+        }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= inv;
+        const uint4 c0 = acc_to_frag(o, 0), c1 = acc_to_frag(o, 1);
+        const uint4 *wp = wo + (size_t)(2 * head) * 64 + lane;  // wo: [nt][ks = 24][64]
+#pragma unroll
+        for (int nt = 0; nt < NFB; ++nt) {
+            y[nt] = mfma(wp[(size_t)nt * KS_H * 64], c0, y[nt]);
+            y[nt] = mfma(wp[(size_t)nt * KS_H * 64 + 64], c1, y[nt]);
+        }
+    }
+    residual_ln_store(y, act_in + (size_t)tt * (NFB * 2 * 64), bo, gamma, beta,
+                      act_out + (size_t)tt * (NFB * 2 * 64), lane, true);
+}
+
+// ---------------------------------------------------------------- E4: FFN1 + GELU + FFN2 + residual + LN
+// Block = 4 waves = 128 tokens sharing the weight stream through LDS.  Per
+// intermediate tile ht (32 of the 1536 features) one 48-KiB stage:
+//   pieces 0..23  W1^T fragments (k-steps over the hidden dim)
+//   pieces 24..47 W2^T fragments for (output tile nt, s2), k-steps 2*ht + s2
+// filled by LDS-DMA (global_load_lds_dwordx4, 12 pieces per wave), double
+// buffered, one barrier per stage.  h^T = gelu(W1^T x^T + b1) never leaves
+// registers: its accumulator is the B fragment of the second product.
+constexpr int FFN_STAGE_BYTES = 48 * 1024;
+constexpr int FFN_PARAM_FLOATS = FF + 3 * H;  // b1 | b2 | gamma | beta
+
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)gsrc,
+                                     (void __attribute__((address_space(3))) *)lds_dst, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void ffn_ln_kernel(const uint4 *__restrict__ act_in, int n_tiles,
+                                                        const unsigned char *__restrict__ wffn,
+                                                        const float *__restrict__ params,
+                                                        uint4 *__restrict__ act_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *stage0 = smem;
+    unsigned char *stage1 = smem + FFN_STAGE_BYTES;
+    float *prm = reinterpret_cast<float *>(smem + 2 * FFN_STAGE_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int tt_raw = blockIdx.x * 4 + wave;
+    const bool live = tt_raw < n_tiles;
+    const int tt = live ? tt_raw : n_tiles - 1;  // idle waves shadow a real tile: they must join barriers and DMA
+
+    for (int i = tid; i < FFN_PARAM_FLOATS; i += 256) prm[i] = params[i];
+    const uint4 *xin = act_in + (size_t)tt * (NFB * 2 * 64) + lane;
+    uint4 x[KS_H];
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) x[ks] = xin[ks * 64];
+
+    auto issue = [&](int ht, unsigned char *dst) {
+        const unsigned char *src = wffn + (size_t)ht * FFN_STAGE_BYTES + (size_t)(wave * 12) * 1024 + lane * 16;
+        unsigned char *d = dst + (wave * 12) * 1024;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) glds16(src + i * 1024, d + i * 1024);
+    };
+    issue(0, stage0);
+    f32x16 y[NFB];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) y[fb] = f32x16{0};
+    __syncthreads();  // params + stage 0 landed (drains vmcnt)
+
+    for (int ht = 0; ht < NHT; ++ht) {
+        unsigned char *cur = (ht & 1) ? stage1 : stage0;
+        unsigned char *nxt = (ht & 1) ? stage0 : stage1;
+        if (ht + 1 < NHT) issue(ht + 1, nxt);
+        const uint4 *st = reinterpret_cast<const uint4 *>(cur) + lane;
+        f32x16 hacc = {0};
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) hacc = mfma(st[ks * 64], x[ks], hacc);
+        const float *b1 = prm + 32 * ht;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[r] = gelu(hacc[r] + b1[fi(r, h)]);
+        const uint4 h0 = acc_to_frag(hacc, 0), h1 = acc_to_frag(hacc, 1);
+#pragma unroll
+        for (int nt = 0; nt < NFB; ++nt) {
+            y[nt] = mfma(st[(24 + 2 * nt) * 64], h0, y[nt]);
+            y[nt] = mfma(st[(25 + 2 * nt) * 64], h1, y[nt]);
+        }
+        __syncthreads();  // next stage landed; everyone is done with `cur`
+    }
+    residual_ln_store(y, act_in + (size_t)tt * (NFB * 2 * 64), prm + FF, prm + FF + H, prm + FF + 2 * H,
+                      act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
+}
+
+// ---------------------------------------------------------------- E5: CLS pooling + L2 normalise
+// one wave per sequence: token 0 of the sequence, float32 [384] in natural feature order.
+__global__ __launch_bounds__(64) void pool_normalize_kernel(const uint4 *__restrict__ act,
+                                                            const int32_t *__restrict__ seq_first_tile, int n_seq,
+                                                            int normalize, float *__restrict__ out) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= n_seq) return;
+    const uint4 *tile = act + (size_t)seq_first_tile[s] * (NFB * 2 * 64);
+    // token 0 of the tile lives in lanes 0 (h=0) and 32 (h=1); lane i < 48 handles fragment block i>>1, half i&1
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float sq = 0.f;
+    const int blk = lane >> 1, hh = lane & 1;
+    if (lane < 48) {
+        frag_to_floats(tile[blk * 64 + 32 * hh], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sq = fmaf(v[j], v[j], sq);
+    }
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float inv = normalize ? 1.0f / fmaxf(sqrtf(sq), 1e-12f) : 1.0f;
+    if (lane < 48) {
+        const int fb = blk >> 1, s2 = blk & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[(size_t)s * H + 32 * fb + fi(8 * s2 + j, hh)] = v[j] * inv;
+    }
+}
+
+// debug / test helper: ACT -> float32 [n_tokens][384] natural order; one wave per tile
+__global__ __launch_bounds__(64) void act_unpack_kernel(const uint4 *__restrict__ act, int n_tiles,
+                                                        float *__restrict__ out) {
+    const int tt = blockIdx.x, lane = threadIdx.x, h = lane >> 5, t_in = lane & 31;
+    if (tt >= n_tiles) return;
+    const uint4 *tile = act + (size_t)tt * (NFB * 2 * 64);
+    for (int blk = 0; blk < NFB * 2; ++blk) {
+        float v[8];
+        frag_to_floats(tile[blk * 64 + lane], v);
+        const int fb = blk >> 1, s2 = blk & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[((size_t)tt * 32 + t_in) * H + 32 * fb + fi(8 * s2 + j, h)] = v[j];
+    }
+}
+
+}  // namespace enc
+}  // namespace mir

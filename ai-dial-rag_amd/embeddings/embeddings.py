@@ -1,0 +1,204 @@
+"""Local text encoder, same surface as aidial_rag/embeddings/embeddings.py:52-108.
+
+``bge_embedding.embed_documents / embed_query / aembed_documents_numpy /
+aembed_query`` and ``build_embeddings`` keep their names and return types
+(``List[np.ndarray float32[384]]`` for documents, ``List[float]`` for a query).
+The forward pass is ``mir_encoder_encode`` (HIP MFMA kernels); tokenisation and
+the text conventions of the wrappers the reference goes through stay on the
+host:
+
+* langchain-community 0.3.20 ``HuggingFaceBgeEmbeddings``: newlines are replaced
+  by spaces; queries get the English BGE instruction prefix; documents get no
+  prefix (embeddings.py:57-64,81,95).
+* sentence-transformers 3.3.1: truncation at the model's 512 tokens, CLS pooling,
+  ``normalize_embeddings=True``.
+
+Weights: a Hugging Face BERT state dict (``epam/bge-small-en`` layout).  No
+weights ship with this repository; ``BgeEncoder.from_state_dict`` /
+``from_pretrained_dir`` load what the caller provides.  Model path and device
+come from the same environment variables as upstream
+(``BGE_EMBEDDINGS_MODEL_PATH``, ``BGE_EMBEDDINGS_DEVICE``, embeddings.py:30-36).
+"""
+
+import asyncio
+import ctypes as C
+import os
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from .. import _native as nat
+from .detect_device import DeviceType, detect_device
+
+EMBEDDINGS_BATCH_SIZE = 128  # embeddings.py:24-26 (outer batch; the GPU path packs all of it into token tiles)
+EMBEDDING_LENGTH = 384       # embeddings.py:69 finds this by encoding ""; bge-small-en is 384 by construction
+BGE_QUERY_INSTRUCTION_EN = "Represent this question for searching relevant passages: "
+MAX_TOKENS = 512
+
+BGE_EMBEDDINGS_MODEL_NAME_OR_PATH = os.environ.get("BGE_EMBEDDINGS_MODEL_PATH", "epam/bge-small-en")
+
+_LAYER_KEYS = [
+    "attention.self.query.weight", "attention.self.query.bias",
+    "attention.self.key.weight", "attention.self.key.bias",
+    "attention.self.value.weight", "attention.self.value.bias",
+    "attention.output.dense.weight", "attention.output.dense.bias",
+    "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
+    "intermediate.dense.weight", "intermediate.dense.bias",
+    "output.dense.weight", "output.dense.bias",
+    "output.LayerNorm.weight", "output.LayerNorm.bias",
+]
+
+
+def _np32(t) -> np.ndarray:
+    if hasattr(t, "detach"):
+        t = t.detach().cpu().float().numpy()
+    return np.ascontiguousarray(t, dtype=np.float32)
+
+
+class BgeEncoder:
+    """Owner of one ``mir_encoder`` handle plus the host-side tokenizer."""
+
+    def __init__(self, handle, layers: int, tokenizer=None, device: int = 0):
+        self._h, self.layers, self.tokenizer, self.device = handle, layers, tokenizer, device
+
+    @classmethod
+    def from_state_dict(cls, sd: Dict[str, object], tokenizer=None, device: int = 0, prefix: str = "") -> "BgeEncoder":
+        """`sd`: BertModel state dict (numpy arrays or torch tensors); `prefix` e.g. "bert." if nested."""
+        g = lambda k: _np32(sd[prefix + k])  # noqa: E731
+        word, pos, typ = g("embeddings.word_embeddings.weight"), g("embeddings.position_embeddings.weight"), g("embeddings.token_type_embeddings.weight")
+        ln_g, ln_b = g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias")
+        layers = 0
+        while f"{prefix}encoder.layer.{layers}.attention.self.query.weight" in sd:
+            layers += 1
+        tensors = [g(f"encoder.layer.{i}.{k}") for i in range(layers) for k in _LAYER_KEYS]
+        hidden = word.shape[1]
+        inter = tensors[10].shape[0] if tensors else 0
+        heads = hidden // 32
+        arr = (C.c_void_p * len(tensors))(*[t.ctypes.data for t in tensors])
+        h = C.c_void_p()
+        type0 = np.ascontiguousarray(typ[0])
+        nat.check(nat.lib.mir_encoder_create(hidden, layers, heads, inter, word.shape[0], pos.shape[0], nat.ptr(word), nat.ptr(pos),
+                                             nat.ptr(type0), nat.ptr(ln_g), nat.ptr(ln_b), arr, device, C.byref(h)))
+        return cls(h, layers, tokenizer, device)
+
+    @classmethod
+    def from_pretrained_dir(cls, path: str, device: int = 0) -> "BgeEncoder":
+        """Load `model.safetensors` + tokenizer files from a local Hugging Face directory."""
+        from safetensors.numpy import load_file
+        from transformers import AutoTokenizer
+
+        sd = load_file(os.path.join(path, "model.safetensors"))
+        prefix = "bert." if any(k.startswith("bert.") for k in sd) else ""
+        return cls.from_state_dict(sd, AutoTokenizer.from_pretrained(path), device, prefix)
+
+    # ---- token-id level (what crosses the C ABI) ----
+    def encode_ids(self, sequences: Sequence[Sequence[int]], normalize: bool = True) -> np.ndarray:
+        lens = np.asarray([len(s) for s in sequences], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(s, dtype=np.int32) for s in sequences]) if len(sequences) else np.zeros(0, np.int32))
+        out = np.zeros((len(sequences), EMBEDDING_LENGTH), np.float32)
+        nat.check(nat.lib.mir_encoder_encode(self._h, nat.ptr(flat), nat.ptr(lens), len(sequences), 1 if normalize else 0, nat.ptr(out)))
+        return out
+
+    def encode_ids_to_device(self, sequences: Sequence[Sequence[int]], out_ptr: int, stream: int = 0, normalize: bool = True) -> None:
+        lens = np.asarray([len(s) for s in sequences], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(s, dtype=np.int32) for s in sequences]))
+        nat.check(nat.lib.mir_encoder_encode_to_device(self._h, nat.ptr(flat), nat.ptr(lens), len(sequences), 1 if normalize else 0, out_ptr, stream or None))
+
+    def debug_hidden(self, sequences: Sequence[Sequence[int]], run_layers: int):
+        lens = np.asarray([len(s) for s in sequences], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(s, dtype=np.int32) for s in sequences]))
+        padded = int(sum((l + 31) // 32 * 32 for l in lens))
+        pooled = np.zeros((len(sequences), EMBEDDING_LENGTH), np.float32)
+        hidden = np.zeros((padded, EMBEDDING_LENGTH), np.float32)
+        nat.check(nat.lib.mir_encoder_debug_hidden(self._h, nat.ptr(flat), nat.ptr(lens), len(sequences), run_layers, nat.ptr(pooled), nat.ptr(hidden), padded))
+        return pooled, hidden
+
+    # ---- text level ----
+    def _tokenize(self, texts: Sequence[str]) -> List[List[int]]:
+        if self.tokenizer is None:
+            raise RuntimeError("this BgeEncoder was built without a tokenizer; use encode_ids or pass one")
+        enc = self.tokenizer(list(texts), add_special_tokens=True, truncation=True, max_length=MAX_TOKENS)
+        return enc["input_ids"]
+
+    def embed_documents(self, texts: List[str]) -> List[List[float]]:
+        texts = [t.replace("\n", " ") for t in texts]  # HuggingFaceBgeEmbeddings.embed_documents
+        return self.encode_ids(self._tokenize(texts)).tolist()
+
+    def embed_documents_numpy(self, texts: List[str]) -> List[np.ndarray]:
+        texts = [t.replace("\n", " ") for t in texts]
+        return list(self.encode_ids(self._tokenize(texts)))
+
+    def embed_query(self, text: str) -> List[float]:
+        text = text.replace("\n", " ")  # HuggingFaceBgeEmbeddings.embed_query
+        return self.encode_ids(self._tokenize([BGE_QUERY_INSTRUCTION_EN + text]))[0].tolist()
+
+    def close(self):
+        if self._h:
+            nat.lib.mir_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_impl: Optional[BgeEncoder] = None
+
+
+def set_bge_embedding_impl(encoder: BgeEncoder) -> None:
+    """Install the process-wide encoder (the reference builds its own at import, embeddings.py:52-66)."""
+    global _impl
+    _impl = encoder
+
+
+def bge_embedding_impl() -> BgeEncoder:
+    global _impl
+    if _impl is None:
+        device = detect_device(os.environ.get("BGE_EMBEDDINGS_DEVICE", DeviceType.AUTO))
+        if device not in (DeviceType.ROCM, DeviceType.CUDA):
+            raise RuntimeError(f"BGE embeddings device {device}: this build computes on a ROCm GPU only")
+        if not os.path.isdir(BGE_EMBEDDINGS_MODEL_NAME_OR_PATH):
+            raise RuntimeError(
+                f"no local model directory at BGE_EMBEDDINGS_MODEL_PATH={BGE_EMBEDDINGS_MODEL_NAME_OR_PATH!r}; "
+                "there is no network access to download epam/bge-small-en"
+            )
+        _impl = BgeEncoder.from_pretrained_dir(BGE_EMBEDDINGS_MODEL_NAME_OR_PATH)
+    return _impl
+
+
+class AsyncEmbeddings:
+    """embeddings.py:72-96.  The sync methods raise upstream too."""
+
+    def embed_documents(self, texts: List[str]) -> List[List[float]]:
+        raise NotImplementedError()
+
+    def embed_query(self, text: str) -> List[float]:
+        raise NotImplementedError()
+
+    async def aembed_documents(self, texts: List[str]) -> List[List[float]]:
+        return await asyncio.get_running_loop().run_in_executor(None, bge_embedding_impl().embed_documents, texts)
+
+    async def aembed_documents_numpy(self, texts: List[str]) -> List[np.ndarray]:
+        return await asyncio.get_running_loop().run_in_executor(None, bge_embedding_impl().embed_documents_numpy, texts)
+
+    async def aembed_query(self, text: str) -> List[float]:
+        return await asyncio.get_running_loop().run_in_executor(None, bge_embedding_impl().embed_query, text)
+
+
+bge_embedding = AsyncEmbeddings()
+
+
+async def build_embeddings(texts: Iterable[str], stageio=None) -> List[np.ndarray]:
+    """embeddings.py:102-108: outer batches of EMBEDDINGS_BATCH_SIZE, strictly one after the other (batched.py:42-53)."""
+    out: List[np.ndarray] = []
+    batch: List[str] = []
+    for t in texts:
+        batch.append(t)
+        if len(batch) == EMBEDDINGS_BATCH_SIZE:
+            out.extend(await bge_embedding.aembed_documents_numpy(batch))
+            batch = []
+    if batch:
+        out.extend(await bge_embedding.aembed_documents_numpy(batch))
+    return out

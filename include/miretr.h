@@ -204,6 +204,46 @@ int32_t mir_bm25_search_device(mir_bm25 *h, const int32_t *q_terms_device, const
 int32_t mir_rrf_fuse(const int64_t *keys, const int32_t *list_ptr, const double *weights, int32_t n_lists,
                      int32_t c, int64_t *out_keys, double *out_scores, int32_t *out_count);
 
+/* ------------------------------------------------------------------------
+ * Text encoder: replaces the sentence-transformers forward behind
+ * bge_embedding_impl / AsyncEmbeddings (aidial_rag/embeddings/embeddings.py:
+ * 52-108): bge-small-en = BERT with hidden 384, 12 heads, FFN 1536, CLS
+ * pooling, L2-normalised output (`normalize_embeddings=True`, :60-62).
+ * Tokenisation (WordPiece, truncation at 512, the BGE query instruction) stays
+ * on the host side of the boundary: the entry points take token ids.
+ *
+ * mir_encoder_create: float32 host tensors in the Hugging Face BertModel
+ * layout.  `layer_tensors` holds layers*16 pointers, per layer in this order:
+ *   attention.self.query.{weight,bias}, key.{weight,bias}, value.{weight,bias},
+ *   attention.output.dense.{weight,bias}, attention.output.LayerNorm.{weight,bias},
+ *   intermediate.dense.{weight,bias}, output.dense.{weight,bias},
+ *   output.LayerNorm.{weight,bias}
+ * (Linear weights are [out][in]).  type_emb is row 0 of token_type_embeddings.
+ * This build is specialised for the bge-small-en shape and refuses others.
+ *
+ * mir_encoder_encode: token_ids = the sequences back to back (with [CLS] /
+ * [SEP] already in place), seq_lens[n_seq] in 1..512; out float32
+ * [n_seq][384].  normalize = 1 for the reference's behaviour.
+ * ---------------------------------------------------------------------- */
+typedef struct mir_encoder mir_encoder;
+
+int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_t intermediate, int32_t vocab,
+                           int32_t max_pos, const float *word_emb, const float *pos_emb, const float *type_emb,
+                           const float *emb_ln_gamma, const float *emb_ln_beta, const float *const *layer_tensors,
+                           int32_t device, mir_encoder **out);
+int32_t mir_encoder_destroy(mir_encoder *e);
+int32_t mir_encoder_info(const mir_encoder *e, int32_t *layers, int32_t *hidden, int64_t *hbm_bytes);
+int32_t mir_encoder_encode(mir_encoder *e, const int32_t *token_ids_host, const int32_t *seq_lens_host,
+                           int32_t n_seq, int32_t normalize, float *out_host);
+/* embeddings written straight to HBM (e.g. into the matrix an index is built from) */
+int32_t mir_encoder_encode_to_device(mir_encoder *e, const int32_t *token_ids_host, const int32_t *seq_lens_host,
+                                     int32_t n_seq, int32_t normalize, float *out_device, void *stream);
+/* test hook: hidden states after `run_layers` layers (0 = embeddings), unpacked to
+ * float32 [padded tokens][384] (each sequence padded to a multiple of 32 tokens) */
+int32_t mir_encoder_debug_hidden(mir_encoder *e, const int32_t *token_ids_host, const int32_t *seq_lens_host,
+                                 int32_t n_seq, int32_t run_layers, float *pooled_out_host,
+                                 float *hidden_out_host, int64_t hidden_capacity_tokens);
+
 #ifdef __cplusplus
 }
 #endif
