@@ -1,0 +1,119 @@
+"""End to end on the GPU, BASELINE config 1 shape: ~1k synthetic chunks in several documents -> encoder ->
+semantic index + BM25 + page (description) index -> weighted RRF, against the same pipeline assembled from the
+oracle pieces on the SAME embedding matrix (encoder parity is measured separately; retrieval parity must not
+depend on float16-vs-float32 encoder noise)."""
+
+import asyncio
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class Chunk:
+    def __init__(self, text, page):
+        self.text, self.metadata = text, {"page_number": page}
+
+
+class Record:
+    def __init__(self, chunks, text_index, embeddings_index, description_embeddings_index=None, multimodal_embeddings_index=None):
+        self.chunks, self.text_index, self.embeddings_index = chunks, text_index, embeddings_index
+        self.description_embeddings_index, self.multimodal_embeddings_index = description_embeddings_index, multimodal_embeddings_index
+
+
+class WordTokenizer:
+    """Whitespace 'tokenizer' over a closed synthetic vocabulary (stands in for WordPiece)."""
+
+    def __init__(self, words):
+        self.ids = {w: 1000 + i for i, w in enumerate(words)}
+
+    def __call__(self, texts, add_special_tokens=True, truncation=True, max_length=512):
+        out = []
+        for t in texts:
+            ids = [101] + [self.ids.get(w, 100) for w in t.split()][: max_length - 2] + [102]
+            out.append(ids)
+        return {"input_ids": out}
+
+
+@pytest.fixture(scope="module")
+def world():
+    from aidial_rag_amd import retrieval_chain
+    from aidial_rag_amd.embeddings.embeddings import BgeEncoder
+    from aidial_rag_amd.retrievers import bm25_retriever as br
+    from aidial_rag_amd.retrievers import embeddings_index as ei
+    from aidial_rag_amd.retrievers.semantic_retriever import SemanticRetriever
+    from oracle import encoder as oe
+
+    rng = np.random.default_rng(2024)
+    words = [f"w{i}" for i in range(3000)]
+    tok = WordTokenizer(words + "Represent this question for searching relevant passages:".split())
+    enc = BgeEncoder.from_state_dict(oe.make_model(layers=12, seed=1, scale=2.0).state_dict(), tokenizer=tok)
+    records = []
+    zipf = np.minimum(rng.zipf(1.2, 200_000) - 1, len(words) - 1)
+    pos = 0
+    for n_chunks in (400, 1, 350, 250):
+        chunks = []
+        for c in range(n_chunks):
+            L = int(rng.integers(20, 120))
+            chunks.append(Chunk(" ".join(words[i] for i in zipf[pos : pos + L]), page=1 + c // 5))
+            pos += L
+        text_index = asyncio.run(br.BM25Retriever.build_index(chunks, preprocess=str.split))
+        emb_index = asyncio.run(SemanticRetriever.build_index(chunks, encoder=enc))
+        n_pages = 1 + (n_chunks - 1) // 5
+        page_vecs = enc.embed_documents_numpy([" ".join(words[i] for i in rng.integers(0, 3000, 30)) for _ in range(n_pages)])
+        desc = ei.pack_multi_embeddings(list(range(n_pages)), page_vecs, n_pages) if n_chunks > 1 else None
+        records.append(Record(chunks, text_index, emb_index, description_embeddings_index=desc))
+    return retrieval_chain, enc, records, tok, rng, words
+
+
+def oracle_pipeline(records, enc, query, words):
+    from aidial_rag_amd.embeddings.embeddings import BGE_QUERY_INSTRUCTION_EN
+    from oracle import bm25 as ob
+    from oracle import embeddings_index as oi
+    from oracle import fusion as of
+
+    q = np.array(enc.embed_query(query))  # same query vector (float64 list -> array), as semantic_retriever.py:49
+    sem, _ = oi.find(q, [oi.create_index_by_chunk([it.embeddings for it in r.embeddings_index]) for r in records], "sqeuclidean_dist", 7)
+    corpus, owners = [], []
+    for i, r in enumerate(records):
+        for it in r.text_index:
+            corpus.append(it.tokenized_text)
+            owners.append((i, it.chunk_index))
+    top = ob.top_n_indexes(ob.build(corpus).get_scores(query.split()), 7)
+    bm = [owners[int(t)] for t in top]
+    desc_idx = [
+        oi.create_index_by_page([c.metadata["page_number"] for c in r.chunks],
+                                None if r.description_embeddings_index is None else [it.embeddings for it in r.description_embeddings_index])
+        for r in records
+    ]
+    desc, _ = oi.find(q, desc_idx, "sqeuclidean_dist", 7)
+    return sem, bm, desc, of.weighted_reciprocal_rank([sem, bm, desc], [1.0, 1.0, 1.0])
+
+
+def test_hybrid_retrieval_equals_oracle_pipeline(world):
+    retrieval_chain, enc, records, tok, rng, words = world
+    assert sum(len(r.chunks) for r in records) == 1001
+    retr = retrieval_chain.create_retriever(records, encoder=enc, keywords_preprocess=str.split)
+    assert len(retr.retrievers) == 3
+    for qi in range(12):
+        query = " ".join(words[i] for i in rng.integers(0, 300 if qi % 2 else 3000, rng.integers(3, 9)))
+        sem, bm, desc, fused = oracle_pipeline(records, enc, query, words)
+        key = lambda docs: [(d.metadata["doc_id"], d.metadata["chunk_id"]) for d in docs]  # noqa: E731
+        assert key(retr.retrievers[0].invoke(query)) == sem
+        assert key(retr.retrievers[1].invoke(query)) == bm
+        assert key(retr.retrievers[2].invoke(query)) == desc
+        got = retr.invoke(query)
+        assert key(got) == fused
+        assert {d.metadata["retrieval_type"].value for d in retr.retrievers[2].invoke(query)} == {"image"}
+
+
+def test_semantic_batch_equals_single(world):
+    retrieval_chain, enc, records, tok, rng, words = world
+    from aidial_rag_amd.retrievers.semantic_retriever import SemanticRetriever
+
+    r = SemanticRetriever.from_doc_records(records, 7, encoder=enc)
+    qs = [" ".join(words[i] for i in rng.integers(0, 3000, 6)) for _ in range(5)]
+    assert r.get_relevant_documents_batch(qs) == [r.invoke(q) for q in qs]
+    docs = asyncio.run(r._aget_relevant_documents(qs[0]))
+    assert docs == r.invoke(qs[0])
