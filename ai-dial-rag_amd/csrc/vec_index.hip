@@ -93,6 +93,7 @@ struct mir_index {
     // benchmark instrumentation (mir_index_profile)
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<hipEvent_t> prof_free;  // recycled events: hipEventCreate inside a timed loop costs milliseconds now and then
     int64_t prof_launches = 0;
     double prof_ms = 0.0;
 };
@@ -113,6 +114,7 @@ static void free_index(mir_index *ix) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    for (hipEvent_t ev : ix->prof_free) (void)hipEventDestroy(ev);
     (void)hipFree(ix->d_orig);
     (void)hipFree(ix->d_split);
     (void)hipFree(ix->d_docsq);
@@ -193,13 +195,13 @@ struct SearchBuffers {
 };
 
 static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int ksteps, int ngroups, int nwg,
-                    int klist, bool host_api) {
+                    int klist, int qpw, bool host_api) {
     Carver c{base};
     sb.q = host_api ? c.take<double>((size_t)b * d) : nullptr;
-    sb.qsplit = c.take<uint4>((size_t)ngroups * ksteps * 128);
+    sb.qsplit = c.take<uint4>((size_t)ngroups * (qpw / 32) * ksteps * 128);
     sb.q_sq = c.take<double>(b);
     sb.q_norm = c.take<double>(b);
-    sb.part = c.take<uint64_t>((size_t)ngroups * nwg * 32 * klist);
+    sb.part = c.take<uint64_t>((size_t)ngroups * nwg * qpw * klist);
     if (host_api) {
         sb.o_doc = c.take<int32_t>((size_t)b * k);
         sb.o_chunk = c.take<int64_t>((size_t)b * k);
@@ -273,6 +275,12 @@ static void release_ws(mir_index *ix, Workspace *w, hipStream_t used, bool pendi
     ix->pool.push_back(w);
 }
 
+// LDS the 128-query scan needs for a list length
+static size_t b128_lds_bytes(int klist) {
+    // DMA ring (reused for the per-workgroup output at the end) + per-lane lists and pending buffers
+    return (size_t)kB128Stages * 8 * 2048 + (size_t)(klist + kB128Pending) * 256 * 8;
+}
+
 template <int KIND>
 static int32_t launch_scan(const mir_index *ix, const uint4 *qsplit_g, int nq, int klist, int nwg,
                            uint64_t *part_g, hipStream_t stream) {
@@ -309,6 +317,34 @@ static int32_t launch_scan(const mir_index *ix, const uint4 *qsplit_g, int nq, i
     return MIR_OK;
 }
 
+template <int KIND>
+static int32_t launch_scan_b128(const mir_index *ix, const uint4 *qsplit_g, int nq, int klist, int nwg,
+                                uint64_t *part_g, hipStream_t stream) {
+    const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
+    const size_t lds = b128_lds_bytes(klist);
+    const uint32_t n_rows = (uint32_t)ix->n;
+#define MIR_SCAN_CASE(KS)                                                                                    \
+    case KS: {                                                                                               \
+        auto kern = scan_topk_b128_kernel<KS, KIND>;                                                         \
+        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+        kern<<<dim3(nwg), dim3(256), lds, stream>>>(ix->d_split, aux, qsplit_g, n_rows, ix->n_tiles, nq,     \
+                                                    klist, part_g);                                          \
+        break;                                                                                               \
+    }
+    switch (ix->ksteps) {
+        MIR_SCAN_CASE(8)
+        MIR_SCAN_CASE(16)
+        MIR_SCAN_CASE(24)
+        default:
+            set_error("internal: b128 scan has no instance for %d k-steps", ix->ksteps);
+            return MIR_ERR_UNSUPPORTED;
+    }
+#undef MIR_SCAN_CASE
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
 static int32_t check_search_args(const mir_index *ix, const void *queries, int32_t b, int32_t k, int32_t metric,
                                  const int32_t *out_count) {
     MIR_REQUIRE(ix != nullptr, "index is NULL");
@@ -322,24 +358,38 @@ static int32_t check_search_args(const mir_index *ix, const void *queries, int32
 
 // Enqueue prep + scan(s) + finalize for device-resident queries/outputs.
 static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int metric, const SearchBuffers &sb,
-                              int ngroups, int nwg, int klist, int32_t *o_doc, int64_t *o_chunk, int64_t *o_row,
+                              int ngroups, int nwg, int klist, int qpw, int32_t *o_doc, int64_t *o_chunk, int64_t *o_row,
                               double *o_dist, int32_t *o_count, int32_t *o_flags, hipStream_t stream) {
     const int d = ix->d;
-    prep_queries_kernel<<<dim3(ngroups * ix->ksteps + b), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, ngroups,
-                                                                               sb.qsplit, sb.q_sq, sb.q_norm);
+    const int ntiles32 = ngroups * (qpw / 32);  // 32-query fragment tiles, padded to whole launches
+    prep_queries_kernel<<<dim3(ntiles32 * ix->ksteps + b), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, ntiles32,
+                                                                                sb.qsplit, sb.q_sq, sb.q_norm);
     MIR_HIP(hipGetLastError());
     for (int g = 0; g < ngroups; ++g) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (ix->profiling) {
-            MIR_HIP(hipEventCreate(&ev0));
-            MIR_HIP(hipEventCreate(&ev1));
+            {
+                std::lock_guard<std::mutex> lk(ix->mu);
+                if (ix->prof_free.size() >= 2) {
+                    ev0 = ix->prof_free.back(); ix->prof_free.pop_back();
+                    ev1 = ix->prof_free.back(); ix->prof_free.pop_back();
+                }
+            }
+            if (!ev0) {
+                MIR_HIP(hipEventCreate(&ev0));
+                MIR_HIP(hipEventCreate(&ev1));
+            }
             MIR_HIP(hipEventRecord(ev0, stream));
         }
-        const uint4 *qs = sb.qsplit + (size_t)g * ix->ksteps * 128;
-        uint64_t *pg = sb.part + (size_t)g * nwg * 32 * klist;
-        const int nq = std::min(32, b - 32 * g);
+        const uint4 *qs = sb.qsplit + (size_t)g * (qpw / 32) * ix->ksteps * 128;
+        uint64_t *pg = sb.part + (size_t)g * nwg * qpw * klist;
+        const int nq = std::min(qpw, b - qpw * g);
         int32_t rc;
-        if (metric == MIR_METRIC_INNER_PRODUCT) rc = launch_scan<SCAN_IP>(ix, qs, nq, klist, nwg, pg, stream);
+        if (qpw == 128) {
+            if (metric == MIR_METRIC_INNER_PRODUCT) rc = launch_scan_b128<SCAN_IP>(ix, qs, nq, klist, nwg, pg, stream);
+            else if (metric == MIR_METRIC_COSINE_SIM) rc = launch_scan_b128<SCAN_COS>(ix, qs, nq, klist, nwg, pg, stream);
+            else rc = launch_scan_b128<SCAN_L2>(ix, qs, nq, klist, nwg, pg, stream);
+        } else if (metric == MIR_METRIC_INNER_PRODUCT) rc = launch_scan<SCAN_IP>(ix, qs, nq, klist, nwg, pg, stream);
         else if (metric == MIR_METRIC_COSINE_SIM) rc = launch_scan<SCAN_COS>(ix, qs, nq, klist, nwg, pg, stream);
         else rc = launch_scan<SCAN_L2>(ix, qs, nq, klist, nwg, pg, stream);
         if (ev1) {
@@ -350,7 +400,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         if (rc != MIR_OK) return rc;
     }
     FinalizeArgs fa;
-    fa.part = sb.part; fa.nwg = nwg; fa.klist = klist; fa.k = k; fa.b = b; fa.d = d; fa.metric = metric;
+    fa.part = sb.part; fa.nwg = nwg; fa.qpw = qpw; fa.klist = klist; fa.k = k; fa.b = b; fa.d = d; fa.metric = metric;
     fa.docs = ix->d_orig; fa.doc_sq = ix->d_docsq; fa.max_norm = ix->d_maxnorm;
     fa.q = dq; fa.q_sq = sb.q_sq; fa.q_norm = sb.q_norm;
     fa.chunk_ids = ix->d_chunk; fa.doc_ids = ix->d_doc; fa.row_offset = ix->row_offset;
@@ -361,14 +411,19 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     return MIR_OK;
 }
 
-static int32_t plan(const mir_index *ix, int b, int k, int *ngroups, int *nwg, int *klist) {
+static int32_t plan(const mir_index *ix, int b, int k, int *ngroups, int *nwg, int *klist, int *qpw) {
     if (k + kListMargin > kMaxList && ix->n > (int64_t)(kMaxList)) {
         set_error("k=%d exceeds the scan's candidate list (max k = %d) for an index of %lld rows", k,
                   kMaxList - kListMargin, (long long)ix->n);
         return MIR_ERR_UNSUPPORTED;
     }
     *klist = std::min(k + kListMargin, kMaxList);
-    *ngroups = (b + 31) / 32;
+    // 128 queries per pass when it pays (more than one 32-query tile) and fits (d padded to a
+    // multiple of 128 on the register-resident kernels, lists + DMA ring within 160 KiB of LDS)
+    const bool wide = b > 32 && (ix->ksteps == 8 || ix->ksteps == 16 || ix->ksteps == 24) &&
+                      b128_lds_bytes(*klist) <= 160 * 1024;
+    *qpw = wide ? 128 : 32;
+    *ngroups = (b + *qpw - 1) / *qpw;
     // one workgroup per CU; never more workgroups than there are 4-tile chunks of work
     const int64_t want = ((int64_t)ix->n_tiles + 3) / 4;
     *nwg = (int)std::max<int64_t>(1, std::min<int64_t>(ix->num_cus, want));
@@ -477,6 +532,19 @@ int32_t mir_index_info(const mir_index *idx, int64_t *n, int32_t *d, int32_t *dt
 
 int32_t mir_index_profile(mir_index *idx, int32_t enable) {
     MIR_REQUIRE(idx != nullptr, "index is NULL");
+    if (enable) {
+        int32_t rc = use_device(idx->device, nullptr);
+        if (rc != MIR_OK) return rc;
+        std::vector<hipEvent_t> fresh;
+        for (int i = 0; i < 512; ++i) {  // enough for 256 launches between reads, created outside any timed region
+            hipEvent_t ev = nullptr;
+            MIR_HIP(hipEventCreate(&ev));
+            fresh.push_back(ev);
+        }
+        std::lock_guard<std::mutex> lk(idx->mu);
+        if (idx->prof_free.size() < 512) idx->prof_free.insert(idx->prof_free.end(), fresh.begin(), fresh.end());
+        else for (hipEvent_t ev : fresh) (void)hipEventDestroy(ev);
+    }
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->profiling = enable != 0;
     return MIR_OK;
@@ -496,8 +564,11 @@ int32_t mir_index_profile_read(mir_index *idx, int32_t reset, int64_t *launches,
         float t = 0.f;
         hipError_t e = hipEventSynchronize(pr.second);
         if (e == hipSuccess) e = hipEventElapsedTime(&t, pr.first, pr.second);
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+        {
+            std::lock_guard<std::mutex> lk(idx->mu);
+            idx->prof_free.push_back(pr.first);
+            idx->prof_free.push_back(pr.second);
+        }
         if (e != hipSuccess) {
             set_error("profile read failed: %s", hipGetErrorString(e));
             return MIR_ERR_HIP;
@@ -525,16 +596,16 @@ int32_t mir_index_search_device(mir_index *idx, const double *queries_device, in
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     rc = use_device(idx->device, nullptr);
     if (rc != MIR_OK) return rc;
-    int ngroups, nwg, klist;
-    rc = plan(idx, b, k, &ngroups, &nwg, &klist);
+    int ngroups, nwg, klist, qpw;
+    rc = plan(idx, b, k, &ngroups, &nwg, &klist, &qpw);
     if (rc != MIR_OK) return rc;
     SearchBuffers sb;
-    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, ngroups, nwg, klist, false);
+    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, ngroups, nwg, klist, qpw, false);
     Workspace *w = nullptr;
     rc = acquire_ws(idx, stream, need, &w);
     if (rc != MIR_OK) return rc;
-    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, ngroups, nwg, klist, false);
-    rc = enqueue_search(idx, queries_device, b, k, metric, sb, ngroups, nwg, klist, out_doc, out_chunk, out_row,
+    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, ngroups, nwg, klist, qpw, false);
+    rc = enqueue_search(idx, queries_device, b, k, metric, sb, ngroups, nwg, klist, qpw, out_doc, out_chunk, out_row,
                         out_dist, out_count, out_flags, stream);
     release_ws(idx, w, stream, true);
     return rc;
@@ -548,15 +619,15 @@ int32_t mir_index_search(mir_index *idx, const double *queries_host, int32_t b, 
     if (b == 0) return MIR_OK;
     rc = use_device(idx->device, nullptr);
     if (rc != MIR_OK) return rc;
-    int ngroups, nwg, klist;
-    rc = plan(idx, b, k, &ngroups, &nwg, &klist);
+    int ngroups, nwg, klist, qpw;
+    rc = plan(idx, b, k, &ngroups, &nwg, &klist, &qpw);
     if (rc != MIR_OK) return rc;
     SearchBuffers sb;
-    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, ngroups, nwg, klist, true);
+    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, ngroups, nwg, klist, qpw, true);
     Workspace *w = nullptr;
     rc = acquire_ws(idx, nullptr, need, &w);
     if (rc != MIR_OK) return rc;
-    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, ngroups, nwg, klist, true);
+    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, ngroups, nwg, klist, qpw, true);
     hipStream_t s = w->stream;
     auto bail = [&](int32_t code) {
         (void)hipStreamSynchronize(s);
@@ -572,7 +643,7 @@ int32_t mir_index_search(mir_index *idx, const double *queries_host, int32_t b, 
         }                                                                                          \
     } while (0)
     MIR_TRY(hipMemcpyAsync(sb.q, queries_host, (size_t)b * idx->d * sizeof(double), hipMemcpyHostToDevice, s));
-    rc = enqueue_search(idx, sb.q, b, k, metric, sb, ngroups, nwg, klist, out_doc ? sb.o_doc : nullptr,
+    rc = enqueue_search(idx, sb.q, b, k, metric, sb, ngroups, nwg, klist, qpw, out_doc ? sb.o_doc : nullptr,
                         out_chunk ? sb.o_chunk : nullptr, out_row ? sb.o_row : nullptr,
                         out_dist ? sb.o_dist : nullptr, sb.o_count, sb.o_flags, s);
     if (rc != MIR_OK) return bail(rc);

@@ -397,6 +397,267 @@ __global__ __launch_bounds__(256, 1) void scan_topk_kernel(const uint4 *__restri
     for (int i = tid; i < 32 * klist; i += 256) out[i] = stage[i];
 }
 
+// ---------------------------------------------------------------- scan, 128 queries per pass
+// The doc stream costs the same HBM bytes whether 32 or 128 queries ride on it.
+// Here a workgroup's 4 waves hold one 32-query tile EACH (fragments in registers
+// as above) and consume the SAME doc tiles: the stream enters LDS once per
+// workgroup by LDS-DMA (global_load_lds_dwordx4; the split layout is already
+// lane-linear, so a 1-KiB piece is one wave-instruction and ds_read_b128 at
+// lane*16 is conflict-free) and every wave reads it from there.  Ring of NS
+// stages of SK k-steps (16 KiB); per stage ONE raw s_barrier and a COUNTED
+// vmcnt (never 0 in steady state) so (NS-1) stages = 64 KiB per CU stay in
+// flight across barriers.  No VGPR-destination global load exists in the loop
+// (hipcc would drain vmcnt(0) for it): the per-row norm column comes through
+// the scalar cache, it is wave-uniform.
+constexpr int kB128Stages = 5;
+constexpr int kB128Pending = 16;  // per-lane buffer of appended, not yet merged candidates
+
+// LDS-DMA of one 1-KiB piece (16 B per lane) as inline asm: with the builtin, hipcc
+// orders every later ds_read behind ALL pending DMAs (`s_waitcnt vmcnt(0)` after the
+// first ds_read of each stage), which drains the ring; an asm load is outside its
+// bookkeeping, so only the counted waits below apply.  M0 carries the wave-uniform
+// LDS byte address and is saved/restored inside the statement (it is compiler-owned).
+__device__ __forceinline__ void glds16_b128(const void *gsrc, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_byte_addr)
+        : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+// Candidate handling for the 128-query scan.  Its 4 waves run in lockstep (one
+// barrier per stage), so anything lane-divergent with a dependent LDS chain sits
+// on the workgroup's critical path at almost every tile (measured: insertions
+// cost 2.5 ms of a 5.6 ms launch).  Therefore:
+//  * a passing score is only APPENDED to the lane's pending buffer (one LDS
+//    write); when any lane's buffer is full the whole wave merges its buffers
+//    into the lists at once.  The threshold is the list's worst entry as of the
+//    last merge (slightly stale = a few more appends, never a wrong result);
+//  * the per-score filter of tile t-1 is software-pipelined into tile t: one
+//    score after each MFMA of the first stage, so its VALU work issues in the
+//    matrix pipe's shadow instead of extending the tile (see the kernel).
+__device__ __forceinline__ void drain_candidates(uint32_t mask, const float (&v)[16], uint32_t row0, uint64_t *list,
+                                                 int klist, int tid, uint64_t &minkey, int &minpos, int &pending) {
+    while (__any(mask != 0)) {
+        if (mask) {
+            const int r = __builtin_ctz(mask);
+            mask &= mask - 1;
+            float x = v[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) x = (r == j) ? v[j] : x;
+            x = (x == x) ? x + 0.0f : -__builtin_inff();  // NaN ranks last; -0 -> +0
+            const uint64_t key = make_key(x, row0 + 8 * (r >> 2) + (r & 3));
+            if (key > minkey) {
+                list[(klist + pending) * 256 + tid] = key;
+                ++pending;
+            }
+        }
+        if (__any(pending == kB128Pending)) {  // wave-uniform: merge every lane's buffer now
+            for (int i = 0; i < kB128Pending; ++i) {
+                if (i < pending) {
+                    const uint64_t key = list[(klist + i) * 256 + tid];
+                    if (key > minkey) list_insert(list, klist, tid, key, minkey, minpos);
+                }
+            }
+            pending = 0;
+        }
+    }
+}
+
+// score r of a finished tile -> ranking value; sets its mask bit when it may beat the lane's threshold
+template <int KIND>
+__device__ __forceinline__ void filter_score(int r, const f32x16 &am, const f32x16 &ac, const float4 (&ax)[4],
+                                             uint32_t row0, uint32_t n_rows, bool open, float vmin, float (&v)[16],
+                                             uint32_t &mask) {
+    const int g = r >> 2, i = r & 3;
+    const float dot = am[r] + ac[r];
+    float x;
+    if (KIND == SCAN_IP) {
+        x = dot;
+    } else {
+        const float a = (i == 0) ? ax[g].x : (i == 1) ? ax[g].y : (i == 2) ? ax[g].z : ax[g].w;
+        x = (KIND == SCAN_L2) ? fmaf(2.0f, dot, -a) : dot * a;
+    }
+    v[r] = x;
+    // NaN fails `x >= vmin`; while the list is still open (fewer than klist entries) everything is taken
+    if (row0 + 8 * g + i < n_rows && (open || x >= vmin)) mask |= 1u << r;
+}
+
+template <int KSTEPS, int KIND>
+__global__ __launch_bounds__(256, 1) void scan_topk_b128_kernel(const uint4 *__restrict__ docs,
+                                                                const float *__restrict__ aux,
+                                                                const uint4 *__restrict__ qsplit, uint32_t n_rows,
+                                                                uint32_t n_tiles, int nq, int klist,
+                                                                uint64_t *__restrict__ part) {
+    constexpr int SK = 8;                    // k-steps per stage
+    static_assert(KSTEPS % SK == 0, "b128 scan needs d padded to a multiple of 128");
+    constexpr int SPT = KSTEPS / SK;         // stages per tile
+    constexpr int NS = kB128Stages;
+    constexpr int STAGE_U4 = SK * 2 * 64;    // uint4 per stage (16 KiB)
+    constexpr int PPW = SK * 2 / 4;          // DMA pieces per wave per stage (4)
+    constexpr int TILE_U4 = KSTEPS * 128;
+    typedef uint32_t __attribute__((ext_vector_type(16))) u32x16;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *ring = reinterpret_cast<uint4 *>(smem);                                  // [NS][STAGE_U4]
+    uint64_t *list = reinterpret_cast<uint64_t *>(smem + NS * STAGE_U4 * 16);       // [klist + pending][256]
+    uint64_t *stage_out = reinterpret_cast<uint64_t *>(smem);                       // [128][klist], reuses the ring afterwards
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, qj = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool active = nq > 32 * wave;      // this wave's query tile holds at least one real query
+    const bool lane_live = qj + 32 * wave < nq;
+    const uint32_t G = gridDim.x;
+
+    for (int p = 0; p < klist + kB128Pending; ++p) list[p * 256 + tid] = 0;
+    uint64_t minkey = 0;
+    int minpos = 0, pending = 0;
+
+    // this wave's 32 queries as B fragments
+    bf16x8 qh[KSTEPS], ql[KSTEPS];
+    {
+        const uint4 *qs = qsplit + (size_t)wave * KSTEPS * 128;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            qh[s] = __builtin_bit_cast(bf16x8, qs[(s * 2 + 0) * 64 + lane]);
+            ql[s] = __builtin_bit_cast(bf16x8, qs[(s * 2 + 1) * 64 + lane]);
+        }
+    }
+    const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + G - 1) / G : 0;
+    const uint32_t NG = my_tiles * SPT;      // stages this workgroup streams
+
+    auto issue = [&](uint32_t g) {           // stage g -> slot g % NS; 4 pieces per wave
+        const uint32_t tile = blockIdx.x + (g / SPT) * G;
+        const uint4 *src = docs + (size_t)tile * TILE_U4 + (size_t)(g % SPT) * STAGE_U4 + (wave * PPW) * 64 + lane;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(
+            lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave * PPW) * 64) * 16);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
+    };
+    // The Q fragments above are ordinary loads.  Touch every one of them here so hipcc places
+    // its waits for them BEFORE the loop: left alone it keeps `s_waitcnt vmcnt(1..0)` at their
+    // first use inside the loop, and vmcnt(0) there also waits for every DMA in flight.
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(qh[s]), "+v"(ql[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t g = 0; g < (uint32_t)(NS - 1) && g < NG; ++g) issue(g);
+
+    // previous tile, whose filter rides in the current tile's first stage; starts as "no rows"
+    f32x16 pacc_m = {0};
+    const f32x16 pacc_c = {0};  // this kernel keeps ONE accumulator (fewer AGPR<->VGPR moves in the filter)
+    float4 pax[4] = {};
+    uint32_t prow0 = n_rows;
+
+    uint32_t g = 0;
+    for (uint32_t ts = 0; ts < my_tiles; ++ts) {
+        const uint32_t t = blockIdx.x + ts * G;
+        // The tile's 32 norm values are wave-uniform: fetch them through the scalar cache
+        // (lgkmcnt), a whole tile ahead of their use.  A vector load would sit in the vmcnt queue
+        // behind the DMA ring and hipcc's wait for it would drain the ring every tile.
+        u32x16 sa, sb;
+        if (KIND != SCAN_IP) {
+            const float *ap = aux + (size_t)__builtin_amdgcn_readfirstlane(t) * kTileRows;
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(sa), "=&s"(sb) : "s"(ap) : "memory");
+        }
+        f32x16 acc_m = {0};
+        float pv[16];
+        uint32_t pmask = 0;
+        const float vmin = key_value(minkey);
+        const bool open = minkey == 0;
+#pragma unroll
+        for (int part_i = 0; part_i < SPT; ++part_i, ++g) {
+            // my pieces of stage g have landed when at most the younger stages' pieces are outstanding
+            const uint32_t younger = (NG - 1 - g) < (uint32_t)(NS - 2) ? (NG - 1 - g) : (uint32_t)(NS - 2);
+            if (younger == NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only in the last NS-2 stages of the launch
+            __builtin_amdgcn_s_barrier();    // every wave's pieces of stage g are in LDS; stage g-1 is consumed
+            if (g + NS - 1 < NG) issue(g + NS - 1);
+            if (active) {
+                const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
+                // all 16 fragments of the stage first (one LDS latency per stage), then the MFMAs
+                uint4 f[2 * SK];
+#pragma unroll
+                for (int i = 0; i < 2 * SK; ++i) f[i] = st[i * 64];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < SK; ++i) {
+                    const int ks = part_i * SK + i;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, f[2 * i + 0]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, f[2 * i + 1]);
+                    acc_m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], acc_m, 0, 0, 0);
+                    if (part_i == 0 && 2 * i < 16) {
+                        filter_score<KIND>(2 * i, pacc_m, pacc_c, pax, prow0, n_rows, open, vmin, pv, pmask);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc_m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], acc_m, 0, 0, 0);
+                    if (part_i == 0 && 2 * i + 1 < 16) {
+                        filter_score<KIND>(2 * i + 1, pacc_m, pacc_c, pax, prow0, n_rows, open, vmin, pv, pmask);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc_m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[ks], acc_m, 0, 0, 0);
+                }
+                if (part_i == 0) drain_candidates(pmask, pv, prow0, list, klist, tid, minkey, minpos, pending);
+            }
+        }
+        // this tile becomes "previous": its norm values have long arrived
+        if (KIND != SCAN_IP) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sa), "+s"(sb)::"memory");
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                // rows 8*gq + 4*h + i  ->  dwords 8*gq + {0..3} (h = 0) or 8*gq + {4..7} (h = 1)
+                float lo[4], hi[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = 8 * gq + i;
+                    lo[i] = __uint_as_float(idx < 16 ? sa[idx] : sb[idx - 16]);
+                    hi[i] = __uint_as_float(idx + 4 < 16 ? sa[idx + 4] : sb[idx + 4 - 16]);
+                }
+                pax[gq] = h ? make_float4(hi[0], hi[1], hi[2], hi[3]) : make_float4(lo[0], lo[1], lo[2], lo[3]);
+            }
+        }
+        pacc_m = acc_m;
+        prow0 = lane_live ? t * kTileRows + 4 * h : n_rows;
+    }
+    // the last tile's scores, then whatever is still pending
+    if (active) {
+        float pv[16];
+        uint32_t pmask = 0;
+        const float vmin = key_value(minkey);
+        const bool open = minkey == 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) filter_score<KIND>(r, pacc_m, pacc_c, pax, prow0, n_rows, open, vmin, pv, pmask);
+        drain_candidates(pmask, pv, prow0, list, klist, tid, minkey, minpos, pending);
+    }
+    for (int i = 0; i < pending; ++i) {
+        const uint64_t key = list[(klist + i) * 256 + tid];
+        if (key > minkey) list_insert(list, klist, tid, key, minkey, minpos);
+    }
+
+    // ---- merge the two half-lists of each query, write [128][klist] per workgroup ----
+    __syncthreads();
+    for (int i = tid; i < 128 * klist; i += 256) stage_out[i] = 0;
+    __syncthreads();
+    const int qloc = 32 * wave + qj;
+    for (int p = 0; p < klist; ++p) {
+        const uint64_t key = list[p * 256 + tid];
+        if (key == 0) continue;
+        int rank = 0;
+        const int t2 = tid ^ 32;  // the other half of the same query
+        for (int p2 = 0; p2 < klist; ++p2) {
+            rank += (list[p2 * 256 + tid] > key) ? 1 : 0;
+            rank += (list[p2 * 256 + t2] > key) ? 1 : 0;
+        }
+        if (rank < klist) stage_out[qloc * klist + rank] = key;
+    }
+    __syncthreads();
+    uint64_t *out = part + (size_t)blockIdx.x * 128 * klist;
+    for (int i = tid; i < 128 * klist; i += 256) out[i] = stage_out[i];
+}
+
 // Generic dimension: query fragments are re-read from L2 each k-step instead of
 // living in registers.  Same tile walk, same epilogue.  ksteps % 8 == 0.
 template <int KIND>
@@ -552,8 +813,9 @@ __device__ inline void bitonic_sort_desc(uint64_t *keys, int n, int tid) {
 }
 
 struct FinalizeArgs {
-    const uint64_t *part;   // [ngroups][nwg][32][klist]
+    const uint64_t *part;   // [launch][nwg][qpw][klist]
     int nwg;                // workgroups of the scan
+    int qpw;                // queries per scan launch (32 or 128)
     int klist;
     int k;
     int b;
@@ -586,9 +848,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = blockIdx.x;
-    const int g = qi >> 5, ql = qi & 31;
+    const int g = qi / a.qpw, ql = qi % a.qpw;
     const int klist = a.klist;
-    const uint64_t *pg = a.part + (size_t)g * a.nwg * 32 * klist;
+    const uint64_t *pg = a.part + (size_t)g * a.nwg * a.qpw * klist;
     const int m_total = a.nwg * klist;
 
     // ---- 1. best klist candidate keys over all workgroups (chunked bitonic) ----
@@ -600,7 +862,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
             uint64_t v = 0;
             if (e < m_total) {
                 const int wg = e / klist, p = e - wg * klist;
-                v = pg[((size_t)wg * 32 + ql) * klist + p];
+                v = pg[((size_t)wg * a.qpw + ql) * klist + p];
             }
             keys[kMaxList + i] = v;
         }
