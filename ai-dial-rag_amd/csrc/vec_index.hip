@@ -167,6 +167,10 @@ static int32_t check_create_args(int64_t n, int32_t d, int32_t dtype, mir_index 
     return MIR_OK;
 }
 
+// Sample pre-pass of the 128-query scan: kSampleWgs workgroups x kSampleTilesPerWg tiles (64K rows)
+constexpr int kSampleWgs = 64;
+constexpr int kSampleTilesPerWg = 32;
+
 // carve helper
 struct Carver {
     char *base;
@@ -185,7 +189,9 @@ struct SearchBuffers {
     uint4 *qsplit;   // [ngroups][ksteps][2][64]
     double *q_sq;    // [b]
     double *q_norm;  // [b]
-    uint64_t *part;  // [ngroups][nwg][32][klist]
+    uint64_t *part;  // [ngroups][nwg][qpw][klist]
+    uint64_t *gthr;  // [ngroups][128] shared per-query thresholds of the 128-query scan
+    uint64_t *part_sample;  // [kSampleWgs][128][klist], reused by every launch (stream-ordered)
     int32_t *o_doc;  // host API staging of outputs, [b][k]
     int64_t *o_chunk;
     int64_t *o_row;
@@ -202,6 +208,8 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.q_sq = c.take<double>(b);
     sb.q_norm = c.take<double>(b);
     sb.part = c.take<uint64_t>((size_t)ngroups * nwg * qpw * klist);
+    sb.gthr = c.take<uint64_t>((size_t)ngroups * 128);
+    sb.part_sample = c.take<uint64_t>((size_t)kSampleWgs * 128 * klist);
     if (host_api) {
         sb.o_doc = c.take<int32_t>((size_t)b * k);
         sb.o_chunk = c.take<int64_t>((size_t)b * k);
@@ -277,8 +285,9 @@ static void release_ws(mir_index *ix, Workspace *w, hipStream_t used, bool pendi
 
 // LDS the 128-query scan needs for a list length
 static size_t b128_lds_bytes(int klist) {
-    // DMA ring (reused for the per-workgroup output at the end) + per-lane lists and pending buffers
-    return (size_t)kB128Stages * 8 * 2048 + (size_t)(klist + kB128Pending) * 256 * 8;
+    // DMA ring (at most 96 KiB: b128_ring_stages) (reused for the per-workgroup output at the end) + per-lane lists and pending
+    // buffers + the hi->lo partial-accumulator exchange (4 query tiles x 16 x 64 floats)
+    return (size_t)96 * 1024 + (size_t)(klist + kB128Pending) * 256 * 8 + 4 * 16 * 64 * 4;
 }
 
 template <int KIND>
@@ -319,7 +328,7 @@ static int32_t launch_scan(const mir_index *ix, const uint4 *qsplit_g, int nq, i
 
 template <int KIND>
 static int32_t launch_scan_b128(const mir_index *ix, const uint4 *qsplit_g, int nq, int klist, int nwg,
-                                uint64_t *part_g, hipStream_t stream) {
+                                uint32_t n_tiles, uint64_t *part_g, uint64_t *gthr_g, hipStream_t stream) {
     const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
     const size_t lds = b128_lds_bytes(klist);
     const uint32_t n_rows = (uint32_t)ix->n;
@@ -328,8 +337,8 @@ static int32_t launch_scan_b128(const mir_index *ix, const uint4 *qsplit_g, int 
         auto kern = scan_topk_b128_kernel<KS, KIND>;                                                         \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-        kern<<<dim3(nwg), dim3(256), lds, stream>>>(ix->d_split, aux, qsplit_g, n_rows, ix->n_tiles, nq,     \
-                                                    klist, part_g);                                          \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, n_rows, n_tiles, nq,         \
+                                                    klist, part_g, gthr_g);                                  \
         break;                                                                                               \
     }
     switch (ix->ksteps) {
@@ -361,6 +370,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                               int ngroups, int nwg, int klist, int qpw, int32_t *o_doc, int64_t *o_chunk, int64_t *o_row,
                               double *o_dist, int32_t *o_count, int32_t *o_flags, hipStream_t stream) {
     const int d = ix->d;
+    if (qpw == 128) MIR_HIP(hipMemsetAsync(sb.gthr, 0, (size_t)ngroups * 128 * 8, stream));
     const int ntiles32 = ngroups * (qpw / 32);  // 32-query fragment tiles, padded to whole launches
     prep_queries_kernel<<<dim3(ntiles32 * ix->ksteps + b), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, ntiles32,
                                                                                 sb.qsplit, sb.q_sq, sb.q_norm);
@@ -386,9 +396,26 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         const int nq = std::min(qpw, b - qpw * g);
         int32_t rc;
         if (qpw == 128) {
-            if (metric == MIR_METRIC_INNER_PRODUCT) rc = launch_scan_b128<SCAN_IP>(ix, qs, nq, klist, nwg, pg, stream);
-            else if (metric == MIR_METRIC_COSINE_SIM) rc = launch_scan_b128<SCAN_COS>(ix, qs, nq, klist, nwg, pg, stream);
-            else rc = launch_scan_b128<SCAN_L2>(ix, qs, nq, klist, nwg, pg, stream);
+            uint64_t *gt = sb.gthr + (size_t)g * 128;
+            auto run = [&](int wgs, uint32_t tiles, uint64_t *out) {
+                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_b128<SCAN_IP>(ix, qs, nq, klist, wgs, tiles, out, gt, stream);
+                if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_b128<SCAN_COS>(ix, qs, nq, klist, wgs, tiles, out, gt, stream);
+                return launch_scan_b128<SCAN_L2>(ix, qs, nq, klist, wgs, tiles, out, gt, stream);
+            };
+            // Large shard: scan a 64K-row sample first and seed every query's shared threshold with the
+            // sample's klist-th best key, so the full pass starts with tight thresholds instead of
+            // accepting almost everything for its first ~50 tiles per workgroup.
+            const uint32_t sample_tiles = (uint32_t)kSampleWgs * kSampleTilesPerWg;
+            rc = MIR_OK;
+            if (ix->n_tiles >= 16 * sample_tiles && kSampleWgs * klist <= 2048) {
+                rc = run(kSampleWgs, sample_tiles, sb.part_sample);
+                if (rc == MIR_OK) {
+                    sample_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(sb.part_sample, kSampleWgs, 128, klist, nq,
+                                                                                reinterpret_cast<unsigned long long *>(gt));
+                    MIR_HIP(hipGetLastError());
+                }
+            }
+            if (rc == MIR_OK) rc = run(nwg, ix->n_tiles, pg);
         } else if (metric == MIR_METRIC_INNER_PRODUCT) rc = launch_scan<SCAN_IP>(ix, qs, nq, klist, nwg, pg, stream);
         else if (metric == MIR_METRIC_COSINE_SIM) rc = launch_scan<SCAN_COS>(ix, qs, nq, klist, nwg, pg, stream);
         else rc = launch_scan<SCAN_L2>(ix, qs, nq, klist, nwg, pg, stream);

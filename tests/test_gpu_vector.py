@@ -221,6 +221,44 @@ def test_batches_larger_than_a_query_group(amd):
         np.testing.assert_allclose(dist[i], wdist, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("metric", ["sqeuclidean_dist", "cosine_sim", "inner_product"])
+def test_large_shard_wide_scan_with_sample_thresholds(amd, metric):
+    """1.2M rows x 128 queries: the 128-query K-split scan including its sample pre-pass (only taken for
+    shards of >= 32768 tiles).  Oracle on 6 queries (the CPU path costs ~1 s per query here); planted
+    duplicates must resolve to the lower row; every flag must be clear; repeated runs must agree bit for bit
+    (the scan has inter-wave hand-offs: a race would show up as run-to-run differences)."""
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(77)
+    n = 1_200_000
+    docs = rng.standard_normal((n, 384), dtype=np.float32)
+    docs /= np.linalg.norm(docs, axis=1, keepdims=True)
+    qs = unit(rng.standard_normal((128, 384))).astype(np.float64)
+    docs[900_001] = docs[77]
+    docs[1_199_999] = docs[77]
+    qs[0] = docs[77]
+    dev = amd.ei.DeviceIndex.from_host(docs)
+    runs = [dev.search(qs, 10, metric) for _ in range(3)]
+    for r in runs[1:]:
+        np.testing.assert_array_equal(r[2], runs[0][2])
+        np.testing.assert_array_equal(r[3], runs[0][3])
+    _, _, rows, dist, cnt, flags = runs[0]
+    assert (cnt == 10).all()
+    assert flags[1:].sum() == 0  # query 0 ties exactly at the cut by construction
+    assert list(rows[0, :3]) == [77, 900_001, 1_199_999]
+    for i in range(6):
+        wrows, wdist = oi.find_flat(qs[i], docs, metric, 10)
+        alld = None
+        if metric == "cosine_sim":
+            alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs)
+        assert_same_ids(metric, rows[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} q={i}")
+        np.testing.assert_allclose(dist[i], wdist, rtol=0, atol=2e-7)
+    # B = 1 .. 32 take the 32-query kernel: same answers
+    _, _, rows32, dist32, _, _ = dev.search(qs[:32], 10, metric)
+    np.testing.assert_array_equal(rows32, rows[:32])
+    np.testing.assert_array_equal(dist32, dist[:32])
+
+
 def test_k_above_list_capacity_is_refused_not_wrong(amd):
     rng = np.random.default_rng(4)
     dev = amd.ei.DeviceIndex.from_host(unit(rng.standard_normal((500, 32))))
