@@ -160,8 +160,8 @@ static int32_t check_create_args(int64_t n, int32_t d, int32_t dtype, mir_index 
     *out = nullptr;
     MIR_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "n=%lld out of range [0, 2^31)", (long long)n);
     MIR_REQUIRE(d >= 1 && d <= 128 * 4096, "d=%d out of range", d);
-    if (dtype != MIR_DTYPE_F32) {
-        set_error("dtype %d not supported by this build (float32 only)", dtype);
+    if (dtype != MIR_DTYPE_F32 && dtype != MIR_DTYPE_F16) {
+        set_error("dtype %d not supported (float32 = 0, float16 = 1)", dtype);
         return MIR_ERR_UNSUPPORTED;
     }
     return MIR_OK;
@@ -377,7 +377,8 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     MIR_HIP(hipGetLastError());
     for (int g = 0; g < ngroups; ++g) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        if (ix->profiling) {
+        auto begin_profile = [&]() -> int32_t {  // brackets the dominant (full-shard) scan launch only
+            if (!ix->profiling) return MIR_OK;
             {
                 std::lock_guard<std::mutex> lk(ix->mu);
                 if (ix->prof_free.size() >= 2) {
@@ -390,7 +391,8 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                 MIR_HIP(hipEventCreate(&ev1));
             }
             MIR_HIP(hipEventRecord(ev0, stream));
-        }
+            return MIR_OK;
+        };
         const uint4 *qs = sb.qsplit + (size_t)g * (qpw / 32) * ix->ksteps * 128;
         uint64_t *pg = sb.part + (size_t)g * nwg * qpw * klist;
         const int nq = std::min(qpw, b - qpw * g);
@@ -415,10 +417,15 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                     MIR_HIP(hipGetLastError());
                 }
             }
+            if (rc == MIR_OK) rc = begin_profile();
             if (rc == MIR_OK) rc = run(nwg, ix->n_tiles, pg);
-        } else if (metric == MIR_METRIC_INNER_PRODUCT) rc = launch_scan<SCAN_IP>(ix, qs, nq, klist, nwg, pg, stream);
-        else if (metric == MIR_METRIC_COSINE_SIM) rc = launch_scan<SCAN_COS>(ix, qs, nq, klist, nwg, pg, stream);
-        else rc = launch_scan<SCAN_L2>(ix, qs, nq, klist, nwg, pg, stream);
+        } else {
+            rc = begin_profile();
+            if (rc != MIR_OK) return rc;
+            if (metric == MIR_METRIC_INNER_PRODUCT) rc = launch_scan<SCAN_IP>(ix, qs, nq, klist, nwg, pg, stream);
+            else if (metric == MIR_METRIC_COSINE_SIM) rc = launch_scan<SCAN_COS>(ix, qs, nq, klist, nwg, pg, stream);
+            else rc = launch_scan<SCAN_L2>(ix, qs, nq, klist, nwg, pg, stream);
+        }
         if (ev1) {
             (void)hipEventRecord(ev1, stream);
             std::lock_guard<std::mutex> lk(ix->mu);
@@ -506,7 +513,24 @@ static int32_t create_common(const void *emb, bool emb_on_device, int64_t n, int
     const size_t orig_bytes = (size_t)n * d * sizeof(float);
     MIR_TRY(hipMalloc(&ix->d_orig, std::max<size_t>(orig_bytes, 16)));
     ix->hbm_bytes += orig_bytes;
-    if (n > 0) MIR_TRY(hipMemcpyAsync(ix->d_orig, emb, orig_bytes, kind, stream));
+    if (n > 0 && dtype == MIR_DTYPE_F32) {
+        MIR_TRY(hipMemcpyAsync(ix->d_orig, emb, orig_bytes, kind, stream));
+    } else if (n > 0) {
+        // float16 input: widened exactly to float32 on the device.  Every float16 is hi + lo in
+        // bfloat16 exactly (11 significant bits <= 8 + 8), so the scan is EXACT on such an index.
+        void *tmp = nullptr;
+        MIR_TRY(hipMalloc(&tmp, orig_bytes / 2));
+        hipError_t e1 = hipMemcpyAsync(tmp, emb, orig_bytes / 2, kind, stream);
+        if (e1 == hipSuccess) {
+            const int64_t total = n * (int64_t)d;
+            widen_f16_kernel<<<dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), dim3(256), 0, stream>>>(
+                static_cast<const _Float16 *>(tmp), total, ix->d_orig);
+            e1 = hipGetLastError();
+        }
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(stream);
+        (void)hipFree(tmp);
+        MIR_TRY(e1);
+    }
     if (chunk_ids && n > 0) {
         MIR_TRY(hipMalloc(&ix->d_chunk, (size_t)n * 8));
         MIR_TRY(hipMemcpyAsync(ix->d_chunk, chunk_ids, (size_t)n * 8, kind, stream));

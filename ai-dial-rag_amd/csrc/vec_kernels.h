@@ -121,6 +121,12 @@ __global__ __launch_bounds__(256) void pack_split_f32_kernel(const float *__rest
     dst[(blk * 2 + 1) * 64 + lane] = pack8(lo);
 }
 
+// float16 [n*d] -> float32 (exact); grid-stride
+__global__ __launch_bounds__(256) void widen_f16_kernel(const _Float16 *__restrict__ src, int64_t total,
+                                                        float *__restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+
 // numpy's float32 pairwise sum of squares (numpy/_core/src/umath/loops_utils.h.src
 // `@TYPE@_pairwise_sum`, block size 128, 8 accumulators) so that doc_sq matches
 // `np.sum(docs**2, axis=1)` of embeddings_metrics.py:40 bit for bit.  The library

@@ -46,22 +46,24 @@ class DeviceIndex:
 
     @classmethod
     def from_host(cls, emb: np.ndarray, chunk_ids=None, doc_ids=None, device: int = 0, row_offset: int = 0):
-        emb = np.ascontiguousarray(emb, dtype=np.float32)
+        emb = np.asarray(emb)
+        dtype = nat.DTYPE_F16 if emb.dtype == np.float16 else nat.DTYPE_F32  # float16 matrices upload at half the bytes
+        emb = np.ascontiguousarray(emb, dtype=np.float16 if dtype == nat.DTYPE_F16 else np.float32)
         if emb.ndim != 2:
             raise ValueError(f"embeddings must be [n, d], got {emb.shape}")
         n, d = emb.shape
         ci = None if chunk_ids is None else np.ascontiguousarray(chunk_ids, dtype=np.int64)
         di = None if doc_ids is None else np.ascontiguousarray(doc_ids, dtype=np.int32)
         h = C.c_void_p()
-        nat.check(nat.lib.mir_index_create(nat.ptr(emb), n, d, nat.DTYPE_F32, nat.ptr(ci), nat.ptr(di), device, row_offset, C.byref(h)))
+        nat.check(nat.lib.mir_index_create(nat.ptr(emb), n, d, dtype, nat.ptr(ci), nat.ptr(di), device, row_offset, C.byref(h)))
         return cls(h, n, d, device)
 
     @classmethod
     def from_device_ptr(cls, emb_ptr: int, n: int, d: int, device: int, row_offset: int = 0, chunk_ids_ptr: int = 0,
-                        doc_ids_ptr: int = 0, stream: int = 0):
-        """Build from a float32 [n, d] matrix already in HBM (e.g. ``tensor.data_ptr()``)."""
+                        doc_ids_ptr: int = 0, stream: int = 0, float16: bool = False):
+        """Build from a float32 (or float16) [n, d] matrix already in HBM (e.g. ``tensor.data_ptr()``)."""
         h = C.c_void_p()
-        nat.check(nat.lib.mir_index_create_from_device(emb_ptr or None, n, d, nat.DTYPE_F32, chunk_ids_ptr or None,
+        nat.check(nat.lib.mir_index_create_from_device(emb_ptr or None, n, d, nat.DTYPE_F16 if float16 else nat.DTYPE_F32, chunk_ids_ptr or None,
                                                        doc_ids_ptr or None, device, row_offset, stream or None, C.byref(h)))
         return cls(h, n, d, device)
 

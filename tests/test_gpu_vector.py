@@ -259,6 +259,30 @@ def test_large_shard_wide_scan_with_sample_thresholds(amd, metric):
     np.testing.assert_array_equal(dist32, dist[:32])
 
 
+@pytest.mark.parametrize("metric", ["sqeuclidean_dist", "cosine_sim"])
+def test_float16_storage_d1024_multimodal_shape(amd, metric):
+    """BASELINE config 5 shape: d = 1024 float16 vectors, NOT normalised.  The oracle sees the float16 values
+    widened to float32; the GPU index is built straight from the float16 matrix."""
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(2024)
+    docs16 = rng.standard_normal((30000, 1024)).astype(np.float16)
+    docs16[12345] = docs16[77]
+    qs = rng.standard_normal((40, 1024))
+    qs[0] = docs16[77].astype(np.float64)
+    dev = amd.ei.DeviceIndex.from_host(docs16)
+    _, _, rows, dist, cnt, flags = dev.search(qs, 10, metric)
+    docs32 = docs16.astype(np.float32)
+    assert list(rows[0, :2]) == [77, 12345]
+    for i in range(40):
+        wrows, wdist = oi.find_flat(qs[i], docs32, metric, 10)
+        alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs32) if metric == "cosine_sim" else None
+        assert_same_ids(metric, rows[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} q={i}")
+        np.testing.assert_allclose(dist[i], wdist, rtol=1e-12, atol=2e-7)
+    if metric != "cosine_sim":  # full-vector API on the float16-built index; differs only by float64 summation order
+        np.testing.assert_allclose(dev.metric_eval(qs[1], metric), oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[1], docs32), rtol=1e-13)
+
+
 def test_k_above_list_capacity_is_refused_not_wrong(amd):
     rng = np.random.default_rng(4)
     dev = amd.ei.DeviceIndex.from_host(unit(rng.standard_normal((500, 32))))
