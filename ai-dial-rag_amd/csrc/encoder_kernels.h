@@ -249,72 +249,107 @@ __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ a
     }
 }
 
-// ---------------------------------------------------------------- E3: attention + output projection + LN
-// One wave per query tile.  Per head: S^T = K Q^T (keys on rows), online softmax
-// per lane (= per query), O^T += V^T P^T, then y^T += Wo^T[:, head] ctx^T.
-__global__ __launch_bounds__(256, 1) void attn_out_ln_kernel(const uint4 *__restrict__ qf, const uint4 *__restrict__ kf,
-                                                             const uint4 *__restrict__ vf,
-                                                             const TileInfo *__restrict__ ti, int n_tiles,
-                                                             const uint4 *__restrict__ wo, const float *__restrict__ bo,
-                                                             const float *__restrict__ gamma,
-                                                             const float *__restrict__ beta,
-                                                             const uint4 *__restrict__ act_in,
-                                                             uint4 *__restrict__ act_out) {
+// ---------------------------------------------------------------- E3a: attention
+// One wave per (head, query tile): light on registers, so several waves share a SIMD and
+// the softmax's VALU work overlaps other waves' MFMAs (at hd = 32 a 32x32 score tile is 4
+// MFMAs against ~100 VALU instructions: a one-wave-per-SIMD kernel is VALU-bound 4:1).
+// S^T = K Q^T keeps keys on rows, so the softmax statistics of a query are lane-local plus
+// one cross-half shuffle; P^T (converted in registers) is the B operand of O^T += V^T P^T.
+// Output: the context in ACT layout (feature block = head), read by the projection kernel.
+__global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict__ qf, const uint4 *__restrict__ kf,
+                                                        const uint4 *__restrict__ vf,
+                                                        const TileInfo *__restrict__ ti, int n_tiles,
+                                                        uint4 *__restrict__ ctx) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tt >= n_tiles) return;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_tiles * NH) return;
+    const int head = w / n_tiles, tt = w - head * n_tiles;   // neighbours share a sequence's K/V of one head
     const TileInfo info = ti[tt];
     const float scale_log2e = 0.17677669529663688f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e)
-    f32x16 y[NFB];
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) y[fb] = f32x16{0};
-
-    for (int head = 0; head < NH; ++head) {
-        const uint4 *qp = qf + ((size_t)(tt * NH + head) * 2) * 64 + lane;
-        const uint4 q0 = qp[0], q1 = qp[64];
-        f32x16 o = {0};
-        float m = -__builtin_inff(), l = 0.f;
-        for (int kt = 0; kt < info.seq_tiles; ++kt) {
-            const size_t kb = ((size_t)((info.seq_first_tile + kt) * NH + head) * 2) * 64 + lane;
-            const uint4 k0 = kf[kb], k1 = kf[kb + 64];
-            const uint4 v0 = vf[kb], v1 = vf[kb + 64];
-            f32x16 s = {0};
-            s = mfma(k0, q0, s);
-            s = mfma(k1, q1, s);
+    const uint4 *qp = qf + ((size_t)(tt * NH + head) * 2) * 64 + lane;
+    const uint4 q0 = qp[0], q1 = qp[64];
+    f32x16 o = {0};
+    float m = -__builtin_inff(), l = 0.f;
+    for (int kt = 0; kt < info.seq_tiles; ++kt) {
+        const size_t kb = ((size_t)((info.seq_first_tile + kt) * NH + head) * 2) * 64 + lane;
+        const uint4 k0 = kf[kb], k1 = kf[kb + 64];
+        const uint4 v0 = vf[kb], v1 = vf[kb + 64];
+        f32x16 s = {0};
+        s = mfma(k0, q0, s);
+        s = mfma(k1, q1, s);
+        float mx = -__builtin_inff();
+        if (kt == info.seq_tiles - 1) {  // only the sequence's last key tile can hold padding
             const int key0 = 32 * kt;
-            float mx = -__builtin_inff();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool valid = key0 + fi(r, h) < info.seq_len;
-                s[r] = valid ? s[r] * scale_log2e : -__builtin_inff();
+                s[r] = (key0 + fi(r, h) < info.seq_len) ? s[r] * scale_log2e : -__builtin_inff();
                 mx = fmaxf(mx, s[r]);
             }
-            mx = half_max(mx);
-            const float m_new = fmaxf(m, mx);
-            const float alpha = exp2f(m - m_new);
-            float ps = 0.f;
+        } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f(s[r] - m_new);
-                ps += s[r];
+                s[r] *= scale_log2e;
+                mx = fmaxf(mx, s[r]);
             }
-            l = fmaf(l, alpha, half_sum(ps));
-            m = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] *= alpha;
-            o = mfma(v0, acc_to_frag(s, 0), o);
-            o = mfma(v1, acc_to_frag(s, 1), o);
         }
-        const float inv = 1.0f / l;
+        mx = half_max(mx);
+        const float m_new = fmaxf(m, mx);
+        const float alpha = exp2f(m - m_new);
+        float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] *= inv;
-        const uint4 c0 = acc_to_frag(o, 0), c1 = acc_to_frag(o, 1);
-        const uint4 *wp = wo + (size_t)(2 * head) * 64 + lane;  // wo: [nt][ks = 24][64]
-#pragma unroll
-        for (int nt = 0; nt < NFB; ++nt) {
-            y[nt] = mfma(wp[(size_t)nt * KS_H * 64], c0, y[nt]);
-            y[nt] = mfma(wp[(size_t)nt * KS_H * 64 + 64], c1, y[nt]);
+        for (int r = 0; r < 16; ++r) {
+            s[r] = exp2f(s[r] - m_new);
+            ps += s[r];
         }
+        l = fmaf(l, alpha, half_sum(ps));
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        o = mfma(v0, acc_to_frag(s, 0), o);
+        o = mfma(v1, acc_to_frag(s, 1), o);
+    }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= inv;
+    uint4 *out = ctx + (size_t)tt * (NFB * 2 * 64) + (size_t)(head * 2) * 64 + lane;
+    out[0] = acc_to_frag(o, 0);
+    out[64] = acc_to_frag(o, 1);
+}
+
+// ---------------------------------------------------------------- E3b: output projection + residual + LN
+// One wave per token tile: the context's 24 fragments stay in registers as the B operand, the
+// projection weights stream as A fragments through an 8-deep register ring (as in qkv_kernel),
+// all 12 output tiles accumulate in registers so LayerNorm runs in the epilogue.
+__global__ __launch_bounds__(256, 1) void oproj_ln_kernel(const uint4 *__restrict__ ctx, int n_tiles,
+                                                          const uint4 *__restrict__ wo, const float *__restrict__ bo,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          const uint4 *__restrict__ act_in, uint4 *__restrict__ act_out) {
+    const int lane = threadIdx.x & 63;
+    const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tt >= n_tiles) return;
+    const uint4 *cin = ctx + (size_t)tt * (NFB * 2 * 64) + lane;
+    uint4 c[KS_H];
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) c[ks] = cin[ks * 64];
+    constexpr int R = 8;
+    const uint4 *wp = wo + lane;  // [nt][ks][64]
+    uint4 ring[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) ring[i] = wp[i * 64];
+    f32x16 y[NFB];
+#pragma unroll
+    for (int nt = 0; nt < NFB; ++nt) {
+        const uint4 *np = wo + (size_t)(nt + 1 < NFB ? nt + 1 : nt) * (KS_H * 64) + lane;
+        f32x16 acc = {0};
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) {
+            const int slot = ks % R;
+            acc = mfma(ring[slot], c[ks], acc);
+            ring[slot] = (ks + R < KS_H) ? wp[(ks + R) * 64] : np[(ks + R - KS_H) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wp = np;
+        y[nt] = acc;
     }
     residual_ln_store(y, act_in + (size_t)tt * (NFB * 2 * 64), bo, gamma, beta,
                       act_out + (size_t)tt * (NFB * 2 * 64), lane, true);
