@@ -50,8 +50,14 @@ struct mir_encoder {
     int64_t hbm_bytes = 0;
     std::mutex mu;  // one encode at a time per handle (the reference runs its encoder on 1-thread pools, cpu_pools.py:25-34)
     hipStream_t stream = nullptr;
-    void *ws = nullptr;
-    size_t ws_cap = 0;
+    // two workspace slots: the host stages pass p+1 while the GPU runs pass p
+    void *ws[2] = {nullptr, nullptr};
+    size_t ws_cap[2] = {0, 0};
+    hipEvent_t ws_done[2] = {nullptr, nullptr};
+    // pinned host staging per slot (pageable memory would make every hipMemcpyAsync block the
+    // host until the stream reaches it, serialising host staging with GPU work)
+    char *pin[2] = {nullptr, nullptr};
+    size_t pin_cap[2] = {0, 0};
 };
 
 namespace {
@@ -64,7 +70,11 @@ void free_encoder(mir_encoder *e) {
         (void)hipFree(l.wqkv); (void)hipFree(l.bqkv); (void)hipFree(l.wo); (void)hipFree(l.attn_params);
         (void)hipFree(l.wffn); (void)hipFree(l.ffn_params);
     }
-    (void)hipFree(e->ws);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(e->ws[i]);
+        if (e->pin[i]) (void)hipHostFree(e->pin[i]);
+        if (e->ws_done[i]) (void)hipEventDestroy(e->ws_done[i]);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -189,6 +199,8 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
         }
     }
     MIR_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    MIR_TRY(hipEventCreateWithFlags(&e->ws_done[0], hipEventDisableTiming));
+    MIR_TRY(hipEventCreateWithFlags(&e->ws_done[1], hipEventDisableTiming));
     {
         auto kern = ffn_ln_kernel;
         MIR_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -235,12 +247,29 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
     hipStream_t s = out_on_device ? user_stream : e->stream;
     const int nl = run_layers < 0 ? e->layers : std::min(run_layers, e->layers);
 
-    Batch b;
-    int s0 = 0;
+    Batch batches[2];
+    bool slot_busy[2] = {false, false};
+    struct Pending { float *dst; size_t off, bytes; float *hid_dst; size_t hid_off, hid_bytes; } pend[2] = {};
+    auto retire = [&](int slot) -> int32_t {  // wait for the slot's pass, move its pinned results to the caller
+        if (!slot_busy[slot]) return MIR_OK;
+        MIR_HIP(hipEventSynchronize(e->ws_done[slot]));
+        slot_busy[slot] = false;
+        if (pend[slot].dst) std::memcpy(pend[slot].dst, e->pin[slot] + pend[slot].off, pend[slot].bytes);
+        if (pend[slot].hid_dst) std::memcpy(pend[slot].hid_dst, e->pin[slot] + pend[slot].hid_off, pend[slot].hid_bytes);
+        pend[slot] = Pending{};
+        return MIR_OK;
+    };
+    int s0 = 0, pass = 0;
     while (s0 < n_seq) {
+        const int slot = pass & 1;
+        Batch &b = batches[slot];
         // greedy pass: as many sequences as fit in kMaxTilesPerPass tiles
         int s1 = s0, tiles = 0;
         while (s1 < n_seq && tiles + (seq_lens[s1] + 31) / 32 <= kMaxTilesPerPass) { tiles += (seq_lens[s1] + 31) / 32; ++s1; }
+        // this slot's previous pass (two passes ago) must be done before its staging vectors and
+        // device buffers are reused; the pass in between keeps the GPU busy meanwhile
+        rc = retire(slot);
+        if (rc != MIR_OK) return rc;
         build_batch(token_ids, offs.data(), seq_lens, s0, s1, b);
         const int nt = (int)b.tiles.size();
         const size_t act_b = (size_t)nt * NFB * 2 * 64 * 16;
@@ -250,18 +279,32 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         const size_t o_a = take(act_b), o_b = take(act_b), o_q = take(act_b), o_k = take(act_b), o_v = take(act_b);
         const size_t o_out = take((size_t)(s1 - s0) * H * 4);
         const size_t o_hid = hidden_out ? take((size_t)nt * 32 * H * 4) : 0;
-        if (e->ws_cap < off) {
-            if (e->ws) { (void)hipStreamSynchronize(s); (void)hipFree(e->ws); }
-            e->ws = nullptr; e->ws_cap = 0;
-            MIR_HIP(hipMalloc(&e->ws, off));
-            e->ws_cap = off;
+        if (e->ws_cap[slot] < off) {
+            if (e->ws[slot]) (void)hipFree(e->ws[slot]);   // idle: its event was waited for above
+            e->ws[slot] = nullptr; e->ws_cap[slot] = 0;
+            MIR_HIP(hipMalloc(&e->ws[slot], off));
+            e->ws_cap[slot] = off;
         }
-        char *w = static_cast<char *>(e->ws);
-        MIR_HIP(hipMemcpyAsync(w + o_ids, b.ids.data(), b.ids.size() * 4, hipMemcpyHostToDevice, s));
-        MIR_HIP(hipMemcpyAsync(w + o_ti, b.tiles.data(), b.tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice, s));
-        MIR_HIP(hipMemcpyAsync(w + o_sf, b.seq_first.data(), b.seq_first.size() * 4, hipMemcpyHostToDevice, s));
-        // the staging vectors are reused by the next pass: the copies above must have left host memory
-        MIR_HIP(hipStreamSynchronize(s));
+        char *w = static_cast<char *>(e->ws[slot]);
+        // pinned mirror of the small host<->device regions: [ids | tiles | seq_first | out | hidden]
+        const size_t p_ids = 0, p_ti = p_ids + ((b.ids.size() * 4 + 255) & ~(size_t)255);
+        const size_t p_sf = p_ti + ((b.tiles.size() * sizeof(TileInfo) + 255) & ~(size_t)255);
+        const size_t p_out = p_sf + ((b.seq_first.size() * 4 + 255) & ~(size_t)255);
+        const size_t p_hid = p_out + (((size_t)(s1 - s0) * H * 4 + 255) & ~(size_t)255);
+        const size_t p_need = p_hid + (hidden_out ? (size_t)nt * 32 * H * 4 : 0);
+        if (e->pin_cap[slot] < p_need) {
+            if (e->pin[slot]) (void)hipHostFree(e->pin[slot]);
+            e->pin[slot] = nullptr; e->pin_cap[slot] = 0;
+            MIR_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->pin[slot]), p_need, hipHostMallocDefault));
+            e->pin_cap[slot] = p_need;
+        }
+        char *pn = e->pin[slot];
+        std::memcpy(pn + p_ids, b.ids.data(), b.ids.size() * 4);
+        std::memcpy(pn + p_ti, b.tiles.data(), b.tiles.size() * sizeof(TileInfo));
+        std::memcpy(pn + p_sf, b.seq_first.data(), b.seq_first.size() * 4);
+        MIR_HIP(hipMemcpyAsync(w + o_ids, pn + p_ids, b.ids.size() * 4, hipMemcpyHostToDevice, s));
+        MIR_HIP(hipMemcpyAsync(w + o_ti, pn + p_ti, b.tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice, s));
+        MIR_HIP(hipMemcpyAsync(w + o_sf, pn + p_sf, b.seq_first.size() * 4, hipMemcpyHostToDevice, s));
         const int32_t *d_ids = reinterpret_cast<int32_t *>(w + o_ids);
         const TileInfo *d_ti = reinterpret_cast<TileInfo *>(w + o_ti);
         uint4 *a0 = reinterpret_cast<uint4 *>(w + o_a), *a1 = reinterpret_cast<uint4 *>(w + o_b);
@@ -280,17 +323,26 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         float *d_out = out_on_device ? out + (size_t)s0 * H : reinterpret_cast<float *>(w + o_out);
         pool_normalize_kernel<<<dim3(s1 - s0), dim3(64), 0, s>>>(a0, reinterpret_cast<int32_t *>(w + o_sf), s1 - s0, normalize, d_out);
         MIR_HIP(hipGetLastError());
-        if (!out_on_device)
-            MIR_HIP(hipMemcpyAsync(out + (size_t)s0 * H, d_out, (size_t)(s1 - s0) * H * 4, hipMemcpyDeviceToHost, s));
+        if (!out_on_device) {
+            MIR_HIP(hipMemcpyAsync(pn + p_out, d_out, (size_t)(s1 - s0) * H * 4, hipMemcpyDeviceToHost, s));
+            pend[slot].dst = out + (size_t)s0 * H; pend[slot].off = p_out; pend[slot].bytes = (size_t)(s1 - s0) * H * 4;
+        }
         if (hidden_out) {
             MIR_REQUIRE((int64_t)nt * 32 <= hidden_cap_tokens, "hidden_out too small: need %d tokens", nt * 32);
             act_unpack_kernel<<<dim3(nt), dim3(64), 0, s>>>(a0, nt, reinterpret_cast<float *>(w + o_hid));
-            MIR_HIP(hipMemcpyAsync(hidden_out, w + o_hid, (size_t)nt * 32 * H * 4, hipMemcpyDeviceToHost, s));
+            MIR_HIP(hipMemcpyAsync(pn + p_hid, w + o_hid, (size_t)nt * 32 * H * 4, hipMemcpyDeviceToHost, s));
+            pend[slot].hid_dst = hidden_out; pend[slot].hid_off = p_hid; pend[slot].hid_bytes = (size_t)nt * 32 * H * 4;
         }
-        // the workspace is reused by the next pass (and by the next call)
-        MIR_HIP(hipStreamSynchronize(s));
+        MIR_HIP(hipEventRecord(e->ws_done[slot], s));
+        slot_busy[slot] = true;
         s0 = s1;
+        ++pass;
     }
+    // drain: results reach the caller's buffers, the workspaces become reusable
+    rc = retire(0);
+    if (rc == MIR_OK) rc = retire(1);
+    if (rc != MIR_OK) return rc;
+    MIR_HIP(hipStreamSynchronize(s));
     return MIR_OK;
 }
 

@@ -408,17 +408,30 @@ __global__ __launch_bounds__(256, 1) void ffn_ln_kernel(const uint4 *__restrict_
         unsigned char *nxt = (ht & 1) ? stage0 : stage1;
         if (ht + 1 < NHT) issue(ht + 1, nxt);
         const uint4 *st = reinterpret_cast<const uint4 *>(cur) + lane;
+        // The stage's 48 fragments are consumed in order (24 for W1, 24 for W2) through a 4-slot
+        // register ring filled three fragments ahead: left to hipcc, every MFMA sits behind its own
+        // ds_read + lgkmcnt(0) and the matrix pipe idles for the LDS latency 48 times per stage.
+        // The W2 fragments needed first are thereby already in flight while GELU runs.
+        uint4 fr[4];
+        fr[0] = st[0 * 64];
+        fr[1] = st[1 * 64];
+        fr[2] = st[2 * 64];
         f32x16 hacc = {0};
 #pragma unroll
-        for (int ks = 0; ks < KS_H; ++ks) hacc = mfma(st[ks * 64], x[ks], hacc);
+        for (int ks = 0; ks < KS_H; ++ks) {
+            fr[(ks + 3) & 3] = st[(ks + 3) * 64];   // ks + 3 <= 26: runs into the W2 part
+            __builtin_amdgcn_sched_barrier(0);
+            hacc = mfma(fr[ks & 3], x[ks], hacc);
+        }
         const float *b1 = prm + 32 * ht;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[r] = gelu(hacc[r] + b1[fi(r, h)]);
         const uint4 h0 = acc_to_frag(hacc, 0), h1 = acc_to_frag(hacc, 1);
 #pragma unroll
-        for (int nt = 0; nt < NFB; ++nt) {
-            y[nt] = mfma(st[(24 + 2 * nt) * 64], h0, y[nt]);
-            y[nt] = mfma(st[(25 + 2 * nt) * 64], h1, y[nt]);
+        for (int i = 0; i < 24; ++i) {
+            if (i + 3 < 24) fr[(i + 3) & 3] = st[(24 + i + 3) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            y[i >> 1] = mfma(fr[i & 3], (i & 1) ? h1 : h0, y[i >> 1]);
         }
         __syncthreads();  // next stage landed; everyone is done with `cur`
     }
