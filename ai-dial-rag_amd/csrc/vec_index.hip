@@ -167,9 +167,10 @@ static int32_t check_create_args(int64_t n, int32_t d, int32_t dtype, mir_index 
     return MIR_OK;
 }
 
-// Sample pre-pass of the 128-query scan: kSampleWgs workgroups x kSampleTilesPerWg tiles (64K rows)
-constexpr int kSampleWgs = 64;
-constexpr int kSampleTilesPerWg = 32;
+// Sample pre-pass of the 128-query scan: kSampleWgs workgroups x kSampleTilesPerWg tiles (64K rows);
+// at most 1024 workgroups (merge_sorted_lists gives each of 256 threads up to 4 lists)
+constexpr int kSampleWgs = 256;
+constexpr int kSampleTilesPerWg = 8;
 
 // carve helper
 struct Carver {
@@ -409,7 +410,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             // accepting almost everything for its first ~50 tiles per workgroup.
             const uint32_t sample_tiles = (uint32_t)kSampleWgs * kSampleTilesPerWg;
             rc = MIR_OK;
-            if (ix->n_tiles >= 16 * sample_tiles && kSampleWgs * klist <= 2048) {
+            if (ix->n_tiles >= 16 * sample_tiles) {
                 rc = run(kSampleWgs, sample_tiles, sb.part_sample);
                 if (rc == MIR_OK) {
                     sample_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(sb.part_sample, kSampleWgs, 128, klist, nq,
@@ -460,7 +461,8 @@ static int32_t plan(const mir_index *ix, int b, int k, int *ngroups, int *nwg, i
     *ngroups = (b + *qpw - 1) / *qpw;
     // one workgroup per CU; never more workgroups than there are 4-tile chunks of work
     const int64_t want = ((int64_t)ix->n_tiles + 3) / 4;
-    *nwg = (int)std::max<int64_t>(1, std::min<int64_t>(ix->num_cus, want));
+    // (finalize's tournament gives each of its 256 threads up to 4 workgroup lists)
+    *nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want));
     return MIR_OK;
 }
 

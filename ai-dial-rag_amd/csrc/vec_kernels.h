@@ -946,6 +946,52 @@ __device__ inline void bitonic_sort_desc(uint64_t *keys, int n, int tid) {
     __syncthreads();
 }
 
+// Best `klist` keys of `nwg` per-workgroup lists that are each already sorted (the scan kernels
+// emit their lists by rank).  A tournament over the list heads: every thread owns up to 4 lists,
+// per round one block-wide max picks the winner and only its owner advances.  ~klist rounds of a
+// few hundred cycles instead of a bitonic sort of all nwg*klist keys.  Keys are distinct (they
+// carry the row), 0 = empty.  out[0..klist) receives the keys, best first, 0-padded.
+__device__ inline void merge_sorted_lists(const uint64_t *__restrict__ lists, size_t list_stride, int nwg, int klist,
+                                          uint64_t *out, uint64_t *red /*[4]*/, int tid) {
+    int head[4];
+    uint64_t cur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int wg = tid + 256 * j;
+        head[j] = 0;
+        cur[j] = wg < nwg ? lists[(size_t)wg * list_stride] : 0;
+    }
+    for (int r = 0; r < klist; ++r) {
+        uint64_t mine = cur[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) mine = cur[j] > mine ? cur[j] : mine;
+        uint64_t best = mine;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(best >> 32), off, 64) << 32) |
+                               (uint64_t)__shfl_xor((uint32_t)best, off, 64);
+            best = o > best ? o : best;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = best;
+        __syncthreads();
+        best = red[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
+        __syncthreads();
+        if (tid == 0) out[r] = best;
+        if (best != 0 && mine == best) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (cur[j] == best) {
+                    ++head[j];
+                    cur[j] = head[j] < klist ? lists[(size_t)(tid + 256 * j) * list_stride + head[j]] : 0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 struct FinalizeArgs {
     const uint64_t *part;   // [launch][nwg][qpw][klist]
     int nwg;                // workgroups of the scan
@@ -974,7 +1020,8 @@ struct FinalizeArgs {
 
 // grid = b (one block per query), block = 256, static LDS 64 KiB + small.
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
-    __shared__ uint64_t keys[kSortN];
+    __shared__ uint64_t keys[kMaxList];
+    __shared__ uint64_t red[4];
     __shared__ double c_dist[kMaxList];
     __shared__ double c_rank[kMaxList];
     __shared__ uint32_t c_row[kMaxList];
@@ -985,28 +1032,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     const int g = qi / a.qpw, ql = qi % a.qpw;
     const int klist = a.klist;
     const uint64_t *pg = a.part + (size_t)g * a.nwg * a.qpw * klist;
-    const int m_total = a.nwg * klist;
 
-    // ---- 1. best klist candidate keys over all workgroups (chunked bitonic) ----
-    const int chunk = kSortN - kMaxList;
-    for (int i = tid; i < kMaxList; i += 256) keys[i] = 0;
-    for (int base = 0; base < m_total; base += chunk) {
-        for (int i = tid; i < chunk; i += 256) {
-            const int e = base + i;
-            uint64_t v = 0;
-            if (e < m_total) {
-                const int wg = e / klist, p = e - wg * klist;
-                v = pg[((size_t)wg * a.qpw + ql) * klist + p];
-            }
-            keys[kMaxList + i] = v;
-        }
-        bitonic_sort_desc(keys, kSortN, tid);  // begins and ends with a barrier
-        // survivors stay in keys[0..klist); clear the rest of the carry window
-        for (int i = klist + tid; i < kMaxList; i += 256) keys[i] = 0;
-        __syncthreads();
-    }
+    // ---- 1. best klist candidate keys over all workgroups (tournament over the sorted lists) ----
+    merge_sorted_lists(pg + (size_t)ql * klist, (size_t)a.qpw * klist, a.nwg, klist, keys, red, tid);
     int nc = 0;
-    for (int i = 0; i < klist; ++i) nc += keys[i] != 0 ? 1 : 0;  // sorted: valid ones first
+    for (int i = 0; i < klist; ++i) nc += keys[i] != 0 ? 1 : 0;  // valid ones first
 
     // ---- 2. re-score the candidates exactly (float64, reference formulas) ----
     const double *q = a.q + (size_t)qi * a.d;
@@ -1065,23 +1095,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
 // ---------------------------------------------------------------- sample thresholds
 // After a scan of a SAMPLE of the rows: the klist-th best key of the sample is a lower bound on
 // the klist-th best key of the whole index (the sample is a subset), so it is a valid starting
-// threshold for every list of the full scan.  One block per query; nwg*klist <= 2048 keys.
+// threshold for every list of the full scan.  One block per query.
 __global__ __launch_bounds__(256) void sample_threshold_kernel(const uint64_t *__restrict__ part, int nwg, int qpw,
                                                                int klist, int b_in_launch,
                                                                unsigned long long *__restrict__ gthr) {
-    __shared__ uint64_t keys[2048];
+    __shared__ uint64_t keys[kMaxList];
+    __shared__ uint64_t red[4];
     const int tid = threadIdx.x, q = blockIdx.x;
     if (q >= b_in_launch) return;
-    const int m = nwg * klist;
-    for (int i = tid; i < 2048; i += 256) {
-        uint64_t v = 0;
-        if (i < m) {
-            const int wg = i / klist, p = i - wg * klist;
-            v = part[((size_t)wg * qpw + q) * klist + p];
-        }
-        keys[i] = v;
-    }
-    bitonic_sort_desc(keys, 2048, tid);
+    merge_sorted_lists(part + (size_t)q * klist, (size_t)qpw * klist, nwg, klist, keys, red, tid);
     if (tid == 0 && keys[klist - 1] != 0)
         __hip_atomic_fetch_max(gthr + q, (unsigned long long)keys[klist - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--metric", default="sqeuclidean_dist")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-queries", type=int, default=4)
+    ap.add_argument("--encode-chunks", type=int, default=8192,
+                    help="chunks per GPU for the index-build (encoder) leg of the metric; 0 = skip")
     return ap.parse_args()
 
 
@@ -56,6 +58,69 @@ def gen_rows(torch, device, lo, hi, dim):
         out[a - lo : b - lo] = x[a - c * CHUNK_ROWS : b - c * CHUNK_ROWS]
         del x
     return out
+
+
+def random_bge_small_state_dict(np, seed=0):
+    """Random-init weights of the bge-small-en architecture (there is no network for the real checkpoint):
+    BERT, hidden 384, 12 layers, 12 heads, FFN 1536, vocab 30522 - Hugging Face parameter names."""
+    rng = np.random.default_rng(seed)
+    w = lambda *shape: (rng.standard_normal(shape) * 0.02).astype(np.float32)  # noqa: E731
+    sd = {
+        "embeddings.word_embeddings.weight": w(30522, 384),
+        "embeddings.position_embeddings.weight": w(512, 384),
+        "embeddings.token_type_embeddings.weight": w(2, 384),
+        "embeddings.LayerNorm.weight": np.ones(384, np.float32),
+        "embeddings.LayerNorm.bias": np.zeros(384, np.float32),
+    }
+    for i in range(12):
+        p = f"encoder.layer.{i}."
+        for name, shape in (("attention.self.query", (384, 384)), ("attention.self.key", (384, 384)),
+                            ("attention.self.value", (384, 384)), ("attention.output.dense", (384, 384)),
+                            ("intermediate.dense", (1536, 384)), ("output.dense", (384, 1536))):
+            sd[p + name + ".weight"] = w(*shape)
+            sd[p + name + ".bias"] = np.zeros(shape[0], np.float32)
+        for name in ("attention.output.LayerNorm", "output.LayerNorm"):
+            sd[p + name + ".weight"] = np.ones(384, np.float32)
+            sd[p + name + ".bias"] = np.zeros(384, np.float32)
+    return sd
+
+
+def encoder_leg(np, torch, dist, args, world, rank, local_rank, barrier):
+    """Index-build half of the metric: chunks/s of the bge-small-en forward (CLS + L2 normalise), every rank
+    encoding its own `--encode-chunks` synthetic chunks (token ids, length ~N(220, 60) clipped to [8, 512],
+    SURVEY.md 8(d)) straight into HBM.  Pure data parallel: no communication."""
+    from aidial_rag_amd.embeddings.embeddings import BgeEncoder
+
+    enc = BgeEncoder.from_state_dict(random_bge_small_state_dict(np), device=local_rank)
+    rng = np.random.default_rng(99 + rank)
+    n = args.encode_chunks
+    lens = np.clip(np.round(rng.normal(220, 60, n)), 8, 512).astype(np.int64)
+    seqs = [rng.integers(999, 30522, L).astype(np.int32) for L in lens]
+    out = torch.empty((n, 384), dtype=torch.float32, device=f"cuda:{local_rank}")
+    stream = torch.cuda.current_stream().cuda_stream
+    enc.encode_ids_to_device(seqs[:512], out.data_ptr(), stream)  # warm-up (buffers, code objects)
+    barrier()
+    t0 = time.perf_counter()
+    enc.encode_ids_to_device(seqs, out.data_ptr(), stream)
+    barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    tokens = int(lens.sum())
+    flops = float(sum(12 * (L * (2 * 384 * 1152 + 2 * 384 * 384 + 4 * 384 * 1536) + 4 * L * L * 384) for L in lens))
+    norms_ok = bool(torch.allclose(out.norm(dim=1), torch.ones(n, device=out.device), atol=1e-4))
+    enc.close()
+    return {
+        "index_build_chunks_per_s": round(world * n / dt, 1),
+        "chunks_per_gpu": n,
+        "mean_tokens_per_chunk": round(tokens / n, 1),
+        "tflops_per_gpu_real_tokens": round(flops / dt / 1e12, 1),
+        "mfma_peak_tflops_f16_dense": 2500.0,
+        "frac_of_mfma_peak": round(flops / dt / 1e12 / 2500.0, 4),
+        "weights": "random init, bge-small-en shape",
+        "unit_norm_outputs": norms_ok,
+    }
 
 
 def main():
@@ -197,6 +262,9 @@ def main():
         "index_build_s": {"generate": round(t_gen, 2), "upload_pack_norms": round(t_build, 2)},
     }
 
+    if args.encode_chunks > 0:
+        index.close()  # release the shard before the encoder leg allocates its workspaces
+        result["index_build"] = encoder_leg(np, torch, dist, args, world, rank, local_rank, barrier)
     if rank == 0 and world == 1 and sample is not None and len(sample):
         result["cpu_baseline"] = cpu_baseline(np, sample, queries[: args.cpu_queries].cpu().numpy(), args, DeviceIndex)
     if rank == 0:
