@@ -77,11 +77,141 @@ __device__ inline void block_select(int n, int kout, int tid, ScoreF score, Inde
         __syncthreads();
         if (gp < 0) break;  // fewer candidates than kout (uniform)
         if (tid == 0) emit(r, gs, gi);
-        if (gp == bp) {  // this thread owned the winner
-            take(gp);
-            local_best(bs, bi, bp);
-        }
+        // the winner's owner consumes it; every thread whose cached best is the winner (or another
+        // posting of the same document) rescans once the consumption is visible
+        const bool stale = bp >= 0 && gi == bi;
+        if (gp == bp) take(gp);
+        __syncthreads();
+        if (stale) local_best(bs, bi, bp);
     }
+}
+
+// Block-wide exact top-k without rounds (a round of block_select is a chain of ~30 dependent
+// shuffles; an exact float64+index comparison loop costs ~50 cycles per candidate pair).  Three
+// cheap stages cut the candidates down before any exact comparison:
+//   A  (n > 256) the k-th best float32 key of a 256-candidate sample bounds the answer from below;
+//   B  candidates whose float32 key reaches that bound go to an LDS list (expected ~ k*n/256);
+//   C  a list entry is a finalist if fewer than k list keys are strictly greater than its own -
+//      float32 rounding is monotone, so every true top-k entry is a finalist;
+//   D  finalists (about k of them) are ranked exactly: (score desc, index desc).
+// emit(rank, score, index) runs on the owning thread.  List overflows (adversarial order, or a mass
+// of equal keys) go to `fallback`.  Returns the number of results (uniform).
+constexpr int kTopkList = 512;
+constexpr int kTopkDirect = 256;
+constexpr int kTopkFinal = 64;
+
+struct __align__(16) TopkLds {
+    float kf[kTopkList + 4];
+    double cs[kTopkList];
+    double fs[kTopkFinal];
+    int ci[kTopkList];
+    int fi[kTopkFinal];
+    int cnt, fcnt;
+    float thr;
+};
+
+// wave-aggregated append: one LDS atomic per wave instead of one per lane (all lanes must call)
+__device__ __forceinline__ int wave_append(bool want, int *counter) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    int start = 0;
+    if (lane == leader) start = atomicAdd(counter, __popcll(mask));
+    start = __shfl(start, leader, 64);
+    return want ? start + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+}
+
+// number of keys in kf[0, m4) strictly greater than (gt) / not less than (ge) `key`; m4 % 4 == 0
+__device__ __forceinline__ void count_keys(const float *kf, int m4, float key, int &gt, int &ge) {
+    gt = 0;
+    ge = 0;
+    for (int u = 0; u < m4; u += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(kf + u);
+        gt += (v.x > key) + (v.y > key) + (v.z > key) + (v.w > key);
+        ge += (v.x >= key) + (v.y >= key) + (v.z >= key) + (v.w >= key);
+    }
+}
+__device__ __forceinline__ int count_greater(const float *kf, int m4, float key) {
+    int gt = 0;
+    for (int u = 0; u < m4; u += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(kf + u);
+        gt += (v.x > key) + (v.y > key) + (v.z > key) + (v.w > key);
+    }
+    return gt;
+}
+
+template <typename ScoreF, typename IndexF, typename EmitF, typename FallbackF>
+__device__ inline int block_topk(int n, int k, int tid, ScoreF score, IndexF index, EmitF emit, FallbackF fallback,
+                                 TopkLds &L) {
+    const double NEG = -__builtin_inf();
+    const float NEGF = -__builtin_inff();
+    int m, result;
+    if (n <= kTopkDirect) {  // the candidates themselves are the list, one per thread
+        double s = NEG;
+        int ix = -1;
+        if (tid < n) { s = score(tid); ix = (int)index(tid); }
+        L.cs[tid] = s;
+        L.ci[tid] = ix;
+        L.kf[tid] = (float)s;
+        if (tid == 0) L.fcnt = 0;
+        const int nvalid = __syncthreads_count(s != NEG);
+        m = n;
+        result = k < nvalid ? k : nvalid;
+    } else {
+        {   // A: bound from the first 256 candidates
+            const double s = score(tid);
+            const float key = (float)s;
+            L.kf[tid] = key;
+            if (tid == 0) { L.thr = NEGF; L.cnt = 0; L.fcnt = 0; }
+            __syncthreads();
+            if (s != NEG) {
+                int gt, ge;
+                count_keys(L.kf, 256, key, gt, ge);
+                if (gt < k && k <= ge) L.thr = key;  // the tie group holding rank k (all its members write the same value)
+            }
+            __syncthreads();
+        }
+        const float thr = L.thr;
+        __syncthreads();  // everyone has read the sample keys and the bound before the list overwrites them
+        for (int i0 = 0; i0 < n; i0 += 256) {  // B
+            const int i = i0 + tid;
+            double s = NEG;
+            int ix = -1;
+            if (i < n) { s = score(i); ix = (int)index(i); }
+            const float key = (float)s;
+            const bool want = s != NEG && key >= thr;
+            const int slot = wave_append(want, &L.cnt);
+            if (want && slot < kTopkList) { L.cs[slot] = s; L.ci[slot] = ix; L.kf[slot] = key; }
+        }
+        __syncthreads();
+        m = L.cnt;
+        __syncthreads();  // all threads hold m before a fallback may reuse the counters
+        if (m > kTopkList) return fallback();
+        if (tid < 4) L.kf[m + tid] = NEGF;  // pad to a multiple of 4
+        __syncthreads();
+        result = k < m ? k : m;
+    }
+    const int m4 = (m + 3) & ~3;
+    for (int e0 = 0; e0 < m; e0 += 256) {  // C
+        const int e = e0 + tid;
+        bool fin = false;
+        if (e < m && L.cs[e] != NEG) fin = count_greater(L.kf, m4, L.kf[e]) < k;
+        const int slot = wave_append(fin, &L.fcnt);
+        if (fin && slot < kTopkFinal) { L.fs[slot] = L.cs[e]; L.fi[slot] = L.ci[e]; }
+    }
+    __syncthreads();
+    const int f = L.fcnt;
+    __syncthreads();
+    if (f > kTopkFinal) return fallback();
+    if (tid < f) {  // D
+        const double s = L.fs[tid];
+        const int ix = L.fi[tid];
+        int rank = 0;
+        for (int u = 0; u < f; ++u) rank += bm25_before(L.fs[u], (int64_t)L.fi[u], s, (int64_t)ix) ? 1 : 0;
+        if (rank < k) emit(rank, s, (int64_t)ix);
+    }
+    return result;
 }
 
 struct Bm25Dev {
@@ -96,8 +226,24 @@ struct Bm25Dev {
 };
 
 // grid = (ntiles, b), block = 256.  q_ptr[b+1] slices q_terms.
+//
+// The tile's work is a handful of dependent HBM hops, so the kernel is written to keep the chain
+// short rather than to save instructions: the metadata of up to 64 query terms is fetched by 64
+// lanes at once, then every thread fetches its share of ALL those terms' postings in one go
+// (registers), and only the LDS adds are serialised term by term - the order rank-bm25 adds in.
+//
+// SPARSE = true: the tile's top-k is selected only among the documents its postings touched and
+// only among positive scores (every untouched document scores exactly 0).  That is the whole answer
+// whenever the query has at least k positive documents - the common case; otherwise the caller
+// re-runs the query through the dense variant (`need_dense`), which ranks all documents of the tile,
+// zeros and negatives included, exactly as `argsort(stable)[::-1]` does.
+constexpr int kBm25Chunk = 64;     // query terms resolved per metadata round
+constexpr int kBm25Regs = 4;       // postings a thread holds per accumulate round (256*4 per round)
+constexpr int kBm25Cand = 1024;    // distinct touched documents listed per tile (sparse pass)
+
 __global__ __launch_bounds__(256) void bm25_tile_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms,
                                                         const int32_t *__restrict__ q_ptr, int k,
+                                                        const int32_t *__restrict__ need_dense,
                                                         double *__restrict__ out_scores,
                                                         double *__restrict__ part_score,
                                                         int32_t *__restrict__ part_idx,
@@ -106,23 +252,82 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(Bm25Dev m, const int32_t
     __shared__ double red_s[4];
     __shared__ int64_t red_i[4];
     __shared__ int red_p[4];
+    __shared__ int64_t m_lo[kBm25Chunk];
+    __shared__ double m_idf[kBm25Chunk];
+    __shared__ int m_off[kBm25Chunk + 1];
+    __shared__ int m_cnt;
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, q = blockIdx.y;
-    const int64_t base = (int64_t)tile * kBm25Tile;
+    if (need_dense && !need_dense[q]) return;   // fallback launch: only the flagged queries run
+    const int base = tile * kBm25Tile;
     const int cnt = (int)((m.n_docs - base) < kBm25Tile ? (m.n_docs - base) : kBm25Tile);
+    const int qb = q_ptr[q], qe = q_ptr[q + 1];
     for (int i = tid; i < kBm25Tile; i += 256) sc[i] = 0.0;
-    for (int j = q_ptr[q]; j < q_ptr[q + 1]; ++j) {
-        const int t = q_terms[j];
-        if (t < 0 || t >= m.vocab) continue;  // unknown term: `(doc.get(q) or 0)` everywhere
-        const double w_idf = m.idf[t];
-        if (w_idf == 0.0) continue;           // `(self.idf.get(q) or 0)`: adds +-0
-        const int64_t t0 = m.t_ptr[t];
-        const uint32_t *to = m.t_tile + (size_t)t * (m.ntiles + 1) + tile;
-        const int64_t lo = t0 + to[0], hi = t0 + to[1];
-        __syncthreads();  // previous term's adds are complete (t is block-uniform)
-        for (int64_t p = lo + tid; p < hi; p += 256) {
-            const int i = m.p_doc[p] - (int)base;
-            sc[i] = sc[i] + w_idf * m.p_w[p];  // one rounding for the product, one for the sum
+    for (int c0 = qb; c0 < qe; c0 += kBm25Chunk) {
+        __syncthreads();  // the previous chunk's table is consumed (and sc / touched are zeroed)
+        if (tid < 64) {   // wave 0, all lanes: one term each
+            const int j = c0 + tid;
+            bool valid = false;
+            int64_t lo = 0; int n = 0; double w_idf = 0.0;
+            if (j < qe) {
+                const int t = q_terms[j];
+                if (t >= 0 && t < m.vocab) {          // unknown term: `(doc.get(q) or 0)` everywhere
+                    w_idf = m.idf[t];
+                    const uint32_t *to = m.t_tile + (size_t)t * (m.ntiles + 1) + tile;
+                    const uint32_t a = to[0], b = to[1];
+                    lo = m.t_ptr[t] + a;
+                    n = (int)(b - a);
+                    valid = (w_idf != 0.0) && n > 0;  // `(self.idf.get(q) or 0)`: adds +-0
+                }
+            }
+            const unsigned long long mask = __ballot(valid);
+            const int pos = __popcll(mask & ((1ull << tid) - 1ull));
+            const int nt = __popcll(mask);
+            // exclusive prefix of n over the valid lanes, in lane (= query) order
+            int incl = valid ? n : 0;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += o;
+            }
+            if (valid) { m_lo[pos] = lo; m_idf[pos] = w_idf; m_off[pos] = incl - n; }
+            if (tid == 63) { m_off[nt] = incl; m_cnt = nt; }
+        }
+        __syncthreads();
+        const int nt = m_cnt, total = m_off[nt];
+        for (int r0 = 0; r0 < total; r0 += 256 * kBm25Regs) {
+            int d[kBm25Regs], tj[kBm25Regs];
+            double x[kBm25Regs];
+            int jmin = nt, jmax = -1;
+#pragma unroll
+            for (int r = 0; r < kBm25Regs; ++r) {
+                const int e = r0 + r * 256 + tid;
+                tj[r] = -1; d[r] = 0; x[r] = 0.0;
+                if (e < total) {
+                    int j = 0;
+                    while (m_off[j + 1] <= e) ++j;
+                    const int64_t p = m_lo[j] + (e - m_off[j]);
+                    d[r] = m.p_doc[p] - base;
+                    x[r] = m_idf[j] * m.p_w[p];  // one rounding for the product ...
+                    tj[r] = j;
+                }
+            }
+            {   // terms present in this round (uniform): those overlapping [r0, r0 + 1024)
+                int j = 0;
+                while (m_off[j + 1] <= r0) ++j;
+                jmin = j;
+                const int last = (r0 + 256 * kBm25Regs < total ? r0 + 256 * kBm25Regs : total) - 1;
+                while (m_off[j + 1] <= last) ++j;
+                jmax = j;
+            }
+            for (int j = jmin; j <= jmax; ++j) {
+#pragma unroll
+                for (int r = 0; r < kBm25Regs; ++r) {
+                    if (tj[r] == j) {
+                        sc[d[r]] = sc[d[r]] + x[r];  // ... and one for the sum; a document occurs once per term
+                    }
+                }
+                __syncthreads();  // term j's adds are complete before term j+1 touches the same documents
+            }
         }
     }
     __syncthreads();
@@ -130,36 +335,256 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(Bm25Dev m, const int32_t
         double *o = out_scores + (size_t)q * m.n_docs + base;
         for (int i = tid; i < cnt; i += 256) o[i] = sc[i];
     }
-    if (part_score) {
-        const double NEG = -__builtin_inf();
+    if (!part_score) return;
+    const double NEG = -__builtin_inf();
+    const size_t pb = ((size_t)q * m.ntiles + tile) * k;
+    int32_t *my_cnt = part_cnt + (size_t)q * m.ntiles + tile;
+    {
         for (int i = cnt + tid; i < kBm25Tile; i += 256) sc[i] = NEG;  // padding never selected
         __syncthreads();
         const int kout = k < cnt ? k : cnt;
-        const size_t pb = ((size_t)q * m.ntiles + tile) * k;
         block_select(
-            cnt, kout, tid, [&](int i) { return sc[i]; }, [&](int i) { return (int64_t)i; },
-            [&](int i) { sc[i] = NEG; },
-            [&](int r, double s, int64_t i) {
-                part_score[pb + r] = s;
+            cnt, kout, tid, [&](int i) { return sc[i]; }, [&](int i) { return (int64_t)i; }, [&](int i) { sc[i] = NEG; },
+            [&](int r, double v, int64_t i) {
+                part_score[pb + r] = v;
                 part_idx[pb + r] = (int32_t)(base + i);
             },
             red_s, red_i, red_p);
-        if (tid == 0) part_cnt[(size_t)q * m.ntiles + tile] = kout;
+        if (tid == 0) *my_cnt = kout;
+    }
+}
+
+// Fast pass.  grid = (ntiles, ceil(b / qc)), block = 256: a workgroup owns one tile and walks `qc`
+// queries through it, software-pipelined - while query q is accumulated and ranked in LDS, the
+// postings of q+1, the term metadata of q+2 and the term ids of q+3 are in flight, so the
+// three dependent HBM hops of a query cost nothing after the first.  Between queries only the
+// touched score slots are re-zeroed.  Emits, per (query, tile), the top-k among the POSITIVE
+// touched documents and their count; bm25_merge_kernel flags the queries that need the dense pass.
+constexpr int kBm25QcMax = 64;
+
+__global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms,
+                                                          const int32_t *__restrict__ q_ptr, int b, int qc, int k,
+                                                          double *__restrict__ part_score,
+                                                          int32_t *__restrict__ part_idx,
+                                                          int32_t *__restrict__ part_cnt) {
+    __shared__ double sc[kBm25Tile];
+    __shared__ double red_s[4];
+    __shared__ int64_t red_i[4];
+    __shared__ int red_p[4];
+    __shared__ int64_t tb_lo[2][kBm25Chunk];
+    __shared__ double tb_idf[2][kBm25Chunk];
+    __shared__ int tb_off[2][kBm25Chunk + 1];
+    __shared__ int tb_cnt[2];
+    __shared__ int s_qptr[kBm25QcMax + 1];
+    __shared__ uint32_t touched[kBm25Tile / 32];
+    __shared__ uint16_t cand[kBm25Cand];
+    __shared__ int ncand;
+    __shared__ TopkLds L;
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int q0 = blockIdx.y * qc;
+    const int nq = (b - q0) < qc ? (b - q0) : qc;
+    const int base = tile * kBm25Tile;
+    const int cnt = (int)((m.n_docs - base) < kBm25Tile ? (m.n_docs - base) : kBm25Tile);
+    const double NEG = -__builtin_inf();
+    for (int i = tid; i < kBm25Tile; i += 256) sc[i] = 0.0;
+    touched[tid] = 0;
+    if (tid == 0) ncand = 0;
+    if (tid <= nq) s_qptr[tid] = q_ptr[q0 + tid];
+    __syncthreads();
+
+    // --- wave 0: one query term per lane -------------------------------------------------
+    int t_reg = -1;                       // term id (hop 1)
+    bool m_ok = false;                    // metadata registers hold a real term (hop 2)
+    double r_idf = 0.0; uint32_t r_a = 0, r_b = 0; int64_t r_tp = 0;
+    auto load_term = [&](int qi) {
+        t_reg = -1;
+        if (tid < 64 && qi < nq) {
+            const int qb = s_qptr[qi], len = s_qptr[qi + 1] - qb;
+            if (len <= kBm25Chunk && tid < len) t_reg = q_terms[qb + tid];  // longer queries: nothing here, dense pass
+        }
+    };
+    auto load_meta = [&]() {
+        m_ok = false;
+        if (tid < 64 && t_reg >= 0 && t_reg < m.vocab) {
+            const uint32_t *to = m.t_tile + (size_t)t_reg * (m.ntiles + 1) + tile;
+            r_idf = m.idf[t_reg];
+            r_a = to[0];
+            r_b = to[1];
+            r_tp = m.t_ptr[t_reg];
+            m_ok = true;
+        }
+    };
+    auto build_table = [&](int buf) {
+        if (tid < 64) {
+            const int n = m_ok ? (int)(r_b - r_a) : 0;
+            const bool valid = m_ok && r_idf != 0.0 && n > 0;
+            const unsigned long long mask = __ballot(valid);
+            const int pos = __popcll(mask & ((1ull << tid) - 1ull));
+            const int nt = __popcll(mask);
+            int incl = valid ? n : 0;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += o;
+            }
+            if (valid) { tb_lo[buf][pos] = r_tp + r_a; tb_idf[buf][pos] = r_idf; tb_off[buf][pos] = incl - n; }
+            if (tid == 63) { tb_off[buf][nt] = incl; tb_cnt[buf] = nt; }
+        }
+    };
+    // --- all threads: up to 1024 postings of the next query held raw in registers ---------
+    int d_raw[kBm25Regs], tj[kBm25Regs];
+    double w_raw[kBm25Regs];
+    auto load_postings = [&](int buf) {
+        const int total = tb_off[buf][tb_cnt[buf]];
+#pragma unroll
+        for (int r = 0; r < kBm25Regs; ++r) {
+            const int e = r * 256 + tid;
+            tj[r] = -1;
+            if (e < total) {
+                int j = 0;
+                while (tb_off[buf][j + 1] <= e) ++j;
+                const int64_t p = tb_lo[buf][j] + (e - tb_off[buf][j]);
+                d_raw[r] = m.p_doc[p];
+                w_raw[r] = m.p_w[p];
+                tj[r] = j;
+            }
+        }
+    };
+    auto add = [&](int di, double x) {
+        sc[di] = sc[di] + x;  // product rounded, then the sum; a document occurs once per term
+        const uint32_t bit = 1u << (di & 31);
+        const uint32_t old = atomicOr(&touched[di >> 5], bit);
+        if (!(old & bit)) {
+            const int slot = atomicAdd(&ncand, 1);
+            if (slot < kBm25Cand) cand[slot] = (uint16_t)di;
+        }
+    };
+
+    // prologue: fill the pipeline
+    load_term(0);
+    load_meta();
+    build_table(0);
+    load_term(1);
+    __syncthreads();
+    load_postings(0);
+    load_meta();
+    load_term(2);
+
+    for (int qi = 0; qi < nq; ++qi) {
+        const int cur = qi & 1;
+        // ---- accumulate query qi ----
+        const int nt = tb_cnt[cur], total = tb_off[cur][nt];
+        if (total > 0) {
+            const int last = (total < 256 * kBm25Regs ? total : 256 * kBm25Regs) - 1;
+            int jmax = 0;
+            while (tb_off[cur][jmax + 1] <= last) ++jmax;
+            for (int j = 0; j <= jmax; ++j) {
+#pragma unroll
+                for (int r = 0; r < kBm25Regs; ++r)
+                    if (tj[r] == j) add(d_raw[r] - base, tb_idf[cur][j] * w_raw[r]);
+                __syncthreads();  // term j complete before term j+1 touches the same documents
+            }
+            for (int r0 = 256 * kBm25Regs; r0 < total; r0 += 256) {  // the rare long tail, unpipelined
+                const int e = r0 + tid;
+                int j = -1, di = 0;
+                double x = 0.0;
+                if (e < total) {
+                    j = 0;
+                    while (tb_off[cur][j + 1] <= e) ++j;
+                    const int64_t p = tb_lo[cur][j] + (e - tb_off[cur][j]);
+                    di = m.p_doc[p] - base;
+                    x = tb_idf[cur][j] * m.p_w[p];
+                }
+                int ja = 0;
+                while (tb_off[cur][ja + 1] <= r0) ++ja;
+                const int lastb = (r0 + 256 < total ? r0 + 256 : total) - 1;
+                int jb = ja;
+                while (tb_off[cur][jb + 1] <= lastb) ++jb;
+                for (int jj = ja; jj <= jb; ++jj) {
+                    if (j == jj) add(di, x);
+                    __syncthreads();
+                }
+            }
+        }
+        // ---- keep the pipeline full: table of qi+1, then its postings, metadata of qi+2, terms of qi+3 ----
+        build_table(cur ^ 1);
+        __syncthreads();
+        load_postings(cur ^ 1);
+        load_meta();
+        load_term(qi + 3);
+        // ---- top-k of query qi among the touched positives ----
+        const int q = q0 + qi;
+        const size_t pb = ((size_t)q * m.ntiles + tile) * k;
+        const int nc = ncand;
+        auto emit = [&](int r, double v, int64_t i) {
+            part_score[pb + r] = v;
+            part_idx[pb + r] = (int32_t)(base + i);
+        };
+        auto pos = [&](int i) { const double v = sc[i]; return v > 0.0 ? v : NEG; };
+        int got;
+        if (nc <= kBm25Cand) {
+            got = block_topk(
+                nc, k, tid, [&](int i) { return pos(cand[i]); }, [&](int i) { return (int64_t)cand[i]; }, emit,
+                [&]() {
+                    if (tid == 0) s_cnt = 0;
+                    block_select(
+                        nc, k < nc ? k : nc, tid, [&](int i) { return pos(cand[i]); },
+                        [&](int i) { return (int64_t)cand[i]; }, [&](int i) { sc[cand[i]] = NEG; },
+                        [&](int r, double v, int64_t i) { emit(r, v, i); s_cnt = r + 1; }, red_s, red_i, red_p);
+                    __syncthreads();
+                    return s_cnt;
+                },
+                L);
+        } else {  // more distinct documents than the list holds: the positives of the whole tile
+            got = block_topk(
+                cnt, k, tid, pos, [&](int i) { return (int64_t)i; }, emit,
+                [&]() {
+                    if (tid == 0) s_cnt = 0;
+                    block_select(
+                        cnt, k < cnt ? k : cnt, tid, pos, [&](int i) { return (int64_t)i; }, [&](int i) { sc[i] = NEG; },
+                        [&](int r, double v, int64_t i) { emit(r, v, i); s_cnt = r + 1; }, red_s, red_i, red_p);
+                    __syncthreads();
+                    return s_cnt;
+                },
+                L);
+        }
+        if (tid == 0) part_cnt[(size_t)q * m.ntiles + tile] = got;
+        // ---- reset only what query qi touched ----
+        __syncthreads();
+        if (nc <= kBm25Cand) {
+            for (int i = tid; i < nc; i += 256) {
+                const int c = cand[i];
+                sc[c] = 0.0;
+                touched[c >> 5] = 0;
+            }
+        } else {
+            for (int i = tid; i < kBm25Tile; i += 256) sc[i] = 0.0;
+            touched[tid] = 0;
+        }
+        if (tid == 0) ncand = 0;
+        __syncthreads();
     }
 }
 
 // grid = b, block = 256: merge the tiles' candidates of one query.
+// mode 0: merge the sparse pass and flag the queries that came up short (need_dense[q] = 1);
+// mode 1: merge the dense pass, for the flagged queries only.
 __global__ __launch_bounds__(256) void bm25_merge_kernel(double *__restrict__ part_score,
                                                          const int32_t *__restrict__ part_idx,
                                                          const int32_t *__restrict__ part_cnt, int ntiles, int k,
-                                                         int64_t doc_offset, int64_t *__restrict__ out_idx,
+                                                         int64_t doc_offset, int64_t n_docs, int mode,
+                                                         int32_t *__restrict__ need_dense,
+                                                         int64_t *__restrict__ out_idx,
                                                          double *__restrict__ out_score,
                                                          int32_t *__restrict__ out_count) {
     __shared__ double red_s[4];
     __shared__ int64_t red_i[4];
     __shared__ int red_p[4];
     __shared__ int s_total;
+    __shared__ TopkLds L;
     const int tid = threadIdx.x, q = blockIdx.x;
+    if (mode == 1 && !need_dense[q]) return;
     double *ps = part_score + (size_t)q * ntiles * k;
     const int32_t *pi = part_idx + (size_t)q * ntiles * k;
     const int32_t *pc = part_cnt + (size_t)q * ntiles;
@@ -176,15 +601,23 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(double *__restrict__ pa
     __syncthreads();
     const int kout = k < s_total ? k : s_total;
     __syncthreads();
-    block_select(
-        ntiles * k, kout, tid, [&](int e) { return ps[e]; }, [&](int e) { return (int64_t)pi[e]; },
-        [&](int e) { ps[e] = NEG; },
-        [&](int r, double s, int64_t i) {
-            out_score[(size_t)q * k + r] = s;
-            out_idx[(size_t)q * k + r] = doc_offset + i;
+    auto emit = [&](int r, double s, int64_t i) {
+        out_score[(size_t)q * k + r] = s;
+        out_idx[(size_t)q * k + r] = doc_offset + i;
+    };
+    block_topk(
+        ntiles * k, k, tid, [&](int e) { return ps[e]; }, [&](int e) { return (int64_t)pi[e]; }, emit,
+        [&]() {
+            block_select(
+                ntiles * k, kout, tid, [&](int e) { return ps[e]; }, [&](int e) { return (int64_t)pi[e]; },
+                [&](int e) { ps[e] = NEG; }, emit, red_s, red_i, red_p);
+            return kout;
         },
-        red_s, red_i, red_p);
-    if (tid == 0) out_count[q] = kout;
+        L);
+    if (tid == 0) {
+        out_count[q] = kout;
+        if (mode == 0) need_dense[q] = (kout < k && (int64_t)kout < n_docs) ? 1 : 0;
+    }
 }
 
 }  // namespace mir
@@ -408,29 +841,43 @@ int32_t mir_bm25_idf(const mir_bm25 *h, double *out_idf_host) {
 }
 
 // Shared implementation: queries already on the device (q_terms[nt], q_ptr[b+1]).
+// part = [part_score f64 | part_idx i32 | part_cnt i32 | need_dense i32]
 static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_ptr, int b, int k, double *d_scores,
                         int64_t *d_out_idx, double *d_out_score, int32_t *d_out_count, void *part, hipStream_t s) {
     const int T = h->ntiles;
-    double *part_score = nullptr;
-    int32_t *part_idx = nullptr, *part_cnt = nullptr;
-    if (k > 0) {
-        char *p = static_cast<char *>(part);
-        part_score = reinterpret_cast<double *>(p);
-        part_idx = reinterpret_cast<int32_t *>(p + (size_t)b * T * k * 8);
-        part_cnt = reinterpret_cast<int32_t *>(p + (size_t)b * T * k * 12);
-    }
-    bm25_tile_kernel<<<dim3(T, b), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, k, d_scores, part_score, part_idx,
-                                                      part_cnt);
-    MIR_HIP(hipGetLastError());
-    if (k > 0) {
-        bm25_merge_kernel<<<dim3(b), dim3(256), 0, s>>>(part_score, part_idx, part_cnt, T, k, h->doc_offset,
-                                                        d_out_idx, d_out_score, d_out_count);
+    if (k <= 0) {  // get_scores: dense score vector only
+        bm25_tile_kernel<<<dim3(T, b), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, 0, nullptr, d_scores, nullptr,
+                                                                 nullptr, nullptr);
         MIR_HIP(hipGetLastError());
+        return MIR_OK;
     }
+    char *p = static_cast<char *>(part);
+    double *part_score = reinterpret_cast<double *>(p);
+    int32_t *part_idx = reinterpret_cast<int32_t *>(p + (size_t)b * T * k * 8);
+    int32_t *part_cnt = reinterpret_cast<int32_t *>(p + (size_t)b * T * k * 12);
+    int32_t *need = part_cnt + (size_t)b * T;
+    // 1. fast pass: positives among touched documents
+    //    queries per workgroup: as many as still leave ~8 workgroups per CU of parallelism
+    int qc = (int)((int64_t)b * T / 2048);
+    qc = qc < 1 ? 1 : (qc > kBm25QcMax ? kBm25QcMax : qc);
+    bm25_sparse_kernel<<<dim3(T, (b + qc - 1) / qc), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, b, qc, k, part_score,
+                                                                        part_idx, part_cnt);
+    MIR_HIP(hipGetLastError());
+    bm25_merge_kernel<<<dim3(b), dim3(256), 0, s>>>(part_score, part_idx, part_cnt, T, k, h->doc_offset, h->n_docs, 0, need,
+                                                    d_out_idx, d_out_score, d_out_count);
+    MIR_HIP(hipGetLastError());
+    // 2. exact dense pass for the queries with fewer than k positive documents (workgroups of
+    //    the other queries exit at once; usually that is all of them)
+    bm25_tile_kernel<<<dim3(T, b), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, k, need, nullptr, part_score,
+                                                             part_idx, part_cnt);
+    MIR_HIP(hipGetLastError());
+    bm25_merge_kernel<<<dim3(b), dim3(256), 0, s>>>(part_score, part_idx, part_cnt, T, k, h->doc_offset, h->n_docs, 1, need,
+                                                    d_out_idx, d_out_score, d_out_count);
+    MIR_HIP(hipGetLastError());
     return MIR_OK;
 }
 
-static size_t part_bytes(int b, int T, int k) { return (size_t)b * T * k * 12 + (size_t)b * T * 4 + 64; }
+static size_t part_bytes(int b, int T, int k) { return (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 4 + 64; }
 
 // BM25Okapi.get_scores(query) -> float64[n_docs] (bm25_retriever.py:83)
 int32_t mir_bm25_scores(mir_bm25 *h, const int32_t *q_terms_host, int32_t nq, double *out_scores_host) {

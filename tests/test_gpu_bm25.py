@@ -101,12 +101,75 @@ def test_synthetic_vs_oracle_bit_exact(br, n, vocab):
         assert cnt[i] == 10
         np.testing.assert_array_equal(idx[i], top, err_msg=f"query {i} {q}")
         np.testing.assert_array_equal(sc[i], want[top])
+    # a query longer than the fast path's term table goes through the dense pass, batched with short ones
+    long_q = [int(t) for t in np.random.default_rng(5).integers(0, vocab, 45)]
+    i3, s3, c3 = dev.search([qs[1], long_q, qs[2]], 10)
+    want = o.get_scores(long_q)
+    np.testing.assert_array_equal(i3[1], ob.top_n_indexes(want, 10))
+    np.testing.assert_array_equal(s3[1], want[i3[1]])
+    np.testing.assert_array_equal(i3[0], idx[1])
+    np.testing.assert_array_equal(i3[2], idx[2])
     # k larger than a tile's population and than the corpus
     small = br.DeviceBM25.from_token_ids(indptr[:8], toks[: indptr[7]], vocab)
     i2, s2, c2 = small.search([qs[0]], 64)
     assert c2[0] == 7
     with pytest.raises(NotImplementedError):
         dev.search(qs[:1], 65)
+
+
+def _check_batch(dev, o, qs, k=10):
+    idx, sc, cnt = dev.search(qs, k)
+    for i, q in enumerate(qs):
+        want = o.get_scores(q)
+        top = ob.top_n_indexes(want, k)
+        assert cnt[i] == k
+        np.testing.assert_array_equal(idx[i], top, err_msg=f"query {i} {q}")
+        np.testing.assert_array_equal(sc[i], want[top])
+
+
+def test_topk_overflow_paths(br):
+    """Orders that defeat the sampled bound of the block top-k: scores ascending with the document
+    index (the 256-document sample is the worst of the tile, so nearly everything passes the bound),
+    and a mass of exactly equal scores (every document is a finalist; ties go to the highest index).
+    Both must fall back to the round-based selection and stay exact, also deep inside a batch."""
+    n, vocab = 20000, 64
+    docs = []
+    for i in range(n):
+        tf = 1 + (i % 8192) // 64
+        docs.append([0] * tf + [1 + i % 40] * (1 + i % 3))
+    lens = np.array([len(d) for d in docs], np.int64)
+    indptr = np.concatenate(([0], np.cumsum(lens)))
+    toks = np.concatenate([np.asarray(d, np.int32) for d in docs])
+    dev = br.DeviceBM25.from_token_ids(indptr, toks, vocab)
+    o = ob.BM25OkapiCSR(indptr, toks, vocab)
+    qs = [[0], [0, 5], [0, 0], [7, 0, 9]] * 24
+    _check_batch(dev, o, qs)
+    _check_batch(dev, o, qs[:3], k=64)
+    # identical documents: all scores equal
+    same = [[1, 2, 2]] * 9000 + [[3], [4, 4]] * 50
+    lens = np.array([len(d) for d in same], np.int64)
+    indptr = np.concatenate(([0], np.cumsum(lens)))
+    toks = np.concatenate([np.asarray(d, np.int32) for d in same])
+    dev = br.DeviceBM25.from_token_ids(indptr, toks, 8)
+    o = ob.BM25OkapiCSR(indptr, toks, 8)
+    _check_batch(dev, o, [[1], [2, 1], [3, 1], [4]] * 10)
+
+
+@pytest.mark.parametrize("batch", [1024])
+def test_frequent_terms_large_batch(br, batch):
+    """Very frequent terms (every tile lists more distinct documents than the candidate list holds)
+    across a batch large enough that each workgroup walks many queries."""
+    indptr, toks = synth(60000, 3000, 21)
+    dev = br.DeviceBM25.from_token_ids(indptr, toks, 3000)
+    o = ob.BM25OkapiCSR(indptr, toks, 3000)
+    rng = np.random.default_rng(22)
+    qs = [[int(t) for t in rng.integers(0, 40, rng.integers(1, 7))] for _ in range(batch)]
+    idx, sc, cnt = dev.search(qs, 10)
+    for i in range(0, batch, 37):
+        want = o.get_scores(qs[i])
+        top = ob.top_n_indexes(want, 10)
+        np.testing.assert_array_equal(idx[i], top, err_msg=f"query {i} {qs[i]}")
+        np.testing.assert_array_equal(sc[i], want[top])
 
 
 def test_dict_loop_oracle_agrees_on_token_ids(br):

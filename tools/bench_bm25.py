@@ -39,6 +39,20 @@ for B in (1, 64, 512, 4096):
     touched = float(np.mean([sum(int(df[t]) for t in q if 0 <= t < vocab) for q in qs]))
     res["runs"].append({"batch": B, "qps": round(B / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "postings_touched_per_query": touched,
                         "algorithmic_bytes_per_query": 12 * touched, "achieved_GBps": round(12 * touched * B / dt / 1e9, 1)})
+# query classes at B=4096: rare terms (rank >= 5000), mid band (50..5000), very frequent (rank < 50)
+def make_class(kind, nq):
+    lo, hi = {"rare": (5000, vocab), "mid": (50, 5000), "frequent": (0, 50)}[kind]
+    return [[int(t) for t in qr.integers(lo, hi, int(qr.integers(2, 9)))] for _ in range(nq)]
+res["classes"] = []
+for kind in ("rare", "mid", "frequent"):
+    qs = make_class(kind, 4096)
+    dev.search(qs, 10)
+    t0 = time.perf_counter()
+    for _ in range(3): dev.search(qs, 10)
+    dt = (time.perf_counter() - t0) / 3
+    touched = float(np.mean([sum(int(df[t]) for t in q) for q in qs]))
+    res["classes"].append({"class": kind, "batch": 4096, "qps": round(4096 / dt, 1), "postings_touched_per_query": touched,
+                           "achieved_GBps": round(12 * touched * 4096 / dt / 1e9, 1)})
 # parity + CPU baseline on the same corpus (vectorised restatement; the reference's dict loop is ~1000x slower)
 qs = make_queries(32)
 t0 = time.perf_counter(); want = [o.get_scores(q) for q in qs]; dt = time.perf_counter() - t0
