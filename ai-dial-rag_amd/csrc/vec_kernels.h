@@ -431,7 +431,7 @@ constexpr int kB128Pending = 4;  // per-lane buffer of appended, not yet merged 
 __device__ __forceinline__ void glds16_b128(const void *gsrc, uint32_t lds_byte_addr) {
     uint32_t keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_byte_addr)
         : "memory");
@@ -592,7 +592,20 @@ __global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__r
 
     // filter + append for the previous tile.  `comb` holds ranking values already (inner product:
     // the dot; sqeuclid: 2*dot - |d|^2, the hi wave folded the norm in); cosine still scales by pax.
-    auto lo_epilogue = [&](const f32x16 &comb) {
+    auto lo_epilogue = [&](const float4 (&w4)[4]) {
+        // complete scores of the previous tile: own partial + the partner's (which, for sqeuclid,
+        // arrives as 2*dot_hi - |d|^2)
+        f32x16 comb;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (KIND == SCAN_L2) {
+                comb[4 * c + 0] = fmaf(2.0f, pacc[4 * c + 0], w4[c].x); comb[4 * c + 1] = fmaf(2.0f, pacc[4 * c + 1], w4[c].y);
+                comb[4 * c + 2] = fmaf(2.0f, pacc[4 * c + 2], w4[c].z); comb[4 * c + 3] = fmaf(2.0f, pacc[4 * c + 3], w4[c].w);
+            } else {
+                comb[4 * c + 0] = pacc[4 * c + 0] + w4[c].x; comb[4 * c + 1] = pacc[4 * c + 1] + w4[c].y;
+                comb[4 * c + 2] = pacc[4 * c + 2] + w4[c].z; comb[4 * c + 3] = pacc[4 * c + 3] + w4[c].w;
+            }
+        }
         float pv[16];
         uint32_t pmask = 0;
         // the two half-lanes of a query share the tighter threshold: a row below EITHER list's
@@ -615,8 +628,18 @@ __global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__r
                 x *= (i == 0) ? pax[gq].x : (i == 1) ? pax[gq].y : (i == 2) ? pax[gq].z : pax[gq].w;
             }
             pv[r] = x;
-            pmask |= (uint32_t)(!(x < vmin)) << r;
         }
+        // Most tiles hold nothing for any lane once the thresholds are seeded: one maximum per lane
+        // (v_max3 tree) and one wave vote instead of 16 compare-and-set-bit.  max ignores a NaN next
+        // to a number - such a row could only matter while the list is open, and then vmin = -inf
+        // and `!(m < vmin)` holds for any m, NaN included.
+        const float m01 = fmaxf(fmaxf(pv[0], pv[1]), pv[2]), m02 = fmaxf(fmaxf(pv[3], pv[4]), pv[5]);
+        const float m03 = fmaxf(fmaxf(pv[6], pv[7]), pv[8]), m04 = fmaxf(fmaxf(pv[9], pv[10]), pv[11]);
+        const float m05 = fmaxf(fmaxf(pv[12], pv[13]), pv[14]);
+        const float mx = fmaxf(fmaxf(fmaxf(m01, m02), fmaxf(m03, m04)), fmaxf(m05, pv[15]));
+        if (!__any(!(mx < vmin) && prow0 != n_rows)) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pmask |= (uint32_t)(!(pv[r] < vmin)) << r;
         if (!full_tile) {  // wave-uniform; only the index's last, partial tile
             uint32_t ok = 0;
 #pragma unroll
@@ -627,30 +650,54 @@ __global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__r
         drain_candidates(pmask, pv, prow0, list, klist, ltid, minkey, minpos, pending);
     };
 
+    // The tile's 32 norm values are wave-uniform: one scalar fetch (lgkmcnt); a vector load would
+    // queue behind the DMA ring and hipcc's wait for it would drain the ring.  Load and wait in ONE
+    // statement (SGPRs left "in flight" across other code get copied / spilled before the data
+    // lands).
+    auto load_aux = [&](uint32_t t, float4 (&ax)[4]) {
+        u32x16 sa, sb;
+        const float *ap = aux + (size_t)__builtin_amdgcn_readfirstlane(t) * kTileRows;
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(sa), "=&s"(sb)
+                     : "s"(ap)
+                     : "memory");
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            // rows 8*gq + 4*h + i  ->  dwords 8*gq + {0..3} (h = 0) or 8*gq + {4..7} (h = 1)
+            float lo[4], hi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = 8 * gq + i;
+                lo[i] = __uint_as_float(idx < 16 ? sa[idx] : sb[idx - 16]);
+                hi[i] = __uint_as_float(idx + 4 < 16 ? sa[idx + 4] : sb[idx + 4 - 16]);
+            }
+            ax[gq] = h ? make_float4(hi[0], hi[1], hi[2], hi[3]) : make_float4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    };
+    // sqeuclid: the hi wave folds the norms into its partial.  With two stages per tile it has no
+    // k-steps in the first one, so it fetches them there, off its critical path (MFMAs -> partial ->
+    // barrier); cosine: the lo wave needs them as a factor, after its epilogue.
+    constexpr bool kAuxEarly = KIND == SCAN_L2 && SPT == 2;
+
     uint32_t g = 0;
     for (uint32_t ts = 0; ts < my_tiles; ++ts) {
         const uint32_t t = blockIdx.x + ts * G;
         f32x16 acc = {0};
-        f32x16 comb = {0};  // lo: complete scores of tile t-1 (own partial + partner's)
+        float4 ax[4] = {};
+        float4 w4[4] = {};  // lo: the partner's partial of tile t-1 (combined with pacc in the epilogue)
 #pragma unroll
         for (int part_i = 0; part_i < SPT; ++part_i, ++g) {
             const uint32_t younger = (NG - 1 - g) < (uint32_t)(NS - 2) ? (NG - 1 - g) : (uint32_t)(NS - 2);
             if (younger == NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * PPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only in the last NS-2 stages of the launch
             __builtin_amdgcn_s_barrier();    // stage g is in LDS; stage g-1 is consumed; partials of tile t-1 are written
+            // Refill the ring FIRST: the loop runs at the DMA pipe's cadence (about 12 B/clk per CU),
+            // and issuing after the first fragment reads instead measured 3 % slower.
             if (g + NS - 1 < NG) issue(g + NS - 1);
+            if (kAuxEarly && part_i == 0 && is_hi && active) load_aux(t, ax);
             if (part_i == 0 && !is_hi && active) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float4 w = pb[c * 64];
-                    if (KIND == SCAN_L2) {  // partner sent 2*dot_hi - |d|^2
-                        comb[4 * c + 0] = fmaf(2.0f, pacc[4 * c + 0], w.x); comb[4 * c + 1] = fmaf(2.0f, pacc[4 * c + 1], w.y);
-                        comb[4 * c + 2] = fmaf(2.0f, pacc[4 * c + 2], w.z); comb[4 * c + 3] = fmaf(2.0f, pacc[4 * c + 3], w.w);
-                    } else {
-                        comb[4 * c + 0] = pacc[4 * c + 0] + w.x; comb[4 * c + 1] = pacc[4 * c + 1] + w.y;
-                        comb[4 * c + 2] = pacc[4 * c + 2] + w.z; comb[4 * c + 3] = pacc[4 * c + 3] + w.w;
-                    }
-                }
+                for (int c = 0; c < 4; ++c) w4[c] = pb[c * 64];
             }
             // this wave's k-steps inside the stage, with a distance-2 LDS prefetch (three fragment
             // pairs in registers): in stages where only one wave of the SIMD has MFMAs, a
@@ -697,7 +744,7 @@ __global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__r
                     }
                 }
                 // lo waves are free in the last stage (or right after their k-steps): previous tile's candidates
-                if (part_i == SPT - 1 && !is_hi) lo_epilogue(comb);
+                if (part_i == SPT - 1 && !is_hi) lo_epilogue(w4);
             }
         }
         // The tile's 32 norm values are wave-uniform: one scalar fetch (lgkmcnt); a vector load would
@@ -705,27 +752,7 @@ __global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__r
         // statement (SGPRs left "in flight" across other code get copied / spilled before the data
         // lands).  sqeuclid: the hi wave, which has slack, fetches and folds them into its partial;
         // cosine: the lo wave needs them as a factor.
-        float4 ax[4] = {};
-        if (KIND != SCAN_IP && active && (KIND == SCAN_L2 ? is_hi : !is_hi)) {
-            u32x16 sa, sb;
-            const float *ap = aux + (size_t)__builtin_amdgcn_readfirstlane(t) * kTileRows;
-            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(sa), "=&s"(sb)
-                         : "s"(ap)
-                         : "memory");
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                // rows 8*gq + 4*h + i  ->  dwords 8*gq + {0..3} (h = 0) or 8*gq + {4..7} (h = 1)
-                float lo[4], hi[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = 8 * gq + i;
-                    lo[i] = __uint_as_float(idx < 16 ? sa[idx] : sb[idx - 16]);
-                    hi[i] = __uint_as_float(idx + 4 < 16 ? sa[idx + 4] : sb[idx + 4 - 16]);
-                }
-                ax[gq] = h ? make_float4(hi[0], hi[1], hi[2], hi[3]) : make_float4(lo[0], lo[1], lo[2], lo[3]);
-            }
-        }
+        if (KIND != SCAN_IP && active && !kAuxEarly && (KIND == SCAN_L2 ? is_hi : !is_hi)) load_aux(t, ax);
         if (is_hi) {
             if (active) {   // read by the partner after the next barrier
 #pragma unroll
@@ -750,19 +777,10 @@ __global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__r
     // the last tile: its partials are complete after one more barrier
     __syncthreads();
     if (!is_hi && active) {
-        f32x16 comb;
+        float4 w4[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 w = pb[c * 64];
-            if (KIND == SCAN_L2) {
-                comb[4 * c + 0] = fmaf(2.0f, pacc[4 * c + 0], w.x); comb[4 * c + 1] = fmaf(2.0f, pacc[4 * c + 1], w.y);
-                comb[4 * c + 2] = fmaf(2.0f, pacc[4 * c + 2], w.z); comb[4 * c + 3] = fmaf(2.0f, pacc[4 * c + 3], w.w);
-            } else {
-                comb[4 * c + 0] = pacc[4 * c + 0] + w.x; comb[4 * c + 1] = pacc[4 * c + 1] + w.y;
-                comb[4 * c + 2] = pacc[4 * c + 2] + w.z; comb[4 * c + 3] = pacc[4 * c + 3] + w.w;
-            }
-        }
-        lo_epilogue(comb);
+        for (int c = 0; c < 4; ++c) w4[c] = pb[c * 64];
+        lo_epilogue(w4);
         for (int i = 0; i < pending; ++i) {
             const uint64_t key = list[(klist + i) * 256 + ltid];
             if (key > minkey) list_insert(list, klist, ltid, key, minkey, minpos);
