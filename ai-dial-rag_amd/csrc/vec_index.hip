@@ -329,13 +329,14 @@ static int32_t launch_scan(const mir_index *ix, const uint4 *qsplit_g, int nq, i
 
 template <int KIND>
 static int32_t launch_scan_b128(const mir_index *ix, const uint4 *qsplit_g, int nq, int klist, int nwg,
-                                uint32_t n_tiles, uint64_t *part_g, uint64_t *gthr_g, hipStream_t stream) {
+                                uint32_t n_tiles, uint64_t *part_g, uint64_t *gthr_g, bool sample,
+                                hipStream_t stream) {
     const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
     const size_t lds = b128_lds_bytes(klist);
     const uint32_t n_rows = (uint32_t)ix->n;
 #define MIR_SCAN_CASE(KS)                                                                                    \
     case KS: {                                                                                               \
-        auto kern = scan_topk_b128_kernel<KS, KIND>;                                                         \
+        auto kern = sample ? scan_topk_b128_kernel<KS, KIND, true> : scan_topk_b128_kernel<KS, KIND, false>; \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
         kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, n_rows, n_tiles, nq,         \
@@ -400,10 +401,10 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         int32_t rc;
         if (qpw == 128) {
             uint64_t *gt = sb.gthr + (size_t)g * 128;
-            auto run = [&](int wgs, uint32_t tiles, uint64_t *out) {
-                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_b128<SCAN_IP>(ix, qs, nq, klist, wgs, tiles, out, gt, stream);
-                if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_b128<SCAN_COS>(ix, qs, nq, klist, wgs, tiles, out, gt, stream);
-                return launch_scan_b128<SCAN_L2>(ix, qs, nq, klist, wgs, tiles, out, gt, stream);
+            auto run = [&](int wgs, uint32_t tiles, uint64_t *out, bool sample) {
+                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_b128<SCAN_IP>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
+                if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_b128<SCAN_COS>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
+                return launch_scan_b128<SCAN_L2>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
             };
             // Large shard: scan a 64K-row sample first and seed every query's shared threshold with the
             // sample's klist-th best key, so the full pass starts with tight thresholds instead of
@@ -411,15 +412,16 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             const uint32_t sample_tiles = (uint32_t)kSampleWgs * kSampleTilesPerWg;
             rc = MIR_OK;
             if (ix->n_tiles >= 16 * sample_tiles) {
-                rc = run(kSampleWgs, sample_tiles, sb.part_sample);
+                rc = run(kSampleWgs, sample_tiles, sb.part_sample, true);
                 if (rc == MIR_OK) {
-                    sample_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(sb.part_sample, kSampleWgs, 128, klist, nq,
+                    sample_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(reinterpret_cast<const float *>(sb.part_sample),
+                                                                                kSampleWgs, klist, nq,
                                                                                 reinterpret_cast<unsigned long long *>(gt));
                     MIR_HIP(hipGetLastError());
                 }
             }
             if (rc == MIR_OK) rc = begin_profile();
-            if (rc == MIR_OK) rc = run(nwg, ix->n_tiles, pg);
+            if (rc == MIR_OK) rc = run(nwg, ix->n_tiles, pg, false);
         } else {
             rc = begin_profile();
             if (rc != MIR_OK) return rc;

@@ -514,7 +514,13 @@ __device__ __forceinline__ void filter_score(int r, const f32x16 &am, const f32x
 //     stage 2: lo: filter + append of tile t-1   | hi MFMA
 // The hi wave hands its partial 32x32 accumulator to its lo partner through LDS once per
 // tile (16 floats per lane); the lo wave owns the candidate lists.
-template <int KSTEPS, int KIND>
+//
+// SAMPLE = true is the threshold pre-pass over the first tiles of a large shard: no candidate
+// lists at all - every lane (half a query's rows of this workgroup) keeps the MAXIMUM ranking
+// value it saw and writes it to part as float [wg][128][2].  The klist-th largest of a query's
+// 2*nwg maxima belongs to klist distinct rows, so it bounds the index's klist-th best from below
+// (sample_threshold_kernel); with lists, the pass spent ~100 us inserting into empty lists.
+template <int KSTEPS, int KIND, bool SAMPLE>
 __global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__restrict__ docs,
                                                                 const float *__restrict__ aux,
                                                                 const uint4 *__restrict__ qsplit, uint32_t n_rows,
@@ -545,15 +551,16 @@ __global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__r
     const bool lane_live = qj + 32 * qt < nq;
     const uint32_t G = gridDim.x;
 
-    if (!is_hi) {
+    if (!is_hi && !SAMPLE) {
         for (int p = 0; p < klist + kB128Pending; ++p) list[p * 256 + ltid] = 0;
     }
+    float best = -__builtin_inff();  // SAMPLE: this lane's maximum
     uint64_t minkey = 0;
     int minpos = 0, pending = 0;
     // Lower bound on this query's klist-th best key, from the sample pre-pass (0 = none).  Read-only
     // here on purpose: refreshing it in-kernel needs atomics, and no-return atomics complete out of
     // order with loads in the vmcnt queue, which breaks the counted waits on the DMA ring.
-    const uint64_t seed_thr = is_hi ? 0 : gthr[qt * 32 + qj];
+    const uint64_t seed_thr = (is_hi || SAMPLE) ? 0 : gthr[qt * 32 + qj];
 
     // this wave's half of its 32 queries' B fragments
     bf16x8 qh[KH], ql[KH];
@@ -605,6 +612,23 @@ __global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__r
                 comb[4 * c + 0] = pacc[4 * c + 0] + w4[c].x; comb[4 * c + 1] = pacc[4 * c + 1] + w4[c].y;
                 comb[4 * c + 2] = pacc[4 * c + 2] + w4[c].z; comb[4 * c + 3] = pacc[4 * c + 3] + w4[c].w;
             }
+        }
+        if (SAMPLE) {
+            float x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x[r] = comb[r];
+                if (KIND == SCAN_COS) {
+                    const int gq = r >> 2, i = r & 3;
+                    x[r] *= (i == 0) ? pax[gq].x : (i == 1) ? pax[gq].y : (i == 2) ? pax[gq].z : pax[gq].w;
+                }
+            }
+            const float a0 = fmaxf(fmaxf(x[0], x[1]), x[2]), a1 = fmaxf(fmaxf(x[3], x[4]), x[5]);
+            const float a2 = fmaxf(fmaxf(x[6], x[7]), x[8]), a3 = fmaxf(fmaxf(x[9], x[10]), x[11]);
+            const float a4 = fmaxf(fmaxf(x[12], x[13]), x[14]);
+            const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(a4, x[15]));
+            if (prow0 != n_rows) best = fmaxf(best, mx);  // sample tiles are whole tiles
+            return;
         }
         float pv[16];
         uint32_t pmask = 0;
@@ -785,6 +809,10 @@ __global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__r
             const uint64_t key = list[(klist + i) * 256 + ltid];
             if (key > minkey) list_insert(list, klist, ltid, key, minkey, minpos);
         }
+    }
+    if (SAMPLE) {
+        if (!is_hi) reinterpret_cast<float *>(part)[((size_t)blockIdx.x * 128 + 32 * qt + qj) * 2 + h] = best;
+        return;
     }
 
     // ---- merge the two half-lists of each query, write [128][klist] per workgroup ----
@@ -1114,16 +1142,35 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
 // After a scan of a SAMPLE of the rows: the klist-th best key of the sample is a lower bound on
 // the klist-th best key of the whole index (the sample is a subset), so it is a valid starting
 // threshold for every list of the full scan.  One block per query.
-__global__ __launch_bounds__(256) void sample_threshold_kernel(const uint64_t *__restrict__ part, int nwg, int qpw,
-                                                               int klist, int b_in_launch,
+__global__ __launch_bounds__(256) void sample_threshold_kernel(const float *__restrict__ part, int nwg, int klist,
+                                                               int b_in_launch,
                                                                unsigned long long *__restrict__ gthr) {
-    __shared__ uint64_t keys[kMaxList];
-    __shared__ uint64_t red[4];
+    constexpr int kMaxVals = 2 * 256;  // two half-lanes per workgroup, kSampleWgs <= 256
+    __shared__ __attribute__((aligned(16))) float vals[kMaxVals];
+    __shared__ float thr;
     const int tid = threadIdx.x, q = blockIdx.x;
     if (q >= b_in_launch) return;
-    merge_sorted_lists(part + (size_t)q * klist, (size_t)qpw * klist, nwg, klist, keys, red, tid);
-    if (tid == 0 && keys[klist - 1] != 0)
-        __hip_atomic_fetch_max(gthr + q, (unsigned long long)keys[klist - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n = 2 * nwg;
+    for (int e = tid; e < kMaxVals; e += 256) {
+        float v = -__builtin_inff();
+        if (e < n) v = part[((size_t)(e >> 1) * 128 + q) * 2 + (e & 1)];
+        vals[e] = (v == v) ? v : -__builtin_inff();
+    }
+    if (tid == 0) thr = -__builtin_inff();
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {
+        const float v = vals[e];
+        int gt = 0, ge = 0;
+        for (int u = 0; u < kMaxVals; u += 4) {
+            const float4 w = *reinterpret_cast<const float4 *>(vals + u);
+            gt += (w.x > v) + (w.y > v) + (w.z > v) + (w.w > v);
+            ge += (w.x >= v) + (w.y >= v) + (w.z >= v) + (w.w >= v);
+        }
+        if (gt < klist && klist <= ge) thr = v;  // the tie group holding rank klist (one value)
+    }
+    __syncthreads();
+    // lowest key of that value: still a lower bound whatever the row
+    if (tid == 0 && thr > -__builtin_inff()) gthr[q] = (unsigned long long)orderable(thr) << 32;
 }
 
 // ---------------------------------------------------------------- shard merge
