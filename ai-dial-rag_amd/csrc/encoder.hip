@@ -204,7 +204,7 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
     {
         auto kern = ffn_ln_kernel;
         MIR_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * FFN_STAGE_BYTES + FFN_PARAM_FLOATS * 4));
+                                    FFN_LDS_BYTES));
     }
 #undef MIR_TRY
     *out = e;
@@ -317,7 +317,7 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
             attention_kernel<<<dim3((nt * NH + 3) / 4), blk, 0, s>>>(qf, kf, vf, d_ti, nt, a1);  // a1 = context
             oproj_ln_kernel<<<g4, blk, 0, s>>>(a1, nt, l.wo, l.attn_params, l.attn_params + H, l.attn_params + 2 * H,
                                                a0, a1);  // in place: each wave reads its tile's context before writing it
-            ffn_ln_kernel<<<g4, blk, 2 * FFN_STAGE_BYTES + FFN_PARAM_FLOATS * 4, s>>>(a1, nt, l.wffn, l.ffn_params, a0);
+            ffn_ln_kernel<<<g4, blk, FFN_LDS_BYTES, s>>>(a1, nt, l.wffn, l.ffn_params, a0);
         }
         MIR_HIP(hipGetLastError());
         float *d_out = out_on_device ? out + (size_t)s0 * H : reinterpret_cast<float *>(w + o_out);
