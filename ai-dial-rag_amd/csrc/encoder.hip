@@ -14,7 +14,8 @@ using namespace mir::enc;
 
 namespace {
 
-constexpr int kMaxTilesPerPass = 4096;  // 131 072 tokens per pass: ~0.5 GB of activations
+constexpr int kMaxTilesPerPass = 3072;  // 98 304 tokens per pass (~0.4 GB of activations): 1024 waves x 3 tiles in qkv_kernel
+                                        // = one round of the chip, 768 four-tile blocks = three rounds elsewhere
 
 // Pack a Hugging Face Linear weight W[out][in] (y = x W^T + b) into MFMA A-fragment
 // order for out^T = W x^T: block (nt, ks) = 64 lanes x 8 halfs, lane (row = l&31,
@@ -313,7 +314,7 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         embed_ln_kernel<<<g4, blk, 0, s>>>(d_ids, d_ti, nt, e->word, e->pos, e->type0, e->emb_g, e->emb_b, a0);
         for (int li = 0; li < nl; ++li) {
             const Layer &l = e->L[li];
-            qkv_kernel<<<g4, blk, 0, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
+            qkv_kernel<<<dim3((nt + 4 * QKV_G - 1) / (4 * QKV_G)), blk, 0, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
             attention_kernel<<<dim3((nt * NH + 3) / 4), blk, 0, s>>>(qf, kf, vf, d_ti, nt, a1);  // a1 = context
             oproj_ln_kernel<<<g4, blk, 0, s>>>(a1, nt, l.wo, l.attn_params, l.attn_params + H, l.attn_params + 2 * H,
                                                a0, a1);  // in place: each wave reads its tile's context before writing it

@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mir {
 namespace enc {
@@ -216,54 +217,87 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 }
 
 // ---------------------------------------------------------------- E2: QKV projection
-// One wave per token tile (4 per block, no barriers).  wqkv: 36 tiles x 24 k-steps
-// of 1-KiB fragments: tiles 0-11 = Q heads, 12-23 = K heads, 24-35 = V heads.
+// One wave per QKV_G = 3 token tiles (96 tokens; 4 waves per block, no barriers).  wqkv: 36 tiles
+// x 24 k-steps of 1-KiB fragments: tiles 0-11 = Q heads, 12-23 = K heads, 24-35 = V heads.
+// Every wave streams ALL 864 KiB of weights through a 24-deep register ring (L2 hits); with one
+// token tile per wave that stream, not the matrix pipe, set the pace (measured 36 B/clk per CU
+// against the 128 B/clk four waves at full MFMA rate would need: 28 % of MFMA peak).  A fragment
+// now feeds three MFMAs (three token tiles' activations stay in registers: 288 VGPRs), which puts
+// the demand at 43 B/clk per CU.
 // Q, K come out as W^T x^T (rows = head features, lanes = tokens); V as x W
 // (rows = tokens, lanes = head features) so that each is directly the operand
 // the attention kernel needs.  Output fragment buffers: [tile][head][s2][64].
+constexpr int QKV_G = 3;
+
 __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ act, int n_tiles,
                                                      const uint4 *__restrict__ wqkv, const float *__restrict__ bqkv,
                                                      uint4 *__restrict__ qf, uint4 *__restrict__ kf,
                                                      uint4 *__restrict__ vf) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tt >= n_tiles) return;
-    const uint4 *xin = act + (size_t)tt * (NFB * 2 * 64) + lane;
-    uint4 x[KS_H];
+    const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * QKV_G;
+    if (t0 >= n_tiles) return;
+    int tt[QKV_G];
+    bool live[QKV_G];
 #pragma unroll
-    for (int ks = 0; ks < KS_H; ++ks) x[ks] = xin[ks * 64];
+    for (int g = 0; g < QKV_G; ++g) {
+        live[g] = t0 + g < n_tiles;
+        tt[g] = live[g] ? t0 + g : n_tiles - 1;  // a missing tile shadows a real one; nothing is stored for it
+    }
+    uint4 x[QKV_G][KS_H];
+#pragma unroll
+    for (int g = 0; g < QKV_G; ++g) {
+        const uint4 *xin = act + (size_t)tt[g] * (NFB * 2 * 64) + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) x[g][ks] = xin[ks * 64];
+    }
 
-    constexpr int R = 8;
+    constexpr int R = 24;  // a whole tile of k-steps (2.3K cycles of MFMAs) ahead: an L2 hit under load takes ~1K; must divide KS_H
     const uint4 *wp = wqkv + lane;
     uint4 ring[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) ring[i] = wp[i * 64];
-    for (int tile = 0; tile < 36; ++tile) {
-        const bool is_v = tile >= 24;
-        const uint4 *np = wqkv + (size_t)(tile + 1 < 36 ? tile + 1 : tile) * (KS_H * 64) + lane;
-        f32x16 acc = {0};
+    // Two loops with a compile-time operand order: with `is_v ? mfma(x, w) : mfma(w, x)` inside one
+    // loop hipcc emitted a branch per MFMA.
+    auto run_tiles = [&](int tile_lo, int tile_hi, auto IS_V_) {
+        constexpr bool is_v = decltype(IS_V_)::value;
+        for (int tile = tile_lo; tile < tile_hi; ++tile) {
+            const uint4 *np = wqkv + (size_t)(tile + 1 < 36 ? tile + 1 : tile) * (KS_H * 64) + lane;
+            f32x16 acc[QKV_G];
 #pragma unroll
-        for (int ks = 0; ks < KS_H; ++ks) {
-            const int slot = ks % R;
-            acc = is_v ? mfma(x[ks], ring[slot], acc) : mfma(ring[slot], x[ks], acc);
-            ring[slot] = (ks + R < KS_H) ? wp[(ks + R) * 64] : np[(ks + R - KS_H) * 64];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < QKV_G; ++g) acc[g] = f32x16{0};
+#pragma unroll
+            for (int ks = 0; ks < KS_H; ++ks) {
+                const int slot = ks % R;
+#pragma unroll
+                for (int g = 0; g < QKV_G; ++g)
+                    acc[g] = is_v ? mfma(x[g][ks], ring[slot], acc[g]) : mfma(ring[slot], x[g][ks], acc[g]);
+                ring[slot] = (ks + R < KS_H) ? wp[(ks + R) * 64] : np[(ks + R - KS_H) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wp = np;
+            const int head = tile % 12;
+            const float *b = bqkv + tile * 32;
+            uint4 *dbase = (tile < 12 ? qf : tile < 24 ? kf : vf);
+#pragma unroll
+            for (int g = 0; g < QKV_G; ++g) {
+                if (is_v) {
+                    const float bv = b[lane & 31];  // column = head feature
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[g][r] += bv;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[g][r] += b[fi(r, h)];
+                }
+                if (live[g]) {
+                    uint4 *dst = dbase + ((size_t)(tt[g] * NH + head) * 2) * 64 + lane;
+                    dst[0] = acc_to_frag(acc[g], 0);
+                    dst[64] = acc_to_frag(acc[g], 1);
+                }
+            }
         }
-        wp = np;
-        const int head = tile % 12;
-        const float *b = bqkv + tile * 32;
-        if (is_v) {
-            const float bv = b[lane & 31];  // column = head feature
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += bv;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += b[fi(r, h)];
-        }
-        uint4 *dst = (tile < 12 ? qf : tile < 24 ? kf : vf) + ((size_t)(tt * NH + head) * 2) * 64 + lane;
-        dst[0] = acc_to_frag(acc, 0);
-        dst[64] = acc_to_frag(acc, 1);
-    }
+    };
+    run_tiles(0, 24, std::false_type{});
+    run_tiles(24, 36, std::true_type{});
 }
 
 // ---------------------------------------------------------------- E3a: attention
@@ -348,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void oproj_ln_kernel(const uint4 *__restric
     uint4 c[KS_H];
 #pragma unroll
     for (int ks = 0; ks < KS_H; ++ks) c[ks] = cin[ks * 64];
-    constexpr int R = 8;
+    constexpr int R = 24;  // a whole output tile ahead (768 cycles of MFMAs); must divide KS_H
     const uint4 *wp = wo + lane;  // [nt][ks][64]
     uint4 ring[R];
 #pragma unroll
