@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "vec_kernels.h"
+#include "vec_kernels_f16.h"
 
 namespace mir {
 
@@ -80,8 +81,10 @@ struct mir_index {
     int64_t row_offset = 0;
     int ksteps = 0;
     uint32_t n_tiles = 0;
-    float *d_orig = nullptr;
-    uint4 *d_split = nullptr;
+    float *d_orig = nullptr;     // float32 rows (re-scoring); null on a float16-native index
+    _Float16 *d_f16 = nullptr;   // float16-native index: the rows as given (re-scoring)
+    bool native16 = false;       // float16 storage scanned as 2-byte fragments (vec_kernels_f16.h)
+    uint4 *d_split = nullptr;    // bf16 hi/lo fragments, or the float16 fragments of a native16 index
     float *d_docsq = nullptr;    // padded to n_tiles*32
     float *d_invnorm = nullptr;  // padded to n_tiles*32
     float *d_maxnorm = nullptr;
@@ -116,6 +119,7 @@ static void free_index(mir_index *ix) {
     }
     for (hipEvent_t ev : ix->prof_free) (void)hipEventDestroy(ev);
     (void)hipFree(ix->d_orig);
+    (void)hipFree(ix->d_f16);
     (void)hipFree(ix->d_split);
     (void)hipFree(ix->d_docsq);
     (void)hipFree(ix->d_invnorm);
@@ -129,9 +133,9 @@ static void free_index(mir_index *ix) {
 static int32_t build_derived(mir_index *ix, hipStream_t stream) {
     const int64_t n = ix->n;
     const int d = ix->d;
-    ix->ksteps = pad_ksteps(d);
+    ix->ksteps = ix->native16 ? d / 16 : pad_ksteps(d);
     ix->n_tiles = (uint32_t)((n + kTileRows - 1) / kTileRows);
-    const size_t split_bytes = (size_t)ix->n_tiles * ix->ksteps * 2048;
+    const size_t split_bytes = (size_t)ix->n_tiles * ix->ksteps * (ix->native16 ? 1024 : 2048);
     const size_t aux_bytes = (size_t)ix->n_tiles * kTileRows * sizeof(float);
     MIR_HIP(hipMalloc(&ix->d_split, std::max<size_t>(split_bytes, 16)));
     MIR_HIP(hipMalloc(&ix->d_docsq, std::max<size_t>(aux_bytes, 16)));
@@ -145,11 +149,19 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
         const int64_t total_lanes = (int64_t)ix->n_tiles * ix->ksteps * 64;
         const int64_t blocks = (total_lanes + 255) / 256;
         MIR_REQUIRE(blocks < (int64_t)0x7fffffff, "index too large for one pack launch");
-        pack_split_f32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ksteps,
-                                                                              total_lanes, ix->d_split);
-        MIR_HIP(hipGetLastError());
-        row_norms_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(
-            ix->d_orig, n, d, ix->d_docsq, ix->d_invnorm, reinterpret_cast<unsigned int *>(ix->d_maxnorm));
+        if (ix->native16) {
+            pack_f16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(ix->d_f16, n, d, ix->ksteps, total_lanes,
+                                                                            ix->d_split);
+            MIR_HIP(hipGetLastError());
+            row_norms_kernel<_Float16><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(
+                ix->d_f16, n, d, ix->d_docsq, ix->d_invnorm, reinterpret_cast<unsigned int *>(ix->d_maxnorm));
+        } else {
+            pack_split_f32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ksteps,
+                                                                                  total_lanes, ix->d_split);
+            MIR_HIP(hipGetLastError());
+            row_norms_kernel<float><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(
+                ix->d_orig, n, d, ix->d_docsq, ix->d_invnorm, reinterpret_cast<unsigned int *>(ix->d_maxnorm));
+        }
         MIR_HIP(hipGetLastError());
     }
     return MIR_OK;
@@ -190,6 +202,7 @@ struct SearchBuffers {
     uint4 *qsplit;   // [ngroups][ksteps][2][64]
     double *q_sq;    // [b]
     double *q_norm;  // [b]
+    float *qscale;   // [b] 1 / (query scale) of the float16-native scan
     uint64_t *part;  // [ngroups][nwg][qpw][klist]
     uint64_t *gthr;  // [ngroups][128] shared per-query thresholds of the 128-query scan
     uint64_t *part_sample;  // [kSampleWgs][128][klist], reused by every launch (stream-ordered)
@@ -208,6 +221,7 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.qsplit = c.take<uint4>((size_t)ngroups * (qpw / 32) * ksteps * 128);
     sb.q_sq = c.take<double>(b);
     sb.q_norm = c.take<double>(b);
+    sb.qscale = c.take<float>((size_t)ngroups * 128);
     sb.part = c.take<uint64_t>((size_t)ngroups * nwg * qpw * klist);
     sb.gthr = c.take<uint64_t>((size_t)ngroups * 128);
     sb.part_sample = c.take<uint64_t>((size_t)kSampleWgs * 128 * klist);
@@ -356,6 +370,35 @@ static int32_t launch_scan_b128(const mir_index *ix, const uint4 *qsplit_g, int 
     return MIR_OK;
 }
 
+// float16-native scan: 64 queries per launch
+template <int KIND>
+static int32_t launch_scan_f16(const mir_index *ix, const uint4 *qfrag_g, const float *qscale_g, int nq, int klist, int nwg,
+                               uint32_t n_tiles, uint64_t *part_g, uint64_t *gthr_g, bool sample, hipStream_t stream) {
+    const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
+    const size_t lds = f16_lds_bytes(klist);
+    const uint32_t n_rows = (uint32_t)ix->n;
+#define MIR_SCAN_CASE(KS)                                                                                    \
+    case KS: {                                                                                               \
+        auto kern = sample ? scan_topk_f16_kernel<KS, KIND, true> : scan_topk_f16_kernel<KS, KIND, false>;   \
+        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qfrag_g, qscale_g, n_rows, n_tiles,    \
+                                                    nq, klist, part_g, gthr_g);                              \
+        break;                                                                                               \
+    }
+    switch (ix->ksteps) {
+        MIR_SCAN_CASE(64)
+        MIR_SCAN_CASE(96)
+        MIR_SCAN_CASE(128)
+        default:
+            set_error("internal: float16 scan has no instance for %d k-steps", ix->ksteps);
+            return MIR_ERR_UNSUPPORTED;
+    }
+#undef MIR_SCAN_CASE
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
 static int32_t check_search_args(const mir_index *ix, const void *queries, int32_t b, int32_t k, int32_t metric,
                                  const int32_t *out_count) {
     MIR_REQUIRE(ix != nullptr, "index is NULL");
@@ -372,10 +415,14 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                               int ngroups, int nwg, int klist, int qpw, int32_t *o_doc, int64_t *o_chunk, int64_t *o_row,
                               double *o_dist, int32_t *o_count, int32_t *o_flags, hipStream_t stream) {
     const int d = ix->d;
-    if (qpw == 128) MIR_HIP(hipMemsetAsync(sb.gthr, 0, (size_t)ngroups * 128 * 8, stream));
+    if (qpw != 32) MIR_HIP(hipMemsetAsync(sb.gthr, 0, (size_t)ngroups * 128 * 8, stream));
     const int ntiles32 = ngroups * (qpw / 32);  // 32-query fragment tiles, padded to whole launches
-    prep_queries_kernel<<<dim3(ntiles32 * ix->ksteps + b), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, ntiles32,
-                                                                                sb.qsplit, sb.q_sq, sb.q_norm);
+    if (ix->native16)
+        prep_queries_f16_kernel<<<dim3(ntiles32 * ix->ksteps + b), dim3(64), 0, stream>>>(
+            dq, b, d, ix->ksteps, ntiles32, sb.qsplit, sb.q_sq, sb.q_norm, sb.qscale);
+    else
+        prep_queries_kernel<<<dim3(ntiles32 * ix->ksteps + b), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, ntiles32,
+                                                                                    sb.qsplit, sb.q_sq, sb.q_norm);
     MIR_HIP(hipGetLastError());
     for (int g = 0; g < ngroups; ++g) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -399,9 +446,15 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         uint64_t *pg = sb.part + (size_t)g * nwg * qpw * klist;
         const int nq = std::min(qpw, b - qpw * g);
         int32_t rc;
-        if (qpw == 128) {
+        if (qpw != 32) {
             uint64_t *gt = sb.gthr + (size_t)g * 128;
+            const float *qsc = sb.qscale + (size_t)g * qpw;
             auto run = [&](int wgs, uint32_t tiles, uint64_t *out, bool sample) {
+                if (ix->native16) {
+                    if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_f16<SCAN_IP>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
+                    if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_f16<SCAN_COS>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
+                    return launch_scan_f16<SCAN_L2>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
+                }
                 if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_b128<SCAN_IP>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
                 if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_b128<SCAN_COS>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
                 return launch_scan_b128<SCAN_L2>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
@@ -415,7 +468,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                 rc = run(kSampleWgs, sample_tiles, sb.part_sample, true);
                 if (rc == MIR_OK) {
                     sample_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(reinterpret_cast<const float *>(sb.part_sample),
-                                                                                kSampleWgs, klist, nq,
+                                                                                kSampleWgs, qpw, klist, nq,
                                                                                 reinterpret_cast<unsigned long long *>(gt));
                     MIR_HIP(hipGetLastError());
                 }
@@ -438,7 +491,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     }
     FinalizeArgs fa;
     fa.part = sb.part; fa.nwg = nwg; fa.qpw = qpw; fa.klist = klist; fa.k = k; fa.b = b; fa.d = d; fa.metric = metric;
-    fa.docs = ix->d_orig; fa.doc_sq = ix->d_docsq; fa.max_norm = ix->d_maxnorm;
+    fa.docs = ix->d_orig; fa.docs16 = ix->d_f16; fa.doc_sq = ix->d_docsq; fa.max_norm = ix->d_maxnorm;
     fa.q = dq; fa.q_sq = sb.q_sq; fa.q_norm = sb.q_norm;
     fa.chunk_ids = ix->d_chunk; fa.doc_ids = ix->d_doc; fa.row_offset = ix->row_offset;
     fa.out_doc = o_doc; fa.out_chunk = o_chunk; fa.out_row = o_row; fa.out_dist = o_dist;
@@ -455,6 +508,17 @@ static int32_t plan(const mir_index *ix, int b, int k, int *ngroups, int *nwg, i
         return MIR_ERR_UNSUPPORTED;
     }
     *klist = std::min(k + kListMargin, kMaxList);
+    if (ix->native16) {  // one kernel, 64 queries per pass; its LDS holds lists up to k = 28
+        if (f16_lds_bytes(*klist) > 160 * 1024) {
+            set_error("k=%d exceeds the float16 scan's candidate list (max k = %d)", k, 36 - kListMargin);
+            return MIR_ERR_UNSUPPORTED;
+        }
+        *qpw = kF16Queries;
+        *ngroups = (b + *qpw - 1) / *qpw;
+        const int64_t want16 = ((int64_t)ix->n_tiles + 3) / 4;
+        *nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want16));
+        return MIR_OK;
+    }
     // 128 queries per pass when it pays (more than one 32-query tile) and fits (d padded to a
     // multiple of 128 on the register-resident kernels, lists + DMA ring within 160 KiB of LDS)
     const bool wide = b > 32 && (ix->ksteps == 8 || ix->ksteps == 16 || ix->ksteps == 24) &&
@@ -515,9 +579,19 @@ static int32_t create_common(const void *emb, bool emb_on_device, int64_t n, int
         }                                                                                          \
     } while (0)
     const size_t orig_bytes = (size_t)n * d * sizeof(float);
+    // float16 rows with d a multiple of 512 (>= 1024): kept as they are and scanned as 2-byte
+    // fragments (vec_kernels_f16.h); everything else goes through the float32 / bf16-split layout
+    ix->native16 = dtype == MIR_DTYPE_F16 && d >= 1024 && d % 512 == 0 && d <= 2048;
+    if (ix->native16) {
+        MIR_TRY(hipMalloc(reinterpret_cast<void **>(&ix->d_f16), std::max<size_t>(orig_bytes / 2, 16)));
+        ix->hbm_bytes += orig_bytes / 2;
+        if (n > 0) MIR_TRY(hipMemcpyAsync(ix->d_f16, emb, orig_bytes / 2, kind, stream));
+    } else {
     MIR_TRY(hipMalloc(&ix->d_orig, std::max<size_t>(orig_bytes, 16)));
     ix->hbm_bytes += orig_bytes;
-    if (n > 0 && dtype == MIR_DTYPE_F32) {
+    }
+    if (ix->native16) {
+    } else if (n > 0 && dtype == MIR_DTYPE_F32) {
         MIR_TRY(hipMemcpyAsync(ix->d_orig, emb, orig_bytes, kind, stream));
     } else if (n > 0) {
         // float16 input: widened exactly to float32 on the device.  Every float16 is hi + lo in
@@ -741,8 +815,12 @@ int32_t mir_index_metric_eval(mir_index *idx, const double *query_host, int32_t 
     if (e == hipSuccess) {
         // ngroups = 0: only the per-query norm block runs
         prep_queries_kernel<<<dim3(1), dim3(64), 0, s>>>(dq, 1, d, idx->ksteps, 0, nullptr, dsq, dnm);
-        metric_eval_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(idx->d_orig, idx->d_docsq, n, d, dq,
-                                                                              dsq, dnm, metric, dout);
+        if (idx->native16)
+            metric_eval_kernel<_Float16><<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(idx->d_f16, idx->d_docsq, n, d,
+                                                                                            dq, dsq, dnm, metric, dout);
+        else
+            metric_eval_kernel<float><<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(idx->d_orig, idx->d_docsq, n, d, dq,
+                                                                                         dsq, dnm, metric, dout);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out_host, dout, (size_t)n * 8, hipMemcpyDeviceToHost, s);

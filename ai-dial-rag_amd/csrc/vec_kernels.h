@@ -135,48 +135,52 @@ __global__ __launch_bounds__(256) void widen_f16_kernel(const _Float16 *__restri
 // _rn intrinsics keep the compiler from contracting mul+add into an fma.
 __device__ __forceinline__ float sq_rn(float x) { return __fmul_rn(x, x); }
 
-__device__ inline float np_pairwise_leaf_sq(const float *a, int n) {
+template <typename T>
+__device__ inline float np_pairwise_leaf_sq(const T *a, int n) {
     if (n < 8) {
         float r = 0.f;
-        for (int i = 0; i < n; ++i) r = __fadd_rn(r, sq_rn(a[i]));
+        for (int i = 0; i < n; ++i) r = __fadd_rn(r, sq_rn((float)a[i]));
         return r;
     }
     float r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = sq_rn(a[j]);
+    for (int j = 0; j < 8; ++j) r[j] = sq_rn((float)a[j]);
     int i;
     for (i = 8; i < n - (n % 8); i += 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], sq_rn(a[i + j]));
+        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], sq_rn((float)a[i + j]));
     }
     float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
                           __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
-    for (; i < n; ++i) res = __fadd_rn(res, sq_rn(a[i]));
+    for (; i < n; ++i) res = __fadd_rn(res, sq_rn((float)a[i]));
     return res;
 }
-template <int DEPTH>
-__device__ inline float np_pairwise_sq(const float *a, int n) {
+template <int DEPTH, typename T>
+__device__ inline float np_pairwise_sq(const T *a, int n) {
     if (n <= 128) return np_pairwise_leaf_sq(a, n);
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return __fadd_rn(np_pairwise_sq<DEPTH - 1>(a, n2), np_pairwise_sq<DEPTH - 1>(a + n2, n - n2));
-}
-template <>
-__device__ inline float np_pairwise_sq<0>(const float *a, int n) {
-    // d > 128 * 2^12 is rejected on the host; unreachable
-    return np_pairwise_leaf_sq(a, n < 128 ? n : 128);
+    if constexpr (DEPTH == 0) {
+        // d > 128 * 2^12 is rejected on the host; unreachable
+        return np_pairwise_leaf_sq(a, 128);
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return __fadd_rn(np_pairwise_sq<DEPTH - 1>(a, n2), np_pairwise_sq<DEPTH - 1>(a + n2, n - n2));
+    }
 }
 
 // One thread per row: doc_sq (f32, numpy order), inv_norm = 1/max(|d|, 1e-8),
 // and the running maximum row norm (for the scan's error bound).
-__global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ src, int64_t n, int d,
+// T = float, or _Float16 (a float16 index: the reference up-casts to float32 first, so the values
+// summed are the same)
+template <typename T>
+__global__ __launch_bounds__(256) void row_norms_kernel(const T *__restrict__ src, int64_t n, int d,
                                                         float *__restrict__ doc_sq,
                                                         float *__restrict__ inv_norm,
                                                         unsigned int *__restrict__ max_norm_bits) {
     int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float nrm = 0.f;
     if (row < n) {
-        const float *a = src + row * (int64_t)d;
+        const T *a = src + row * (int64_t)d;
         doc_sq[row] = np_pairwise_sq<12>(a, d);
         double s = 0.0;
         for (int j = 0; j < d; ++j) s += (double)a[j] * (double)a[j];
@@ -236,15 +240,16 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const double *__restri
 // per 8 entries instead of once per entry (klist is a multiple of 2, padded
 // reads past klist see the ~0 sentinel rows of the caller's allocation: no -
 // they are masked by the bound check below).
+template <int STRIDE = 256>
 __device__ __forceinline__ void list_insert(uint64_t *list, int klist, int tid, uint64_t key, uint64_t &minkey,
                                             int &minpos) {
-    list[minpos * 256 + tid] = key;
+    list[minpos * STRIDE + tid] = key;
     uint64_t m = ~0ull;
     int mp = 0;
     for (int p0 = 0; p0 < klist; p0 += 8) {
         uint64_t x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = (p0 + j < klist) ? list[(p0 + j) * 256 + tid] : ~0ull;
+        for (int j = 0; j < 8; ++j) x[j] = (p0 + j < klist) ? list[(p0 + j) * STRIDE + tid] : ~0ull;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (x[j] < m) {
@@ -451,6 +456,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
 //  * the per-score filter of tile t-1 is software-pipelined into tile t: one
 //    score after each MFMA of the first stage, so its VALU work issues in the
 //    matrix pipe's shadow instead of extending the tile (see the kernel).
+template <int STRIDE = 256>
 __device__ __forceinline__ void drain_candidates(uint32_t mask, const float (&v)[16], uint32_t row0, uint64_t *list,
                                                  int klist, int tid, uint64_t &minkey, int &minpos, int &pending) {
     while (__any(mask != 0)) {
@@ -470,15 +476,15 @@ __device__ __forceinline__ void drain_candidates(uint32_t mask, const float (&v)
             x = (x == x) ? x + 0.0f : -__builtin_inff();  // NaN ranks last; -0 -> +0
             const uint64_t key = make_key(x, row0 + 8 * (r >> 2) + (r & 3));
             if (key > minkey) {
-                list[(klist + pending) * 256 + tid] = key;
+                list[(klist + pending) * STRIDE + tid] = key;
                 ++pending;
             }
         }
         if (__any(pending == kB128Pending)) {  // wave-uniform: merge every lane's buffer now
             for (int i = 0; i < kB128Pending; ++i) {
                 if (i < pending) {
-                    const uint64_t key = list[(klist + i) * 256 + tid];
-                    if (key > minkey) list_insert(list, klist, tid, key, minkey, minpos);
+                    const uint64_t key = list[(klist + i) * STRIDE + tid];
+                    if (key > minkey) list_insert<STRIDE>(list, klist, tid, key, minkey, minpos);
                 }
             }
             pending = 0;
@@ -917,26 +923,27 @@ __global__ __launch_bounds__(256, 1) void scan_topk_generic_kernel(const uint4 *
 //   cosine_sim       embeddings_metrics.py:28-31  torch: unit doc row rounded to f32
 //                                                 (norm and division in f32), query unit in f64
 // `rank_value` returns the quantity the scan ranks by, in the scan's units.
-__device__ __forceinline__ double exact_metric_wave(const float *__restrict__ row, const double *__restrict__ q,
+template <typename T>
+__device__ __forceinline__ double exact_metric_wave(const T *__restrict__ row, const double *__restrict__ q,
                                                     int d, int metric, float doc_sq32, double q_sq,
                                                     double q_norm, int lane, double *rank_value) {
     if (metric == MIR_METRIC_COSINE_SIM) {
         double s = 0.0;
         for (int j = lane; j < d; j += 64) {
-            double x = (double)row[j];
+            double x = (double)(float)row[j];
             s += x * x;
         }
         s = wave_sum(s);
         const float dn = fmaxf((float)sqrt(s), 1e-8f);
         const double qn = fmax(q_norm, 1e-8);
         double c = 0.0;
-        for (int j = lane; j < d; j += 64) c += (double)__fdiv_rn(row[j], dn) * (q[j] / qn);
+        for (int j = lane; j < d; j += 64) c += (double)__fdiv_rn((float)row[j], dn) * (q[j] / qn);
         c = wave_sum(c);
         *rank_value = c * qn;
         return -c;
     }
     double dot = 0.0;
-    for (int j = lane; j < d; j += 64) dot += (double)row[j] * q[j];
+    for (int j = lane; j < d; j += 64) dot += (double)(float)row[j] * q[j];
     dot = wave_sum(dot);
     if (metric == MIR_METRIC_INNER_PRODUCT) {
         *rank_value = dot;
@@ -956,7 +963,8 @@ __device__ __forceinline__ bool dist_before(double da, uint32_t ra, double db, u
 }
 
 // One wave per row: out[row] = metric(query, docs[row]).  grid = ceil(n/4), block 256.
-__global__ __launch_bounds__(256) void metric_eval_kernel(const float *__restrict__ docs,
+template <typename T>
+__global__ __launch_bounds__(256) void metric_eval_kernel(const T *__restrict__ docs,
                                                           const float *__restrict__ doc_sq, int64_t n, int d,
                                                           const double *__restrict__ q,
                                                           const double *__restrict__ q_sq,
@@ -1047,7 +1055,8 @@ struct FinalizeArgs {
     int b;
     int d;
     int metric;
-    const float *docs;      // f32 [n][d]
+    const float *docs;      // f32 [n][d], or null with
+    const _Float16 *docs16; // f16 [n][d] (float16-native index)
     const float *doc_sq;    // f32 [n]
     const float *max_norm;  // 1 float
     const double *q;        // [b][d]
@@ -1089,8 +1098,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     for (int c = wave; c < nc; c += 4) {
         const uint32_t row = key_row(keys[c]);
         double rv;
-        const double dist = exact_metric_wave(a.docs + (size_t)row * a.d, q, a.d, a.metric, a.doc_sq[row],
-                                              a.q_sq[qi], a.q_norm[qi], lane, &rv);
+        const double dist = a.docs16 ? exact_metric_wave(a.docs16 + (size_t)row * a.d, q, a.d, a.metric, a.doc_sq[row],
+                                                         a.q_sq[qi], a.q_norm[qi], lane, &rv)
+                                     : exact_metric_wave(a.docs + (size_t)row * a.d, q, a.d, a.metric, a.doc_sq[row],
+                                                         a.q_sq[qi], a.q_norm[qi], lane, &rv);
         if (lane == 0) {
             c_dist[c] = dist;
             c_rank[c] = rv;
@@ -1142,8 +1153,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
 // After a scan of a SAMPLE of the rows: the klist-th best key of the sample is a lower bound on
 // the klist-th best key of the whole index (the sample is a subset), so it is a valid starting
 // threshold for every list of the full scan.  One block per query.
-__global__ __launch_bounds__(256) void sample_threshold_kernel(const float *__restrict__ part, int nwg, int klist,
-                                                               int b_in_launch,
+__global__ __launch_bounds__(256) void sample_threshold_kernel(const float *__restrict__ part, int nwg, int qpw,
+                                                               int klist, int b_in_launch,
                                                                unsigned long long *__restrict__ gthr) {
     constexpr int kMaxVals = 2 * 256;  // two half-lanes per workgroup, kSampleWgs <= 256
     __shared__ __attribute__((aligned(16))) float vals[kMaxVals];
@@ -1153,7 +1164,7 @@ __global__ __launch_bounds__(256) void sample_threshold_kernel(const float *__re
     const int n = 2 * nwg;
     for (int e = tid; e < kMaxVals; e += 256) {
         float v = -__builtin_inff();
-        if (e < n) v = part[((size_t)(e >> 1) * 128 + q) * 2 + (e & 1)];
+        if (e < n) v = part[((size_t)(e >> 1) * qpw + q) * 2 + (e & 1)];
         vals[e] = (v == v) ? v : -__builtin_inff();
     }
     if (tid == 0) thr = -__builtin_inff();

@@ -283,6 +283,65 @@ def test_float16_storage_d1024_multimodal_shape(amd, metric):
         np.testing.assert_allclose(dev.metric_eval(qs[1], metric), oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[1], docs32), rtol=1e-13)
 
 
+@pytest.mark.parametrize("metric", ["inner_product", "euclidean_dist", "sqeuclidean_dist", "cosine_sim"])
+def test_float16_native_scan_shapes(amd, metric):
+    """The float16-native path (d = 1024 kept as 2-byte fragments, 64 queries per pass): a ragged last
+    tile, batches of 1 / 33 / 64 / 100 queries (one and two passes, one and two query tiles), duplicates
+    across the tile boundary, queries of very different magnitude (per-query power-of-two scaling)."""
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(515)
+    n = 20011
+    docs16 = (rng.standard_normal((n, 1024)) * rng.uniform(0.2, 3.0, (n, 1))).astype(np.float16)
+    docs16[31] = docs16[32] = docs16[n - 1]
+    docs32 = docs16.astype(np.float32)
+    dev = amd.ei.DeviceIndex.from_host(docs16)
+    assert dev.hbm_bytes() < 2.2 * docs16.nbytes  # rows (2 B) + fragments (2 B) + norms: not the 8 x of the widened path
+    qs = rng.standard_normal((100, 1024))
+    qs[3] *= 1e-6
+    qs[4] *= 3e4
+    qs[5] = docs32[n - 1].astype(np.float64)
+    for b in (1, 33, 64, 100):
+        _, _, rows, dist, cnt, flags = dev.search(qs[:b], 10, metric)
+        assert (cnt == 10).all()
+        for i in range(b):
+            wrows, wdist = oi.find_flat(qs[i], docs32, metric, 10)
+            alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs32) if metric == "cosine_sim" else None
+            assert_same_ids(metric, rows[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} b={b} q={i}")
+            np.testing.assert_allclose(dist[i], wdist, rtol=1e-12, atol=2e-7 * max(1.0, float(np.abs(wdist).max())))
+    if metric == "sqeuclidean_dist":
+        assert list(rows[5, :3]) == [31, 32, n - 1]
+    # k up to the float16 scan's list capacity; above it the call is refused, never wrong
+    _, _, rows28, _, cnt28, _ = dev.search(qs[:2], 28, metric)
+    for i in range(2):
+        wrows, _ = oi.find_flat(qs[i], docs32, metric, 28)
+        alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs32) if metric == "cosine_sim" else None
+        assert_same_ids(metric, rows28[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} k=28 q={i}")
+    with pytest.raises(NotImplementedError):
+        dev.search(qs[:1], 29, metric)
+
+
+def test_float16_native_large_shard_sample_prepass(amd):
+    """More than 32768 tiles: the threshold pre-pass runs on the float16 scan too."""
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(616)
+    n = 1_060_000
+    docs16 = np.empty((n, 1024), np.float16)
+    for c in range(0, n, 106_000):
+        docs16[c : c + 106_000] = rng.standard_normal((106_000, 1024), dtype=np.float32).astype(np.float16)
+    dev = amd.ei.DeviceIndex.from_host(docs16)
+    qs = rng.standard_normal((70, 1024))
+    _, _, rows, dist, cnt, flags = dev.search(qs, 10, "sqeuclidean_dist")
+    assert (flags == 0).all()
+    fn = oi.ENUM_TO_METRIC[oi.Metric("sqeuclidean_dist")]
+    for i in (0, 33, 69):
+        alld = np.concatenate([fn(qs[i], docs16[c : c + 106_000].astype(np.float32)) for c in range(0, n, 106_000)])
+        want = np.argsort(alld, kind="stable")[:10]
+        np.testing.assert_array_equal(rows[i], want)
+        np.testing.assert_allclose(dist[i], alld[want], rtol=1e-12, atol=1e-6)
+
+
 def test_k_above_list_capacity_is_refused_not_wrong(amd):
     rng = np.random.default_rng(4)
     dev = amd.ei.DeviceIndex.from_host(unit(rng.standard_normal((500, 32))))
