@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--metric", default="sqeuclidean_dist")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-queries", type=int, default=4)
+    ap.add_argument("--c5-rows", type=int, default=6_250_000,
+                    help="rows PER GPU of the float16 d=1024 leg (BASELINE config 5: 50M over 8 GPUs); 0 = skip")
     ap.add_argument("--encode-chunks", type=int, default=8192,
                     help="chunks per GPU for the index-build (encoder) leg of the metric; 0 = skip")
     return ap.parse_args()
@@ -120,6 +122,65 @@ def encoder_leg(np, torch, dist, args, world, rank, local_rank, barrier):
         "frac_of_mfma_peak": round(flops / dt / 1e12 / 2500.0, 4),
         "weights": "random init, bge-small-en shape",
         "unit_norm_outputs": norms_ok,
+    }
+
+
+def c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher):
+    """BASELINE config 5 (SURVEY.md 8(d)): d = 1024 float16 vectors, not normalised, sqeuclidean;
+    rows_per_gpu fixed (50M over 8 GPUs = 6.25M each), so this leg scales weakly with --gpus.
+    The index keeps the rows in float16 (2 B/element scanned, 64 queries per pass)."""
+    device = torch.device("cuda", local_rank)
+    n_loc, d, B, k = args.c5_rows, 1024, 128, args.k
+    g = torch.Generator(device=device)
+    shard = torch.empty((n_loc, d), dtype=torch.float16, device=device)
+    for c in range(0, n_loc, 250_000):
+        g.manual_seed(2024 + rank * 1000 + c // 250_000)
+        m = min(250_000, n_loc - c)
+        shard[c : c + m] = torch.randn((m, d), generator=g, dtype=torch.float32, device=device).half()
+    torch.cuda.synchronize()
+    index = DeviceIndex.from_device_ptr(shard.data_ptr(), n_loc, d, local_rank, row_offset=rank * n_loc,
+                                        stream=torch.cuda.current_stream().cuda_stream, float16=True)
+    torch.cuda.synchronize()
+    hbm = index.hbm_bytes()
+    del shard
+    torch.cuda.empty_cache()
+    g.manual_seed(4322)
+    queries = torch.randn((B, d), generator=g, dtype=torch.float32, device=device).double().contiguous()
+    searcher = ShardedSearcher(local_index=index)
+    index.profile(True)
+    for _ in range(2):
+        out = searcher.search(queries, k, "sqeuclidean_dist")
+    barrier()
+    index.profile_read(reset=True)
+    steps = 10
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = searcher.search(queries, k, "sqeuclidean_dist")
+    barrier()
+    elapsed = time.perf_counter() - t0
+    index.profile(False)
+    launches, scan_ms = index.profile_read(reset=True)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    flags = int(out[3].sum().item())
+    index.close()
+    bytes_pass = n_loc * d * 2 + 4 * n_loc + 64 * d * 4 + 64 * k * 12  # SURVEY 8(d), s = 2 (fp16), 64 queries per pass
+    avg_ms = scan_ms / max(launches, 1)
+    return {
+        "workload": f"{n_loc} x {d} float16 rows per GPU (not normalised), sqeuclidean_dist, k={k}",
+        "scaling": "weak",
+        "queries_per_step": B,
+        "queries_per_pass": 64,
+        "ms_per_step": round(1e3 * elapsed / steps, 4),
+        "qps": round(B * steps / elapsed, 1),
+        "index_hbm_bytes_per_gpu": hbm,
+        "roofline": {"bound": "hbm", "kernel": "scan_topk_f16_kernel", "bytes_per_launch": bytes_pass,
+                     "avg_launch_ms": round(avg_ms, 4), "achieved": round(bytes_pass / (avg_ms * 1e-3) / 1e9, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_pass / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "launches": launches},
+        "uncertain_queries": flags,
     }
 
 
@@ -262,8 +323,11 @@ def main():
         "index_build_s": {"generate": round(t_gen, 2), "upload_pack_norms": round(t_build, 2)},
     }
 
+    if args.encode_chunks > 0 or args.c5_rows > 0:
+        index.close()  # release the shard before the other legs allocate theirs
+    if args.c5_rows > 0:
+        result["c5_float16_d1024"] = c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher)
     if args.encode_chunks > 0:
-        index.close()  # release the shard before the encoder leg allocates its workspaces
         result["index_build"] = encoder_leg(np, torch, dist, args, world, rank, local_rank, barrier)
     if rank == 0 and world == 1 and sample is not None and len(sample):
         result["cpu_baseline"] = cpu_baseline(np, sample, queries[: args.cpu_queries].cpu().numpy(), args, DeviceIndex)
