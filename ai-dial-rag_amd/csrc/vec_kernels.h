@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void scan_topk_kernel(const uint4 *__restri
 // compute stage A, hi waves stage B), except that d <= 128 keeps one 8-k-step stage per tile.
 __host__ __device__ constexpr int b128_stage_ksteps(int ksteps) { return ksteps >= 16 ? ksteps / 2 : 8; }
 __host__ __device__ constexpr int b128_ring_stages(int ksteps) { return 96 / (b128_stage_ksteps(ksteps) * 2); }  // <= 96 KiB of ring
-constexpr int kB128Pending = 4;  // per-lane buffer of appended, not yet merged candidates  // per-lane buffer of appended, not yet merged candidates
+constexpr int kB128Pending = 4;  // per-lane buffer of appended, not yet merged candidates
 
 // LDS-DMA of one 1-KiB piece (16 B per lane) as inline asm: with the builtin, hipcc
 // orders every later ds_read behind ALL pending DMAs (`s_waitcnt vmcnt(0)` after the
@@ -490,25 +490,6 @@ __device__ __forceinline__ void drain_candidates(uint32_t mask, const float (&v)
             pending = 0;
         }
     }
-}
-
-// score r of a finished tile -> ranking value; sets its mask bit when it may beat the lane's threshold
-template <int KIND>
-__device__ __forceinline__ void filter_score(int r, const f32x16 &am, const f32x16 &ac, const float4 (&ax)[4],
-                                             uint32_t row0, uint32_t n_rows, bool open, float vmin, float (&v)[16],
-                                             uint32_t &mask) {
-    const int g = r >> 2, i = r & 3;
-    const float dot = am[r] + ac[r];
-    float x;
-    if (KIND == SCAN_IP) {
-        x = dot;
-    } else {
-        const float a = (i == 0) ? ax[g].x : (i == 1) ? ax[g].y : (i == 2) ? ax[g].z : ax[g].w;
-        x = (KIND == SCAN_L2) ? fmaf(2.0f, dot, -a) : dot * a;
-    }
-    v[r] = x;
-    // NaN fails `x >= vmin`; while the list is still open (fewer than klist entries) everything is taken
-    if (row0 + 8 * g + i < n_rows && (open || x >= vmin)) mask |= 1u << r;
 }
 
 // K-split form: 8 waves per workgroup, TWO per SIMD.  Query tile qt (0..3) is served by a

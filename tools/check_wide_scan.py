@@ -1,3 +1,4 @@
+"""Repeat-run parity check of the 128-query scan against the oracle (B = 70 on a small index): used while chasing an intermittent ordering bug; prints mismatching queries."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
