@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="sqeuclidean_dist")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-queries", type=int, default=4)
+    ap.add_argument("--cpu-queries", type=int, default=16)
     ap.add_argument("--c5-rows", type=int, default=6_250_000,
                     help="rows PER GPU of the float16 d=1024 leg (BASELINE config 5: 50M over 8 GPUs); 0 = skip")
     ap.add_argument("--encode-chunks", type=int, default=8192,
