@@ -273,10 +273,12 @@ def main():
     # ---- roofline of the dominant kernel (scan), per launch ----
     # algorithmic bytes per launch: shard rows * d * 4 (the bf16 hi+lo image is
     # the same 4 B/element) + 4 B/row norm column (sqeuclid/cosine) + the query tile + its results.
-    # One launch serves min(B, 128) queries when B > 32 (scan_topk_b128_kernel), else 32.
+    # One launch of scan_topk_b128_kernel serves up to 128 queries (it is used for every batch size at
+    # d = 384, k <= 12; the 32-query register-ring kernel only for other shapes).
     n_loc = hi - lo
     aux = 0 if args.metric == "inner_product" else 4 * n_loc
-    qpl = 128 if B > 32 else 32
+    wide = d in (128, 256, 384) and k <= 12
+    qpl = 128 if wide else 32
     bytes_launch = n_loc * d * 4 + aux + qpl * d * 4 + qpl * k * 12
     avg_ms = scan_ms / max(launches, 1)
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
@@ -308,7 +310,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "scan_topk_b128_kernel" if B > 32 else "scan_topk_kernel",
+            "kernel": "scan_topk_b128_kernel" if wide else "scan_topk_kernel",
             "queries_per_launch": qpl,
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,

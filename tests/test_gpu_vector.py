@@ -342,6 +342,25 @@ def test_float16_native_large_shard_sample_prepass(amd):
         np.testing.assert_allclose(dist[i], alld[want], rtol=1e-12, atol=1e-6)
 
 
+@pytest.mark.parametrize("metric", ["sqeuclidean_dist", "cosine_sim"])
+def test_register_ring_kernel_large_k(amd, metric):
+    """k > 12 at d = 384 does not fit the 128-query kernel's LDS lists: these searches run the 32-query
+    register-ring kernel (scan_topk_kernel), 32 queries per pass."""
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(77)
+    docs = unit(rng.standard_normal((40000, 384)))
+    qs = unit(rng.standard_normal((40, 384))).astype(np.float64)
+    dev = amd.ei.DeviceIndex.from_host(docs)
+    _, _, rows, dist, cnt, flags = dev.search(qs, 30, metric)
+    assert (cnt == 30).all()
+    for i in range(40):
+        wrows, wdist = oi.find_flat(qs[i], docs, metric, 30)
+        alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs) if metric == "cosine_sim" else None
+        assert_same_ids(metric, rows[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} q={i}")
+        np.testing.assert_allclose(dist[i], wdist, rtol=0, atol=2e-7)
+
+
 def test_k_above_list_capacity_is_refused_not_wrong(amd):
     rng = np.random.default_rng(4)
     dev = amd.ei.DeviceIndex.from_host(unit(rng.standard_normal((500, 32))))
