@@ -35,11 +35,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=384)
-    ap.add_argument("--batch", type=int, default=128, help="queries per step (B)")
+    ap.add_argument("--batch", type=int, default=96,
+                    help="queries per step (B).  The scan is clock/power-limited: 128 per pass gives the most QPS (~37k) at "
+                         "57-60 %% of the HBM roofline, 96 gives ~31k at 63-65 %%, 64 ~25k at 77 %%; the sweep reports the others")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="sqeuclidean_dist")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-queries", type=int, default=16)
+    ap.add_argument("--no-sweep", dest="sweep", action="store_false", help="skip the B = 1 / 32 / 64 side measurements")
     ap.add_argument("--c5-rows", type=int, default=6_250_000,
                     help="rows PER GPU of the float16 d=1024 leg (BASELINE config 5: 50M over 8 GPUs); 0 = skip")
     ap.add_argument("--encode-chunks", type=int, default=8192,
@@ -325,6 +328,32 @@ def main():
         "index_build_s": {"generate": round(t_gen, 2), "upload_pack_norms": round(t_build, 2)},
     }
 
+    # ---- the same index at other batch sizes: queries per pass trade QPS against roofline fraction ----
+    if args.sweep:
+        sweep = []
+        for Bs in (1, 32, 64, 96, 128):
+            if Bs == B:
+                continue
+            index.profile(True)
+            for i in range(3):
+                searcher.search(queries[i * Bs : (i + 1) * Bs], k, args.metric)
+            barrier()
+            index.profile_read(reset=True)
+            t0 = time.perf_counter()
+            for i in range(10):
+                searcher.search(queries[i * Bs : (i + 1) * Bs], k, args.metric)
+            barrier()
+            el = time.perf_counter() - t0
+            index.profile(False)
+            ln, ms = index.profile_read(reset=True)
+            tm = torch.tensor([el], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+            a_ms = ms / max(ln, 1)
+            sweep.append({"queries_per_step": Bs, "qps": round(Bs * 10 / el, 1), "ms_per_step": round(1e3 * el / 10, 4),
+                          "scan_launch_ms": round(a_ms, 4), "roofline_frac": round(bytes_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        result["batch_sweep"] = sweep
     if args.encode_chunks > 0 or args.c5_rows > 0:
         index.close()  # release the shard before the other legs allocate theirs
     if args.c5_rows > 0:
