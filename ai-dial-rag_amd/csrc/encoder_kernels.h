@@ -345,17 +345,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict_
         }
         mx = half_max(mx);
         const float m_new = fmaxf(m, mx);
-        const float alpha = exp2f(m - m_new);
+        // v_exp_f32 directly: exp2f() wraps it in a compare / select / ldexp to keep results below
+        // 2^-126 exact, ~4 extra instructions per value in a VALU-bound loop; a softmax term that small
+        // is zero next to the row's maximum term 1.0 either way
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = exp2f(s[r] - m_new);
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
             ps += s[r];
         }
-        l = fmaf(l, alpha, half_sum(ps));
-        m = m_new;
+        ps = half_sum(ps);
+        if (__any(m_new > m)) {  // some query's running maximum moved: rescale (wave-uniform branch)
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);  // exp2(-inf) = 0 on the first tile
+            l = fmaf(l, alpha, ps);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        } else {
+            l += ps;
+        }
+        m = m_new;
         o = mfma(v0, acc_to_frag(s, 0), o);
         o = mfma(v1, acc_to_frag(s, 1), o);
     }
