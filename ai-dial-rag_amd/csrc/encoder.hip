@@ -315,7 +315,10 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         for (int li = 0; li < nl; ++li) {
             const Layer &l = e->L[li];
             qkv_kernel<<<dim3((nt + 4 * QKV_G - 1) / (4 * QKV_G)), blk, 0, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
-            attention_kernel<<<dim3((nt * NH + 3) / 4), blk, 0, s>>>(qf, kf, vf, d_ti, nt, a1);  // a1 = context
+            {
+                const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);  // a1 = context
+                if (arc != MIR_OK) return arc;
+            }
             oproj_ln_kernel<<<g4, blk, 0, s>>>(a1, nt, l.wo, l.attn_params, l.attn_params + H, l.attn_params + 2 * H,
                                                a0, a1);  // in place: each wave reads its tile's context before writing it
             ffn_ln_kernel<<<g4, blk, FFN_LDS_BYTES, s>>>(a1, nt, l.wffn, l.ffn_params, a0);

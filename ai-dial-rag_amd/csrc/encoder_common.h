@@ -1,0 +1,167 @@
+// Device code of the bge-small-en (BERT-small) encoder for gfx950.
+//
+// Replaces the sentence-transformers forward behind
+//   aidial_rag/embeddings/embeddings.py:52-108  (bge_embedding_impl, aembed_*)
+// 12 layers, hidden 384, 12 heads x 32, FFN 1536, CLS pooling, L2 normalise.
+// float16 operands, float32 accumulation (the reference's own CUDA path is
+// float16 + SDPA, embeddings.py:43-48).
+//
+// Design: tokens live on MFMA *columns* (lanes), features on rows (registers).
+// Every product is computed transposed, out^T = W^T * x^T, with
+// v_mfma_f32_32x32x16_f16: the weight tile is the A operand, 32 tokens' features
+// the B operand.  Consequences:
+//   * a 32-token tile's activations are 24 B-fragments (96 VGPRs) that stay in
+//     registers for a whole kernel; weights are pre-packed on the host into
+//     A-fragment order, so a weight k-step is ONE coalesced 1-KiB load (or one
+//     LDS-DMA piece) with no transpose, no swizzle, no bank conflict;
+//   * the 32x32 accumulator has lane = token, registers = 16 features, which is
+//     already the B fragment of the NEXT product up to a fixed permutation of k
+//     that is folded into the host-side weight packing ("acc-native" order:
+//     element j of lane-half h <-> feature 16*s + 8*(j>>2) + 4*h + (j&3));
+//     no LDS round trip between GEMMs, ever;
+//   * bias, GELU, softmax statistics, residual and LayerNorm are per-token =
+//     per-lane: reductions run over registers plus ONE cross-half shuffle.
+//
+// Activation layout ACT (float16): [token tile][feature block of 32][s2][64 lanes][8]:
+// lane (ti = l&31, h = l>>5), element j of block (fb, s2) = feature
+// 32*fb + 16*s2 + 8*(j>>2) + 4*h + (j&3) of token 32*tile + ti.  This is the
+// accumulator's own register order, so stores and loads are 16-byte per lane,
+// fully coalesced.
+#pragma once
+// (shared by encoder.hip and encoder_attention.hip: types, fragment helpers, the LayerNorm epilogue)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace mir {
+namespace enc {
+
+typedef _Float16 __attribute__((ext_vector_type(8))) f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int H = 384;        // hidden
+constexpr int NH = 12;        // heads
+constexpr int HD = 32;        // head dim
+constexpr int FF = 1536;      // intermediate
+constexpr int NFB = H / 32;   // 12 feature blocks
+constexpr int KS_H = H / 16;  // 24 k-steps over the hidden dim
+constexpr int NHT = FF / 32;  // 48 intermediate tiles
+constexpr float LN_EPS = 1e-12f;
+
+// feature (row) index inside a 32-row accumulator tile for register r of lane-half h
+__device__ __forceinline__ int fi(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    const _Float16 x = (_Float16)a, y = (_Float16)b;
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+// registers 8*s2 .. 8*s2+7 of an accumulator -> one float16 fragment
+__device__ __forceinline__ uint4 acc_to_frag(const f32x16 &a, int s2) {
+    const int o = 8 * s2;
+    return make_uint4(pack2(a[o + 0], a[o + 1]), pack2(a[o + 2], a[o + 3]), pack2(a[o + 4], a[o + 5]),
+                      pack2(a[o + 6], a[o + 7]));
+}
+__device__ __forceinline__ void frag_to_floats(uint4 f, float (&out)[8]) {
+    const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        out[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] & 0xffffu));
+        out[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] >> 16));
+    }
+}
+
+__device__ __forceinline__ float half_sum(float x) { return x + __shfl_xor(x, 32, 64); }
+__device__ __forceinline__ float half_max(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
+
+// exact-erf GELU (HF "gelu"), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
+__device__ __forceinline__ float gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = 1.0f - p * __expf(-z * z);
+    const float erf_v = x < 0.f ? -e : e;
+    return 0.5f * x * (1.0f + erf_v);
+}
+
+// Per-tile bookkeeping: which sequence a 32-token tile belongs to.
+struct TileInfo {
+    int seq_first_tile;  // first tile of the tile's sequence
+    int seq_tiles;       // tiles of that sequence
+    int seq_len;         // real tokens of that sequence
+    int seq_index;
+};
+
+// y[12] (+bias) + residual -> LayerNorm -> ACT store.  `y` rows are features.
+// Register r of lane-half h is feature (r&3) + 8*(r>>2) + 4*h of its 32-feature block: the four
+// registers of a group g = r>>2 are four CONSECUTIVE features, so bias / gamma / beta are read as
+// float4 (a quarter of the loads of the per-register form, which made this epilogue ~3000
+// instructions and longer than the output projection's MFMAs).
+__device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 *__restrict__ resid_tile,
+                                                  const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                  const float *__restrict__ beta, uint4 *__restrict__ out_tile,
+                                                  int lane, bool store) {
+    const int h = lane >> 5;
+    float sum = 0.f;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float rv[8];
+            frag_to_floats(resid_tile[(fb * 2 + s2) * 64 + lane], rv);
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {
+                const int g = 2 * s2 + gq;
+                const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * fb + 8 * g + 4 * h);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * g + i;
+                    const float v = y[fb][r] + bb[i] + rv[4 * gq + i];
+                    y[fb][r] = v;
+                    sum += v;
+                }
+            }
+        }
+    }
+    const float mean = half_sum(sum) * (1.0f / H);
+    float sq = 0.f;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dlt = y[fb][r] - mean;
+            y[fb][r] = dlt;
+            sq = fmaf(dlt, dlt, sq);
+        }
+    const float rstd = rsqrtf(half_sum(sq) * (1.0f / H) + LN_EPS);
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+        float o[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 g4 = *reinterpret_cast<const float4 *>(gamma + 32 * fb + 8 * g + 4 * h);
+            const float4 e4 = *reinterpret_cast<const float4 *>(beta + 32 * fb + 8 * g + 4 * h);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[4 * g + i] = fmaf(y[fb][4 * g + i] * rstd, gg[i], ee[i]);
+        }
+        if (store) {
+            out_tile[(fb * 2 + 0) * 64 + lane] =
+                make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
+            out_tile[(fb * 2 + 1) * 64 + lane] =
+                make_uint4(pack2(o[8], o[9]), pack2(o[10], o[11]), pack2(o[12], o[13]), pack2(o[14], o[15]));
+        }
+    }
+}
+
+
+}  // namespace enc
+}  // namespace mir

@@ -1,165 +1,10 @@
-// Device code of the bge-small-en (BERT-small) encoder for gfx950.
-//
-// Replaces the sentence-transformers forward behind
-//   aidial_rag/embeddings/embeddings.py:52-108  (bge_embedding_impl, aembed_*)
-// 12 layers, hidden 384, 12 heads x 32, FFN 1536, CLS pooling, L2 normalise.
-// float16 operands, float32 accumulation (the reference's own CUDA path is
-// float16 + SDPA, embeddings.py:43-48).
-//
-// Design: tokens live on MFMA *columns* (lanes), features on rows (registers).
-// Every product is computed transposed, out^T = W^T * x^T, with
-// v_mfma_f32_32x32x16_f16: the weight tile is the A operand, 32 tokens' features
-// the B operand.  Consequences:
-//   * a 32-token tile's activations are 24 B-fragments (96 VGPRs) that stay in
-//     registers for a whole kernel; weights are pre-packed on the host into
-//     A-fragment order, so a weight k-step is ONE coalesced 1-KiB load (or one
-//     LDS-DMA piece) with no transpose, no swizzle, no bank conflict;
-//   * the 32x32 accumulator has lane = token, registers = 16 features, which is
-//     already the B fragment of the NEXT product up to a fixed permutation of k
-//     that is folded into the host-side weight packing ("acc-native" order:
-//     element j of lane-half h <-> feature 16*s + 8*(j>>2) + 4*h + (j&3));
-//     no LDS round trip between GEMMs, ever;
-//   * bias, GELU, softmax statistics, residual and LayerNorm are per-token =
-//     per-lane: reductions run over registers plus ONE cross-half shuffle.
-//
-// Activation layout ACT (float16): [token tile][feature block of 32][s2][64 lanes][8]:
-// lane (ti = l&31, h = l>>5), element j of block (fb, s2) = feature
-// 32*fb + 16*s2 + 8*(j>>2) + 4*h + (j&3) of token 32*tile + ti.  This is the
-// accumulator's own register order, so stores and loads are 16-byte per lane,
-// fully coalesced.
+// Kernels of the bge-small-en encoder except attention (encoder_attention.hip); see encoder_common.h
+// for the design notes, layouts and helpers.  Included by encoder.hip only (the kernels have external linkage).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <type_traits>
+#include "encoder_common.h"
 
 namespace mir {
 namespace enc {
-
-typedef _Float16 __attribute__((ext_vector_type(8))) f16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-constexpr int H = 384;        // hidden
-constexpr int NH = 12;        // heads
-constexpr int HD = 32;        // head dim
-constexpr int FF = 1536;      // intermediate
-constexpr int NFB = H / 32;   // 12 feature blocks
-constexpr int KS_H = H / 16;  // 24 k-steps over the hidden dim
-constexpr int NHT = FF / 32;  // 48 intermediate tiles
-constexpr float LN_EPS = 1e-12f;
-
-// feature (row) index inside a 32-row accumulator tile for register r of lane-half h
-__device__ __forceinline__ int fi(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-__device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    const _Float16 x = (_Float16)a, y = (_Float16)b;
-    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
-}
-// registers 8*s2 .. 8*s2+7 of an accumulator -> one float16 fragment
-__device__ __forceinline__ uint4 acc_to_frag(const f32x16 &a, int s2) {
-    const int o = 8 * s2;
-    return make_uint4(pack2(a[o + 0], a[o + 1]), pack2(a[o + 2], a[o + 3]), pack2(a[o + 4], a[o + 5]),
-                      pack2(a[o + 6], a[o + 7]));
-}
-__device__ __forceinline__ void frag_to_floats(uint4 f, float (&out)[8]) {
-    const uint32_t w[4] = {f.x, f.y, f.z, f.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        out[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] & 0xffffu));
-        out[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] >> 16));
-    }
-}
-
-__device__ __forceinline__ float half_sum(float x) { return x + __shfl_xor(x, 32, 64); }
-__device__ __forceinline__ float half_max(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
-
-// exact-erf GELU (HF "gelu"), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
-__device__ __forceinline__ float gelu(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float e = 1.0f - p * __expf(-z * z);
-    const float erf_v = x < 0.f ? -e : e;
-    return 0.5f * x * (1.0f + erf_v);
-}
-
-// Per-tile bookkeeping: which sequence a 32-token tile belongs to.
-struct TileInfo {
-    int seq_first_tile;  // first tile of the tile's sequence
-    int seq_tiles;       // tiles of that sequence
-    int seq_len;         // real tokens of that sequence
-    int seq_index;
-};
-
-// y[12] (+bias) + residual -> LayerNorm -> ACT store.  `y` rows are features.
-// Register r of lane-half h is feature (r&3) + 8*(r>>2) + 4*h of its 32-feature block: the four
-// registers of a group g = r>>2 are four CONSECUTIVE features, so bias / gamma / beta are read as
-// float4 (a quarter of the loads of the per-register form, which made this epilogue ~3000
-// instructions and longer than the output projection's MFMAs).
-__device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 *__restrict__ resid_tile,
-                                                  const float *__restrict__ bias, const float *__restrict__ gamma,
-                                                  const float *__restrict__ beta, uint4 *__restrict__ out_tile,
-                                                  int lane, bool store) {
-    const int h = lane >> 5;
-    float sum = 0.f;
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            float rv[8];
-            frag_to_floats(resid_tile[(fb * 2 + s2) * 64 + lane], rv);
-#pragma unroll
-            for (int gq = 0; gq < 2; ++gq) {
-                const int g = 2 * s2 + gq;
-                const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * fb + 8 * g + 4 * h);
-                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * g + i;
-                    const float v = y[fb][r] + bb[i] + rv[4 * gq + i];
-                    y[fb][r] = v;
-                    sum += v;
-                }
-            }
-        }
-    }
-    const float mean = half_sum(sum) * (1.0f / H);
-    float sq = 0.f;
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float dlt = y[fb][r] - mean;
-            y[fb][r] = dlt;
-            sq = fmaf(dlt, dlt, sq);
-        }
-    const float rstd = rsqrtf(half_sum(sq) * (1.0f / H) + LN_EPS);
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) {
-        float o[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 g4 = *reinterpret_cast<const float4 *>(gamma + 32 * fb + 8 * g + 4 * h);
-            const float4 e4 = *reinterpret_cast<const float4 *>(beta + 32 * fb + 8 * g + 4 * h);
-            const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[4 * g + i] = fmaf(y[fb][4 * g + i] * rstd, gg[i], ee[i]);
-        }
-        if (store) {
-            out_tile[(fb * 2 + 0) * 64 + lane] =
-                make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
-            out_tile[(fb * 2 + 1) * 64 + lane] =
-                make_uint4(pack2(o[8], o[9]), pack2(o[10], o[11]), pack2(o[12], o[13]), pack2(o[14], o[15]));
-        }
-    }
-}
 
 // ---------------------------------------------------------------- E1: embeddings + LN
 // one wave per token tile; block = 256 (4 tiles)
@@ -301,79 +146,14 @@ __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ a
 }
 
 // ---------------------------------------------------------------- E3a: attention
-// One wave per (head, query tile): light on registers, so several waves share a SIMD and
-// the softmax's VALU work overlaps other waves' MFMAs (at hd = 32 a 32x32 score tile is 4
-// MFMAs against ~100 VALU instructions: a one-wave-per-SIMD kernel is VALU-bound 4:1).
-// S^T = K Q^T keeps keys on rows, so the softmax statistics of a query are lane-local plus
-// one cross-half shuffle; P^T (converted in registers) is the B operand of O^T += V^T P^T.
-// Output: the context in ACT layout (feature block = head), read by the projection kernel.
-__global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict__ qf, const uint4 *__restrict__ kf,
-                                                        const uint4 *__restrict__ vf,
-                                                        const TileInfo *__restrict__ ti, int n_tiles,
-                                                        uint4 *__restrict__ ctx) {
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= n_tiles * NH) return;
-    const int head = w / n_tiles, tt = w - head * n_tiles;   // neighbours share a sequence's K/V of one head
-    const TileInfo info = ti[tt];
-    const float scale_log2e = 0.17677669529663688f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e)
-    const uint4 *qp = qf + ((size_t)(tt * NH + head) * 2) * 64 + lane;
-    const uint4 q0 = qp[0], q1 = qp[64];
-    f32x16 o = {0};
-    float m = -__builtin_inff(), l = 0.f;
-    for (int kt = 0; kt < info.seq_tiles; ++kt) {
-        const size_t kb = ((size_t)((info.seq_first_tile + kt) * NH + head) * 2) * 64 + lane;
-        const uint4 k0 = kf[kb], k1 = kf[kb + 64];
-        const uint4 v0 = vf[kb], v1 = vf[kb + 64];
-        f32x16 s = {0};
-        s = mfma(k0, q0, s);
-        s = mfma(k1, q1, s);
-        float mx = -__builtin_inff();
-        if (kt == info.seq_tiles - 1) {  // only the sequence's last key tile can hold padding
-            const int key0 = 32 * kt;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = (key0 + fi(r, h) < info.seq_len) ? s[r] * scale_log2e : -__builtin_inff();
-                mx = fmaxf(mx, s[r]);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] *= scale_log2e;
-                mx = fmaxf(mx, s[r]);
-            }
-        }
-        mx = half_max(mx);
-        const float m_new = fmaxf(m, mx);
-        // v_exp_f32 directly: exp2f() wraps it in a compare / select / ldexp to keep results below
-        // 2^-126 exact, ~4 extra instructions per value in a VALU-bound loop; a softmax term that small
-        // is zero next to the row's maximum term 1.0 either way
-        float ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
-            ps += s[r];
-        }
-        ps = half_sum(ps);
-        if (__any(m_new > m)) {  // some query's running maximum moved: rescale (wave-uniform branch)
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);  // exp2(-inf) = 0 on the first tile
-            l = fmaf(l, alpha, ps);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] *= alpha;
-        } else {
-            l += ps;
-        }
-        m = m_new;
-        o = mfma(v0, acc_to_frag(s, 0), o);
-        o = mfma(v1, acc_to_frag(s, 1), o);
-    }
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= inv;
-    uint4 *out = ctx + (size_t)tt * (NFB * 2 * 64) + (size_t)(head * 2) * 64 + lane;
-    out[0] = acc_to_frag(o, 0);
-    out[64] = acc_to_frag(o, 1);
-}
+// attention_kernel lives in encoder_attention.hip: a translation unit of its own, built with
+// -mllvm -amdgpu-mfma-vgpr-form=1 so that its MFMA results land in VGPRs.  It is VALU-bound and
+// touches every accumulator register with VALU instructions; with accumulators in AGPRs (hipcc's
+// default) that cost a v_accvgpr_read/write per touch, ~130 of its ~700 instructions.  The same
+// option makes oproj_ln_kernel spill (192 accumulators + 96 activations need the AGPR half), hence
+// the separate file.
+int32_t launch_attention(const uint4 *qf, const uint4 *kf, const uint4 *vf, const TileInfo *ti, int n_tiles,
+                         uint4 *ctx, hipStream_t stream);
 
 // ---------------------------------------------------------------- E3b: output projection + residual + LN
 // One wave per token tile: the context's 24 fragments stay in registers as the B operand, the
