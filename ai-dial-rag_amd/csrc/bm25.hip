@@ -16,12 +16,18 @@
 //                                  posting whose document falls in tile >= j
 //   idf    f64[V]
 // Scoring never materialises the dense float64[N] score vector the reference
-// builds per query.  A workgroup owns one tile of 8192 consecutive documents
-// for one query: it accumulates the tile's scores in LDS, one query term after
-// the other in query order (deterministic rounding, a document occurs at most
-// once per term so no atomics), then selects the tile's top-k from LDS.  HBM
-// traffic per query is the postings of its terms (12 B each), read once,
-// coalesced.  A second small kernel merges the tiles' candidates.
+// builds per query.  A workgroup owns one tile of 8192 consecutive documents:
+// it accumulates the tile's scores in LDS, one query term after the other in
+// query order (deterministic rounding, a document occurs at most once per term
+// so no atomics on scores), then selects the tile's top-k from LDS.  HBM traffic
+// per query is the postings of its terms (12 B each), read once, coalesced.
+// Three kernels:
+//   bm25_sparse_kernel  the fast pass: several queries per workgroup, software-
+//                       pipelined; ranks only the positive touched documents
+//   bm25_tile_kernel    the exact dense pass (all 8192 documents of a tile, zeros
+//                       and negatives included) for the queries bm25_merge_kernel
+//                       found short of k positive documents; also get_scores
+//   bm25_merge_kernel   merges the tiles' candidates, flags the short queries
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -232,11 +238,9 @@ struct Bm25Dev {
 // lanes at once, then every thread fetches its share of ALL those terms' postings in one go
 // (registers), and only the LDS adds are serialised term by term - the order rank-bm25 adds in.
 //
-// SPARSE = true: the tile's top-k is selected only among the documents its postings touched and
-// only among positive scores (every untouched document scores exactly 0).  That is the whole answer
-// whenever the query has at least k positive documents - the common case; otherwise the caller
-// re-runs the query through the dense variant (`need_dense`), which ranks all documents of the tile,
-// zeros and negatives included, exactly as `argsort(stable)[::-1]` does.
+// This is the DENSE pass: it ranks all documents of the tile, zeros and negatives included, exactly
+// as `argsort(stable)[::-1]` does.  With `need_dense` it is the fallback behind bm25_sparse_kernel
+// (workgroups of queries whose word is 0 return at once); with `out_scores` it is get_scores.
 constexpr int kBm25Chunk = 64;     // query terms resolved per metadata round
 constexpr int kBm25Regs = 4;       // postings a thread holds per accumulate round (256*4 per round)
 constexpr int kBm25Cand = 1024;    // distinct touched documents listed per tile (sparse pass)
