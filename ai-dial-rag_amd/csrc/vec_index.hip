@@ -133,7 +133,7 @@ static void free_index(mir_index *ix) {
 static int32_t build_derived(mir_index *ix, hipStream_t stream) {
     const int64_t n = ix->n;
     const int d = ix->d;
-    ix->ksteps = ix->native16 ? d / 16 : pad_ksteps(d);
+    ix->ksteps = ix->native16 ? (d + 511) / 512 * 32 : pad_ksteps(d);  // native16: whole 32-k-step stages
     ix->n_tiles = (uint32_t)((n + kTileRows - 1) / kTileRows);
     const size_t split_bytes = (size_t)ix->n_tiles * ix->ksteps * (ix->native16 ? 1024 : 2048);
     const size_t aux_bytes = (size_t)ix->n_tiles * kTileRows * sizeof(float);
@@ -387,9 +387,7 @@ static int32_t launch_scan_f16(const mir_index *ix, const uint4 *qfrag_g, const 
         break;                                                                                               \
     }
     switch (ix->ksteps) {
-        MIR_SCAN_CASE(64)
-        MIR_SCAN_CASE(96)
-        MIR_SCAN_CASE(128)
+        MIR_SCAN_CASE(64)  // 96 / 128 k-steps would need 192 / 256 VGPRs of query fragments per wave: they spill
         default:
             set_error("internal: float16 scan has no instance for %d k-steps", ix->ksteps);
             return MIR_ERR_UNSUPPORTED;
@@ -580,9 +578,10 @@ static int32_t create_common(const void *emb, bool emb_on_device, int64_t n, int
         }                                                                                          \
     } while (0)
     const size_t orig_bytes = (size_t)n * d * sizeof(float);
-    // float16 rows with d a multiple of 512 (>= 1024): kept as they are and scanned as 2-byte
-    // fragments (vec_kernels_f16.h); everything else goes through the float32 / bf16-split layout
-    ix->native16 = dtype == MIR_DTYPE_F16 && d >= 1024 && d % 512 == 0 && d <= 2048;
+    // float16 rows with 512 < d <= 1024: kept as they are and scanned as 2-byte fragments, columns
+    // zero-padded to 1024 (vec_kernels_f16.h); everything else goes through the float32 / bf16-split
+    // layout
+    ix->native16 = dtype == MIR_DTYPE_F16 && d > 512 && d <= 1024;
     if (ix->native16) {
         MIR_TRY(hipMalloc(reinterpret_cast<void **>(&ix->d_f16), std::max<size_t>(orig_bytes / 2, 16)));
         ix->hbm_bytes += orig_bytes / 2;

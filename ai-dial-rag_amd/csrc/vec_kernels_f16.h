@@ -1,7 +1,8 @@
 // Device code of the float16-NATIVE vector index (BASELINE config C5: multimodal vectors,
 // d = 1024, float16 storage; `multimodal_retriever.py:96-153` passes `metric=index_config.metric`).
 //
-// A float16 index whose d is a multiple of 512 keeps the rows as they are (2 B per element) in
+// A float16 index with 512 < d <= 1024 keeps the rows as they are (2 B per element; the fragment copy is
+// zero-padded to 1024 columns) in
 // fragment-major order and scans them with ONE pass of 2-byte data and TWO f16 MFMAs per k-step:
 //     dot(d, q) ~= d . q_hi + d . q_lo,   q_hi = f16(s q), q_lo = f16(s q - q_hi),
 // s a per-query power of two that puts max |q_i| near 2^7, so both parts are normal float16
@@ -20,7 +21,8 @@ namespace mir {
 
 typedef _Float16 __attribute__((ext_vector_type(8))) f16x8;
 
-// f16 [n][d] row-major -> fragment-major.  One thread per (tile, k-step, lane).  d % 16 == 0.
+// f16 [n][d] row-major -> fragment-major.  One thread per (tile, k-step, lane).  ksteps*16 >= d;
+// columns past d and rows past n are 0.
 __global__ __launch_bounds__(256) void pack_f16_kernel(const _Float16 *__restrict__ src, int64_t n, int d, int ksteps,
                                                        int64_t total_lanes, uint4 *__restrict__ dst) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -32,7 +34,15 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(const _Float16 *__restric
     const int64_t row = tile * kTileRows + (lane & 31);
     const int col0 = 16 * s + 8 * (lane >> 5);
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < n) v = *reinterpret_cast<const uint4 *>(src + row * (int64_t)d + col0);
+    if (row < n && col0 + 8 <= d && (d & 7) == 0) {
+        v = *reinterpret_cast<const uint4 *>(src + row * (int64_t)d + col0);
+    } else if (row < n) {
+        uint32_t hbits[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            hbits[j] = col0 + j < d ? (uint32_t)__builtin_bit_cast(uint16_t, src[row * (int64_t)d + col0 + j]) : 0u;
+        v = pack8(hbits);
+    }
     dst[blk * 64 + lane] = v;
 }
 

@@ -321,6 +321,26 @@ def test_float16_native_scan_shapes(amd, metric):
         dev.search(qs[:1], 29, metric)
 
 
+def test_float16_native_padded_dimension(amd):
+    """d = 840 is not a multiple of 512: the fragment copy is zero-padded to 1024 columns, norms and the
+    re-score use the true d."""
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(1408)
+    docs16 = rng.standard_normal((9000, 840)).astype(np.float16)
+    docs32 = docs16.astype(np.float32)
+    qs = rng.standard_normal((70, 840))
+    dev = amd.ei.DeviceIndex.from_host(docs16)
+    assert dev.hbm_bytes() < 2.4 * docs16.nbytes  # rows + fragments padded 840 -> 1024
+    for metric in ("sqeuclidean_dist", "cosine_sim", "inner_product"):
+        _, _, rows, dist, cnt, flags = dev.search(qs, 10, metric)
+        for i in range(0, 70, 7):
+            wrows, wdist = oi.find_flat(qs[i], docs32, metric, 10)
+            alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs32) if metric == "cosine_sim" else None
+            assert_same_ids(metric, rows[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} q={i}")
+            np.testing.assert_allclose(dist[i], wdist, rtol=1e-12, atol=1e-6)
+
+
 def test_float16_native_large_shard_sample_prepass(amd):
     """More than 32768 tiles: the threshold pre-pass runs on the float16 scan too."""
     from oracle import embeddings_index as oi
