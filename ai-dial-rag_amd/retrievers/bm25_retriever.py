@@ -73,6 +73,20 @@ class DeviceBM25:
                                           nat.ptr(sc), nat.ptr(cnt)))
         return idx, sc, cnt
 
+    def workspace_bytes(self, b: int, k: int) -> int:
+        """HBM scratch `search_device` needs for a batch of b queries."""
+        n = int(nat.lib.mir_bm25_workspace_bytes(self._h, b, k))
+        if n < 0:
+            raise ValueError("bad batch shape")
+        return n
+
+    def search_device(self, q_terms_ptr: int, q_ptr_ptr: int, b: int, k: int, out_idx_ptr: int, out_score_ptr: int,
+                      out_count_ptr: int, workspace_ptr: int, stream: int = 0) -> None:
+        """`search` with every buffer in HBM (int32 term ids + int32 q_ptr[b+1] in, int64 idx[b,k] / float64
+        score[b,k] / int32 count[b] out), asynchronous on `stream`."""
+        nat.check(nat.lib.mir_bm25_search_device(self._h, q_terms_ptr or None, q_ptr_ptr, b, k, out_idx_ptr, out_score_ptr,
+                                                 out_count_ptr, workspace_ptr, stream or None))
+
     @property
     def handle(self):
         return self._h

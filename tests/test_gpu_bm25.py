@@ -172,6 +172,33 @@ def test_frequent_terms_large_batch(br, batch):
         np.testing.assert_array_equal(sc[i], want[top])
 
 
+def test_device_buffer_api_matches_host_api(br):
+    """mir_bm25_search_device: queries, results and scratch in HBM, asynchronous on the caller's stream."""
+    import torch
+
+    indptr, toks = synth(30000, 4000, 31)
+    dev = br.DeviceBM25.from_token_ids(indptr, toks, 4000)
+    qs = queries(4000, 50, 32)
+    want_idx, want_sc, want_cnt = dev.search(qs, 10)
+    ptr = np.zeros(len(qs) + 1, np.int32)
+    ptr[1:] = np.cumsum([len(q) for q in qs])
+    flat = np.concatenate([np.asarray(q, np.int32) for q in qs])
+    d_terms = torch.from_numpy(flat).cuda()
+    d_ptr = torch.from_numpy(ptr).cuda()
+    o_idx = torch.zeros((len(qs), 10), dtype=torch.int64, device="cuda")
+    o_sc = torch.zeros((len(qs), 10), dtype=torch.float64, device="cuda")
+    o_cnt = torch.zeros(len(qs), dtype=torch.int32, device="cuda")
+    ws = torch.empty(dev.workspace_bytes(len(qs), 10), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):  # the scratch is reusable
+        dev.search_device(d_terms.data_ptr(), d_ptr.data_ptr(), len(qs), 10, o_idx.data_ptr(), o_sc.data_ptr(),
+                          o_cnt.data_ptr(), ws.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(o_idx.cpu().numpy(), want_idx)
+    np.testing.assert_array_equal(o_sc.cpu().numpy(), want_sc)
+    np.testing.assert_array_equal(o_cnt.cpu().numpy(), want_cnt)
+
+
 def test_dict_loop_oracle_agrees_on_token_ids(br):
     indptr, toks = synth(400, 200, 5, mean_len=30)
     corpus = [toks[indptr[i] : indptr[i + 1]].tolist() for i in range(400)]
