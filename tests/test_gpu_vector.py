@@ -321,6 +321,26 @@ def test_float16_native_scan_shapes(amd, metric):
         dev.search(qs[:1], 29, metric)
 
 
+@pytest.mark.parametrize("metric", METRICS)
+def test_float16_native_vs_reference_golden(amd, golden_dir, metric):
+    """The d = 1024 fp16-rounded set of metrics_random.npz (outputs recorded from the imported reference
+    module): built as a float16-NATIVE index, full-vector metric and top-k against the reference's values."""
+    z = np.load(os.path.join(golden_dir, "metrics_random.npz"))
+    docs32, qs = z["docs1024"], z["q1024"].astype(np.float64)
+    docs16 = docs32.astype(np.float16)
+    assert np.array_equal(docs16.astype(np.float32), docs32)  # the fixture IS fp16-representable
+    dev = amd.ei.DeviceIndex.from_host(docs16)
+    _, _, rows, dist, cnt, _ = dev.search(qs, 10, metric)
+    for i in range(len(qs)):
+        ref = z[f"{metric}_1024_f64"][i]
+        got = dev.metric_eval(qs[i], metric)
+        atol = 1.5e-7 if metric == "cosine_sim" else 1e-8
+        np.testing.assert_allclose(got, ref, rtol=0, atol=atol)
+        want = np.argsort(ref, kind="stable")[:10]
+        assert_same_ids(metric, rows[i], want, lambda r: ref[r], f"{metric} q={i}")
+        np.testing.assert_allclose(dist[i], ref[want], rtol=0, atol=atol)
+
+
 def test_float16_native_padded_dimension(amd):
     """d = 840 is not a multiple of 512: the fragment copy is zero-padded to 1024 columns, norms and the
     re-score use the true d."""
