@@ -460,3 +460,58 @@ def test_merge_device_matches_host(amd):
         for q in range(b):
             np.testing.assert_array_equal(orow.cpu().numpy()[q, : hc[q]], hr[q, : hc[q]])
             np.testing.assert_array_equal(od.cpu().numpy()[q, : hc[q]], hd[q, : hc[q]])
+
+
+# ---------------------------------------------------------------- full size (BASELINE config C4 on one GPU)
+
+def test_full_size_10m_properties(amd):
+    """10M x 384 float32 - the size the headline metric is quoted on - checked through properties that
+    do not need the CPU oracle to scan 15 GB: planted copies of the queries are found first at distance 0;
+    returned distances are ascending and equal the float64 formula on the returned rows; the ids equal a
+    float32 torch top-k of the whole matrix (gaps at this size are ~1e-4, far above float32 noise); and the
+    result is identical to searching two 5M-row shards and merging them with the library's merge."""
+    torch = pytest.importorskip("torch")
+    n, d, k = 10_000_000, 384, 10
+    dev0 = torch.device("cuda", 0)
+    emb = torch.empty((n, d), dtype=torch.float32, device=dev0)
+    g = torch.Generator(device=dev0)
+    for c in range(0, n, 500_000):
+        g.manual_seed(99 + c)
+        x = torch.randn((500_000, d), generator=g, dtype=torch.float32, device=dev0)
+        emb[c : c + 500_000] = x / x.norm(dim=1, keepdim=True)
+    rng = np.random.default_rng(5)
+    q32 = unit(rng.standard_normal((100, d))).astype(np.float32)
+    planted = [123, 4_999_999, 5_000_000, 9_999_999]
+    for j, r in enumerate(planted):
+        emb[r] = torch.from_numpy(q32[j]).to(dev0)
+    torch.cuda.synchronize()
+    qs = q32.astype(np.float64)
+    full = amd.ei.DeviceIndex.from_device_ptr(emb.data_ptr(), n, d, 0)
+    _, _, rows, dist, cnt, flags = full.search(qs, k, "sqeuclidean_dist")
+    assert (cnt == k).all() and (flags == 0).all()
+    assert (np.diff(dist, axis=1) >= 0).all()
+    for j, r in enumerate(planted):
+        assert rows[j, 0] == r and abs(dist[j, 0]) < 1e-6
+    # float64 formula on the returned rows (doc_sq in float32, numpy order, as the reference computes it)
+    for i in (0, 17, 99):
+        got = emb[torch.from_numpy(rows[i]).to(dev0)].cpu().numpy()
+        want = np.sum(got**2, axis=1).astype(np.float64) - 2.0 * (got.astype(np.float64) @ qs[i]) + float(qs[i] @ qs[i])
+        np.testing.assert_allclose(dist[i], want, rtol=0, atol=1e-12)
+    # ids against a float32 top-k of the whole matrix
+    for i in (5, 50, 98):
+        sc = emb @ torch.from_numpy(q32[i]).to(dev0)
+        top = torch.topk(sc, k).indices.cpu().numpy()
+        assert set(top.tolist()) == set(rows[i].tolist())
+    # two shards + the library merge == the full index
+    half = n // 2
+    lo = amd.ei.DeviceIndex.from_device_ptr(emb.data_ptr(), half, d, 0, row_offset=0)
+    hi = amd.ei.DeviceIndex.from_device_ptr(emb.data_ptr() + half * d * 4, n - half, d, 0, row_offset=half)
+    parts = [ix.search(qs, k, "sqeuclidean_dist") for ix in (lo, hi)]
+    pd = np.ascontiguousarray(np.stack([p[3] for p in parts]))
+    pr = np.ascontiguousarray(np.stack([p[2] for p in parts]))
+    pc = np.ascontiguousarray(np.stack([p[4] for p in parts]))
+    od, orow, oc = np.zeros((100, k)), np.zeros((100, k), np.int64), np.zeros(100, np.int32)
+    amd.nat.check(amd.nat.lib.mir_topk_merge_host(amd.nat.ptr(pd), amd.nat.ptr(pr), amd.nat.ptr(pc), 2, 0, 100, k, 0,
+                                                  amd.nat.ptr(od), amd.nat.ptr(orow), amd.nat.ptr(oc)))
+    np.testing.assert_array_equal(orow, rows)
+    np.testing.assert_array_equal(od, dist)
