@@ -231,3 +231,24 @@ def test_sharded_stats_override(br):
     nat.check(nat.lib.mir_topk_merge_host(nat.ptr(dist), nat.ptr(rows), nat.ptr(cnts), 2, 0, len(qs), 10, 1, nat.ptr(od), nat.ptr(orow), nat.ptr(oc)))
     np.testing.assert_array_equal(orow, fi)
     np.testing.assert_array_equal(od, fs)
+
+
+def test_full_size_1m_documents_50k_vocabulary(br):
+    """BASELINE config C3 at full size (1M chunks, 50k-term vocabulary, SURVEY 8(d) corpus and query mix):
+    float64 scores and top-10 bit-identical to the CSR restatement for a 64-query batch."""
+    n, vocab = 1_000_000, 50_000
+    rng = np.random.default_rng(777)
+    lens = np.clip(np.round(rng.normal(150, 40, n)), 1, 400).astype(np.int64)
+    lens[rng.random(n) < 0.001] = 0
+    indptr = np.concatenate(([0], np.cumsum(lens)))
+    toks = np.minimum(rng.zipf(1.07, int(lens.sum())) - 1, vocab - 1).astype(np.int32)
+    dev = br.DeviceBM25.from_token_ids(indptr, toks, vocab)
+    o = ob.BM25OkapiCSR(indptr, toks, vocab)
+    assert dev.info()["avgdl"] == o.avgdl and dev.info()["average_idf"] == o.average_idf
+    qs = queries(vocab, 64, 778)
+    idx, sc, cnt = dev.search(qs, 10)
+    for i, q in enumerate(qs):
+        want = o.get_scores(q)
+        top = ob.top_n_indexes(want, 10)
+        np.testing.assert_array_equal(idx[i], top, err_msg=f"query {i} {q}")
+        np.testing.assert_array_equal(sc[i], want[top])
