@@ -515,3 +515,50 @@ def test_full_size_10m_properties(amd):
                                                   amd.nat.ptr(od), amd.nat.ptr(orow), amd.nat.ptr(oc)))
     np.testing.assert_array_equal(orow, rows)
     np.testing.assert_array_equal(od, dist)
+
+
+def test_full_size_c5_float16_properties(amd):
+    """One GPU's share of BASELINE config C5: 6.25M x 1024 float16, not normalised, cosine.  Same properties
+    as the float32 full-size test; the float32 torch reference works on the widened float16 values."""
+    torch = pytest.importorskip("torch")
+    n, d, k = 6_250_000, 1024, 10
+    dev0 = torch.device("cuda", 0)
+    emb = torch.empty((n, d), dtype=torch.float16, device=dev0)
+    g = torch.Generator(device=dev0)
+    for c in range(0, n, 250_000):
+        g.manual_seed(2024 + c)
+        emb[c : c + 250_000] = torch.randn((250_000, d), generator=g, dtype=torch.float32, device=dev0).half()
+    rng = np.random.default_rng(6)
+    qs = rng.standard_normal((70, d))
+    planted = [7, 3_124_999, 3_125_000, 6_249_999]
+    for j, r in enumerate(planted):
+        emb[r] = torch.from_numpy(qs[j].astype(np.float16)).to(dev0)
+        qs[j] = qs[j].astype(np.float16).astype(np.float64) * (j + 1)  # cosine ignores the query's length
+    torch.cuda.synchronize()
+    full = amd.ei.DeviceIndex.from_device_ptr(emb.data_ptr(), n, d, 0, float16=True)
+    assert full.hbm_bytes() < 2.1 * n * d * 2
+    _, _, rows, dist, cnt, flags = full.search(qs, k, "cosine_sim")
+    assert (cnt == k).all() and (flags == 0).all()
+    assert (np.diff(dist, axis=1) >= 0).all()
+    for j, r in enumerate(planted):
+        assert rows[j, 0] == r and abs(dist[j, 0] + 1.0) < 1e-6
+    for i in (10, 40, 69):
+        q = torch.from_numpy(qs[i].astype(np.float32)).to(dev0)
+        sc = torch.zeros(n, dtype=torch.float32, device=dev0)
+        for c in range(0, n, 1_250_000):
+            blk = emb[c : c + 1_250_000].float()
+            sc[c : c + 1_250_000] = (blk @ q) / blk.norm(dim=1)
+        top = torch.topk(sc, k).indices.cpu().numpy()
+        assert set(top.tolist()) == set(rows[i].tolist())
+    half = n // 2
+    lo = amd.ei.DeviceIndex.from_device_ptr(emb.data_ptr(), half, d, 0, row_offset=0, float16=True)
+    hi = amd.ei.DeviceIndex.from_device_ptr(emb.data_ptr() + half * d * 2, n - half, d, 0, row_offset=half, float16=True)
+    parts = [ix.search(qs, k, "cosine_sim") for ix in (lo, hi)]
+    pd = np.ascontiguousarray(np.stack([p[3] for p in parts]))
+    pr = np.ascontiguousarray(np.stack([p[2] for p in parts]))
+    pc = np.ascontiguousarray(np.stack([p[4] for p in parts]))
+    od, orow, oc = np.zeros((70, k)), np.zeros((70, k), np.int64), np.zeros(70, np.int32)
+    amd.nat.check(amd.nat.lib.mir_topk_merge_host(amd.nat.ptr(pd), amd.nat.ptr(pr), amd.nat.ptr(pc), 2, 0, 70, k, 0,
+                                                  amd.nat.ptr(od), amd.nat.ptr(orow), amd.nat.ptr(oc)))
+    np.testing.assert_array_equal(orow, rows)
+    np.testing.assert_array_equal(od, dist)
