@@ -432,6 +432,37 @@ def test_concurrent_searches_share_a_handle(amd):
             np.testing.assert_array_equal(r, want[2 * t : 2 * t + 2])
 
 
+def test_concurrent_find_calls_share_passes(amd):
+    """EmbeddingsIndex.find from many threads (the reference's executor threads, semantic_retriever.py:54-56):
+    answers equal the sequential ones, and the calls were served by fewer search passes than calls."""
+    import threading
+
+    rng = np.random.default_rng(12)
+    docs = unit(rng.standard_normal((200_000, 384)))
+    index = amd.ei.EmbeddingsIndex(
+        retrieval_type="text",
+        indexes=[amd.ei.DocIndex(chunk_ids=np.arange(100_000), embeddings=docs[:100_000]),
+                 amd.ei.DocIndex(chunk_ids=np.arange(100_000), embeddings=docs[100_000:])],
+        limit=7,
+    )
+    qs = unit(rng.standard_normal((64, 384))).astype(np.float64)
+    key = lambda found: [(d.metadata["doc_id"], d.metadata["chunk_id"]) for d in found]
+    want = [key(index.find(q)) for q in qs]
+    passes0, calls0 = index._commit.passes, index._commit.calls
+    got = [None] * 64
+
+    def work(t):
+        for i in range(t, 64, 16):
+            got[i] = key(index.find(qs[i]))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert got == want
+    assert index._commit.calls - calls0 == 64
+    assert index._commit.passes - passes0 < 64
+
+
 def test_merge_device_matches_host(amd):
     import ctypes as C
 
