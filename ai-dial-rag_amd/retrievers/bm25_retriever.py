@@ -14,12 +14,14 @@ launch); a single query is the B = 1 case of the same kernels.
 
 import asyncio
 import ctypes as C
+import threading
 from typing import Callable, Dict, Hashable, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from .. import _native as nat
 from ..index_record import Document, RetrievalType, to_metadata_doc
+from ._group_commit import _GroupCommit
 
 
 class DeviceBM25:
@@ -128,6 +130,10 @@ class BM25Retriever:
         self.bm25 = bm25
         self.vocab = vocab
         self._preprocess = preprocess
+        # concurrent single-query calls (bm25_retriever.py:102-104 runs them on executor threads) share passes;
+        # one pass serves up to 512 queries, grouped by the n they ask for
+        self._commits: Dict[int, _GroupCommit] = {}
+        self._commits_lock = threading.Lock()
 
     @staticmethod
     def _get_text_index_gen(doc_records) -> Iterable[Tuple[int, object]]:
@@ -166,8 +172,12 @@ class BM25Retriever:
 
     def _get_top_n_indexes(self, query: List[str], n: int = 5) -> np.ndarray:
         # bm25_retriever.py:81-84
-        idx, _, cnt = self.bm25.search([self._ids(query)], n)
-        return idx[0, : cnt[0]]
+        with self._commits_lock:
+            gc = self._commits.get(n)
+            if gc is None:
+                gc = self._commits[n] = _GroupCommit(lambda qs, n=n: self.bm25.search(qs, n), max_batch=512)
+        idx, _, cnt = gc.submit(self._ids(query))
+        return idx[: int(cnt)]
 
     def get_metadata_doc(self, index: int) -> Document:
         doc_index, chunk_index = self.text_indexes[index]

@@ -23,6 +23,7 @@ import numpy.typing as npt
 
 from .. import _native as nat
 from ..index_record import Document, RetrievalType, to_metadata_doc
+from ._group_commit import _GroupCommit
 from .embeddings_metrics import ENUM_TO_METRIC, Metric  # noqa: F401  (re-exported like upstream)
 
 
@@ -126,71 +127,6 @@ class DeviceIndex:
             pass
 
 
-class _GroupCommit:
-    """Coalesces concurrent single-query ``find`` calls into shared search passes.
-
-    The reference issues one-vector ``find`` calls from many executor threads
-    (semantic_retriever.py:54-56, cpu_pools.py:31-34); a pass over the index costs the same for 1 or 96
-    queries, so what turns kernel throughput into service QPS is batching at this boundary
-    (SURVEY 8(f), rank 4).  No timer and no dedicated thread: the first caller to find no pass in flight
-    becomes the leader and runs a pass for everything queued; callers that arrive while a pass is running
-    queue up and ride the next one.  A lone caller pays nothing extra.
-    """
-
-    def __init__(self, run_batch, max_batch: int = 96):
-        self._run = run_batch          # f64[b, d] -> tuple of arrays with leading dimension b
-        self._max = max_batch
-        self._cv = threading.Condition()
-        self._queue: list = []         # [query, holder]; holder = [done, result row or exception]
-        self._leader = False
-        self.passes = 0
-        self.calls = 0
-
-    def submit(self, query: np.ndarray):
-        holder = [False, None]
-        with self._cv:
-            self.calls += 1
-            self._queue.append((np.asarray(query, dtype=np.float64), holder))
-            if self._leader:
-                while not holder[0]:
-                    self._cv.wait()
-                return self._unwrap(holder)
-            self._leader = True
-        try:
-            while True:
-                with self._cv:
-                    batch, self._queue = self._queue[: self._max], self._queue[self._max :]
-                    if not batch:
-                        self._leader = False
-                        break
-                    self.passes += 1
-                try:
-                    out = self._run(np.stack([q for q, _ in batch]))
-                    rows = [tuple(a[i] for a in out) for i in range(len(batch))]
-                except Exception as e:  # every rider of this pass sees the failure
-                    rows = [e] * len(batch)
-                with self._cv:
-                    for (_, h), r in zip(batch, rows):
-                        h[1] = r
-                        h[0] = True
-                    self._cv.notify_all()
-        except BaseException:  # e.g. KeyboardInterrupt in the leader: nobody may wait forever
-            with self._cv:
-                self._leader = False
-                for _, h in self._queue:
-                    h[1], h[0] = RuntimeError("search pass aborted"), True
-                self._queue = []
-                self._cv.notify_all()
-            raise
-        return self._unwrap(holder)
-
-    @staticmethod
-    def _unwrap(holder):
-        if isinstance(holder[1], Exception):
-            raise holder[1]
-        return holder[1]
-
-
 class EmbeddingsIndex:
     """embeddings_index.py:33-89."""
 
@@ -208,7 +144,7 @@ class EmbeddingsIndex:
         self.device = device
         self._dev: Optional[DeviceIndex] = None
         self._lock = threading.Lock()
-        self._commit = _GroupCommit(self.search_arrays)
+        self._commit = _GroupCommit(lambda qs: self.search_arrays(np.stack(qs)))
 
     def _device_index(self) -> Optional[DeviceIndex]:
         """Flatten non-empty documents in order (embeddings_index.py:67-69) and upload once."""
@@ -250,7 +186,7 @@ class EmbeddingsIndex:
         """One query (embeddings_index.py:62-89).  Concurrent callers share search passes (`_GroupCommit`);
         the result of a query does not depend on what else rides in its pass."""
         Metric(self.metric)
-        doc, chunk, _dist, cnt, _flags = self._commit.submit(np.asarray(query))
+        doc, chunk, _dist, cnt, _flags = self._commit.submit(np.asarray(query, dtype=np.float64))
         return [to_metadata_doc(int(doc[j]), int(chunk[j]), retrieval_type=self.retrieval_type) for j in range(int(cnt))]
 
 

@@ -252,3 +252,29 @@ def test_full_size_1m_documents_50k_vocabulary(br):
         top = ob.top_n_indexes(want, 10)
         np.testing.assert_array_equal(idx[i], top, err_msg=f"query {i} {q}")
         np.testing.assert_array_equal(sc[i], want[top])
+
+
+def test_concurrent_retriever_calls_share_passes(br):
+    """BM25Retriever._get_relevant_documents from many threads: same answers as sequentially, fewer passes than calls."""
+    import threading
+
+    rng = np.random.default_rng(41)
+    words = [f"w{i}" for i in range(300)]
+    docs = [[words[j] for j in rng.integers(0, 300, rng.integers(5, 40))] for _ in range(20000)]
+    r = br.BM25Retriever.from_doc_records([Rec(docs[:12000]), Rec(docs[12000:])], k=5, preprocess=str.split)
+    qs = [" ".join(words[j] for j in rng.integers(0, 300, rng.integers(1, 5))) for _ in range(96)]
+    key = lambda found: [(d.metadata["doc_id"], d.metadata["chunk_id"]) for d in found]
+    want = [key(r._get_relevant_documents(q)) for q in qs]
+    gc = r._commits[5]
+    passes0 = gc.passes
+    got = [None] * 96
+
+    def work(t):
+        for i in range(t, 96, 16):
+            got[i] = key(r._get_relevant_documents(qs[i]))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert got == want
+    assert gc.passes - passes0 < 96

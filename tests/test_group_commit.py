@@ -6,11 +6,12 @@ import time
 
 import numpy as np
 
-from aidial_rag_amd.retrievers.embeddings_index import _GroupCommit
+from aidial_rag_amd.retrievers._group_commit import _GroupCommit
 
 
 def _fake_pass(log):
-    def run(q):
+    def run(items):
+        q = np.stack(items)
         log.append(len(q))
         time.sleep(0.01)  # a pass costs the same for 1 or 96 queries
         return (q[:, 0] * 2.0, np.arange(len(q)))
@@ -47,11 +48,11 @@ def test_concurrent_callers_share_passes_and_get_their_own_rows():
 def test_a_failing_pass_reaches_every_rider_and_the_queue_recovers():
     calls = []
 
-    def run(q):
-        calls.append(len(q))
+    def run(items):
+        calls.append(len(items))
         if len(calls) == 1:
             raise ValueError("boom")
-        return (q[:, 0],)
+        return (np.stack(items)[:, 0],)
 
     gc = _GroupCommit(run)
     try:
