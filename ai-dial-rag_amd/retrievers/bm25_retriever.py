@@ -151,20 +151,29 @@ class BM25Retriever:
     @classmethod
     def from_doc_records(cls, doc_records, k: int = 4, device: int = 0,
                          preprocess: Optional[Callable[[str], List[str]]] = None) -> "BM25Retriever":
-        # bm25_retriever.py:64-79
-        text_indexes, lens, flat = [], [], []
-        vocab: Dict[Hashable, int] = {}
-        for i, item in cls._get_text_index_gen(doc_records):
-            text_indexes.append((i, item.chunk_index))
-            toks = item.tokenized_text
-            lens.append(len(toks))
-            for t in toks:
-                flat.append(vocab.setdefault(t, len(vocab)))
-        if sum(lens) == 0:
-            raise ValueError("Text index is empty.")
-        indptr = np.zeros(len(lens) + 1, np.int64)
-        indptr[1:] = np.cumsum(lens)
-        bm25 = DeviceBM25.from_token_ids(indptr, np.asarray(flat, np.int32), max(1, len(vocab)), device=device)
+        # bm25_retriever.py:64-79.  The model (postings in HBM, vocabulary, flat index -> (doc, chunk) table) is
+        # shared across requests that hand over the same text_index objects (retrievers/_device_cache.py);
+        # the reference rebuilds BM25Okapi from scratch in every request.
+        def build():
+            text_indexes, lens, flat = [], [], []
+            vocab: Dict[Hashable, int] = {}
+            for i, item in cls._get_text_index_gen(doc_records):
+                text_indexes.append((i, item.chunk_index))
+                toks = item.tokenized_text
+                lens.append(len(toks))
+                for t in toks:
+                    flat.append(vocab.setdefault(t, len(vocab)))
+            if sum(lens) == 0:
+                raise ValueError("Text index is empty.")
+            indptr = np.zeros(len(lens) + 1, np.int64)
+            indptr[1:] = np.cumsum(lens)
+            bm25 = DeviceBM25.from_token_ids(indptr, np.asarray(flat, np.int32), max(1, len(vocab)), device=device)
+            return (text_indexes, bm25, vocab), bm25.info()["hbm_bytes"]
+
+        from ._device_cache import CACHE
+
+        sources = [doc.text_index for doc in doc_records]  # None entries included: they shape the doc numbering
+        text_indexes, bm25, vocab = CACHE.get_or_build("bm25", device, sources, build)
         return cls(text_indexes=text_indexes, k=k, bm25=bm25, vocab=vocab, preprocess=preprocess)
 
     def _ids(self, tokens: Sequence[Hashable]) -> List[int]:

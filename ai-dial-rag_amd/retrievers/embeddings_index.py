@@ -135,32 +135,54 @@ class EmbeddingsIndex:
     metric: str
     limit: int
 
-    def __init__(self, retrieval_type: RetrievalType, indexes: List[DocIndex], metric: Metric = Metric.SQEUCLIDEAN_DIST,
-                 limit: int = 1, device: int = 0):
+    def __init__(self, retrieval_type: RetrievalType, indexes, metric: Metric = Metric.SQEUCLIDEAN_DIST,
+                 limit: int = 1, device: int = 0, cache_sources: Optional[Sequence[object]] = None):
+        """`indexes`: List[DocIndex] as in the reference, or a zero-argument callable that returns it (built
+        only when the rows are actually needed).  `cache_sources`: the objects the rows come from, one per
+        document; when given, the device index is shared across requests through retrievers/_device_cache.py
+        instead of being flattened and uploaded again."""
         self.retrieval_type = retrieval_type
         self.metric = metric
         self.limit = limit
-        self.doc_indexes = indexes
+        self._indexes = indexes
         self.device = device
         self._dev: Optional[DeviceIndex] = None
+        self._built = False
         self._lock = threading.Lock()
+        self._cache_sources = tuple(cache_sources) if cache_sources is not None else None
         self._commit = _GroupCommit(lambda qs: self.search_arrays(np.stack(qs)))
 
+    @property
+    def doc_indexes(self) -> List[DocIndex]:
+        if callable(self._indexes):
+            self._indexes = self._indexes()
+        return self._indexes
+
+    def _upload(self):
+        """Flatten non-empty documents in order (embeddings_index.py:67-69) -> (DeviceIndex or None, HBM bytes)."""
+        embs, chunk_ids, doc_ids = [], [], []
+        for i, doc in enumerate(self.doc_indexes):
+            if len(doc.embeddings) == 0:
+                continue
+            e = np.asarray(doc.embeddings, dtype=np.float32)
+            embs.append(e)
+            chunk_ids.append(np.asarray(doc.chunk_ids, dtype=np.int64))
+            doc_ids.append(np.full(len(e), i, dtype=np.int32))
+        if not embs:
+            return None, 0
+        dev = DeviceIndex.from_host(np.concatenate(embs), np.concatenate(chunk_ids), np.concatenate(doc_ids), self.device)
+        return dev, dev.hbm_bytes()
+
     def _device_index(self) -> Optional[DeviceIndex]:
-        """Flatten non-empty documents in order (embeddings_index.py:67-69) and upload once."""
         with self._lock:
-            if self._dev is None:
-                embs, chunk_ids, doc_ids = [], [], []
-                for i, doc in enumerate(self.doc_indexes):
-                    if len(doc.embeddings) == 0:
-                        continue
-                    e = np.asarray(doc.embeddings, dtype=np.float32)
-                    embs.append(e)
-                    chunk_ids.append(np.asarray(doc.chunk_ids, dtype=np.int64))
-                    doc_ids.append(np.full(len(e), i, dtype=np.int32))
-                if not embs:
-                    return None
-                self._dev = DeviceIndex.from_host(np.concatenate(embs), np.concatenate(chunk_ids), np.concatenate(doc_ids), self.device)
+            if not self._built:
+                if self._cache_sources is not None:
+                    from ._device_cache import CACHE
+
+                    self._dev = CACHE.get_or_build("vector", self.device, self._cache_sources, self._upload)
+                else:
+                    self._dev = self._upload()[0]
+                self._built = True
             return self._dev
 
     def search_arrays(self, queries: np.ndarray):

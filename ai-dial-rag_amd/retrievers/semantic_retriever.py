@@ -23,8 +23,12 @@ class SemanticRetriever:
     @classmethod
     def from_doc_records(cls, document_records, k: int = 1, encoder: Optional[emb.BgeEncoder] = None, device: int = 0) -> "SemanticRetriever":
         # semantic_retriever.py:26-41
-        indexes = [create_index_by_chunk(doc.embeddings_index) for doc in document_records if doc.embeddings_index]
-        return cls(index=EmbeddingsIndex(retrieval_type=RetrievalType.TEXT, indexes=indexes, limit=k, device=device), encoder=encoder)
+        sources = [doc.embeddings_index for doc in document_records if doc.embeddings_index]
+        # same source objects as an earlier request -> the index already in HBM (retrievers/_device_cache.py);
+        # the per-chunk flattening loop runs only on a miss
+        return cls(index=EmbeddingsIndex(retrieval_type=RetrievalType.TEXT,
+                                         indexes=lambda: [create_index_by_chunk(src) for src in sources], limit=k,
+                                         device=device, cache_sources=sources), encoder=encoder)
 
     def _find_relevant_documents(self, query_emb: np.ndarray) -> List[Document]:
         return self.index.find(query=query_emb)

@@ -117,3 +117,49 @@ def test_semantic_batch_equals_single(world):
     assert r.get_relevant_documents_batch(qs) == [r.invoke(q) for q in qs]
     docs = asyncio.run(r._aget_relevant_documents(qs[0]))
     assert docs == r.invoke(qs[0])
+
+
+def test_indexes_survive_across_requests():
+    """a second `from_doc_records` over the SAME record objects reuses the indexes already
+    in HBM (vector index and BM25 model); different records build new ones; results are unaffected."""
+    import numpy as np
+
+    from aidial_rag_amd.retrievers import _device_cache as dc
+    from aidial_rag_amd.retrievers.bm25_retriever import BM25Retriever
+    from aidial_rag_amd.retrievers.embeddings_index import ItemEmbeddings
+    from aidial_rag_amd.retrievers.semantic_retriever import SemanticRetriever
+
+    rng = np.random.default_rng(3)
+
+    class Item:
+        def __init__(self, i, toks):
+            self.chunk_index, self.tokenized_text = i, toks
+
+    class Rec:
+        def __init__(self, n):
+            v = rng.standard_normal((n, 384)).astype(np.float32)
+            self.embeddings_index = [ItemEmbeddings(v[i : i + 1]) for i in range(n)]
+            self.text_index = [Item(i, [f"w{j}" for j in rng.integers(0, 50, 8)]) for i in range(n)]
+
+    recs = [Rec(300), Rec(200)]
+    dc.CACHE.clear()
+    m0, h0 = dc.CACHE.misses, dc.CACHE.hits
+    q = rng.standard_normal(384)
+    s1 = SemanticRetriever.from_doc_records(recs, k=5)
+    r1 = s1._find_relevant_documents(q)
+    b1 = BM25Retriever.from_doc_records(recs, k=4, preprocess=str.split)
+    k1 = b1._get_relevant_documents("w1 w7 w9")
+    assert dc.CACHE.misses - m0 == 2 and dc.CACHE.hits - h0 == 0
+    s2 = SemanticRetriever.from_doc_records(recs, k=5)
+    b2 = BM25Retriever.from_doc_records(recs, k=4, preprocess=str.split)
+    assert s2._find_relevant_documents(q) == r1 and b2._get_relevant_documents("w1 w7 w9") == k1
+    assert dc.CACHE.hits - h0 == 2 and s2.index._device_index() is s1.index._device_index() and b2.bm25 is b1.bm25
+    other = [Rec(100)]
+    s3 = SemanticRetriever.from_doc_records(other, k=5)
+    assert s3.index._device_index() is not s1.index._device_index() and dc.CACHE.misses - m0 == 3
+    # a tiny budget keeps only the most recent entry; evicted indexes stay valid for whoever still holds them
+    small = dc.DeviceCache(budget_bytes=1)
+    a = small.get_or_build("x", 0, [recs[0]], lambda: ("A", 10))
+    b = small.get_or_build("x", 0, [recs[1]], lambda: ("B", 10))
+    assert (a, b) == ("A", "B") and len(small) == 1
+    assert s1._find_relevant_documents(q) == r1
