@@ -32,8 +32,13 @@ class MultimodalRetriever:
     def from_doc_records(cls, document_records, k: int = 1, metric: Metric = Metric.SQEUCLIDEAN_DIST,
                          embed_query: Optional[Callable[[str], List[float]]] = None, device: int = 0) -> "MultimodalRetriever":
         # multimodal_retriever.py:108-131: page embeddings expanded to the chunks of each page; metric from the index config
-        indexes = [create_index_by_page(doc.chunks, doc.multimodal_embeddings_index) for doc in document_records]
-        return cls(EmbeddingsIndex(retrieval_type=RetrievalType.IMAGE, indexes=indexes, metric=metric, limit=k, device=device), embed_query)
+        # (shared across requests over the same records: retrievers/_device_cache.py; the chunk list is part of
+        # the key because it decides how page rows are repeated)
+        docs = list(document_records)
+        return cls(EmbeddingsIndex(retrieval_type=RetrievalType.IMAGE,
+                                   indexes=lambda: [create_index_by_page(doc.chunks, doc.multimodal_embeddings_index) for doc in docs],
+                                   metric=metric, limit=k, device=device,
+                                   cache_sources=[x for doc in docs for x in (doc.chunks, doc.multimodal_embeddings_index)]), embed_query)
 
     def _find_relevant_documents(self, query_emb: np.ndarray) -> List[Document]:
         return self.index.find(query=query_emb)
@@ -58,8 +63,11 @@ class DescriptionRetriever:
     @classmethod
     def from_doc_records(cls, document_records, k: int = 4, encoder: Optional[emb.BgeEncoder] = None, device: int = 0) -> "DescriptionRetriever":
         # description_retriever.py:95-112
-        indexes = [create_index_by_page(doc.chunks, doc.description_embeddings_index) for doc in document_records]
-        return cls(EmbeddingsIndex(retrieval_type=RetrievalType.IMAGE, indexes=indexes, limit=k, device=device), encoder)
+        docs = list(document_records)
+        return cls(EmbeddingsIndex(retrieval_type=RetrievalType.IMAGE,
+                                   indexes=lambda: [create_index_by_page(doc.chunks, doc.description_embeddings_index) for doc in docs],
+                                   limit=k, device=device,
+                                   cache_sources=[x for doc in docs for x in (doc.chunks, doc.description_embeddings_index)]), encoder)
 
     def _find_relevant_documents(self, query_emb: np.ndarray) -> List[Document]:
         return self.index.find(query=query_emb)
