@@ -179,10 +179,9 @@ static int32_t check_create_args(int64_t n, int32_t d, int32_t dtype, mir_index 
     return MIR_OK;
 }
 
-// Sample pre-pass of the 128-query scan: kSampleWgs workgroups x kSampleTilesPerWg tiles (64K rows);
-// at most 1024 workgroups (merge_sorted_lists gives each of 256 threads up to 4 lists)
+// Threshold pre-pass of the wide scans: kSampleWgs workgroups x up to kSampleTilesPerWg tiles (32K rows)
 constexpr int kSampleWgs = 256;
-constexpr int kSampleTilesPerWg = 8;
+constexpr int kSampleTilesPerWg = 4;
 
 // carve helper
 struct Carver {
@@ -457,12 +456,16 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                 if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_b128<SCAN_COS>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
                 return launch_scan_b128<SCAN_L2>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
             };
-            // Large shard: scan a 64K-row sample first and seed every query's shared threshold with the
-            // sample's klist-th best key, so the full pass starts with tight thresholds instead of
-            // accepting almost everything for its first ~50 tiles per workgroup.
-            const uint32_t sample_tiles = (uint32_t)kSampleWgs * kSampleTilesPerWg;
+            // Scan a sample of the shard first and seed every query's threshold with a lower bound of its
+            // klist-th best value (sample_threshold_kernel), so the full pass starts with tight thresholds
+            // instead of accepting almost everything for its first ~50 tiles per workgroup.
+            // Measured: the pre-pass pays from ~32K rows up (500K rows: 0.48 -> 0.24 ms per step; 1M: 0.69 ->
+            // 0.39; 10M: see DESIGN.md), 4 tiles per workgroup being the best size from 100K to 10M rows; it
+            // must stay a small part of the shard, so smaller shards sample fewer tiles or skip it
+            const uint32_t tpw = std::min<uint32_t>(kSampleTilesPerWg, ix->n_tiles / (4u * kSampleWgs));
+            const uint32_t sample_tiles = (uint32_t)kSampleWgs * tpw;
             rc = MIR_OK;
-            if (ix->n_tiles >= 16 * sample_tiles) {
+            if (tpw >= 1) {
                 rc = run(kSampleWgs, sample_tiles, sb.part_sample, true);
                 if (rc == MIR_OK) {
                     sample_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(reinterpret_cast<const float *>(sb.part_sample),
