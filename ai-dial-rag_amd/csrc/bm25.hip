@@ -646,6 +646,8 @@ struct mir_bm25 {
     std::mutex mu;  // serialises use of the scratch below (searches on one handle run one at a time)
     void *scratch = nullptr;
     size_t scratch_cap = 0;
+    char *pin = nullptr;       // pinned host staging of mir_bm25_search: queries in, results out, one copy each
+    size_t pin_cap = 0;
     hipStream_t stream = nullptr;
 };
 
@@ -660,6 +662,7 @@ static void free_bm25(mir_bm25 *h) {
     (void)hipFree(h->t_tile);
     (void)hipFree(h->idf);
     (void)hipFree(h->scratch);
+    if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -935,16 +938,30 @@ int32_t mir_bm25_search(mir_bm25 *h, const int32_t *q_terms_host, const int32_t 
     if (rc != MIR_OK) return rc;
     char *base = static_cast<char *>(h->scratch);
     hipStream_t s = h->stream;
-    if (nt) MIR_HIP(hipMemcpyAsync(base + o_terms, q_terms_host, (size_t)nt * 4, hipMemcpyHostToDevice, s));
-    MIR_HIP(hipMemcpyAsync(base + o_ptr, q_ptr_host, (size_t)(b + 1) * 4, hipMemcpyHostToDevice, s));
+    // pinned staging: [terms | ptr] go in with one copy, [idx | score | count] come back with one
+    // (pageable buffers make every hipMemcpyAsync a synchronous staged copy of its own)
+    const size_t in_bytes = o_idx;                 // o_terms = 0 .. end of the q_ptr slot
+    const size_t out_bytes = o_part - o_idx;       // idx, score, count slots
+    if (h->pin_cap < in_bytes + out_bytes) {
+        if (h->pin) (void)hipHostFree(h->pin);
+        h->pin = nullptr;
+        h->pin_cap = 0;
+        MIR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin), in_bytes + out_bytes, hipHostMallocDefault));
+        h->pin_cap = in_bytes + out_bytes;
+    }
+    if (nt) std::memcpy(h->pin + o_terms, q_terms_host, (size_t)nt * 4);
+    std::memcpy(h->pin + o_ptr, q_ptr_host, (size_t)(b + 1) * 4);
+    MIR_HIP(hipMemcpyAsync(base, h->pin, in_bytes, hipMemcpyHostToDevice, s));
     rc = bm25_run(h, reinterpret_cast<int32_t *>(base + o_terms), reinterpret_cast<int32_t *>(base + o_ptr), b, k,
                   nullptr, reinterpret_cast<int64_t *>(base + o_idx), reinterpret_cast<double *>(base + o_sc),
                   reinterpret_cast<int32_t *>(base + o_cnt), base + o_part, s);
     if (rc != MIR_OK) { (void)hipStreamSynchronize(s); return rc; }
-    MIR_HIP(hipMemcpyAsync(out_idx, base + o_idx, (size_t)b * k * 8, hipMemcpyDeviceToHost, s));
-    MIR_HIP(hipMemcpyAsync(out_score, base + o_sc, (size_t)b * k * 8, hipMemcpyDeviceToHost, s));
-    MIR_HIP(hipMemcpyAsync(out_count, base + o_cnt, (size_t)b * 4, hipMemcpyDeviceToHost, s));
+    char *res = h->pin + in_bytes;
+    MIR_HIP(hipMemcpyAsync(res, base + o_idx, out_bytes, hipMemcpyDeviceToHost, s));
     MIR_HIP(hipStreamSynchronize(s));
+    std::memcpy(out_idx, res, (size_t)b * k * 8);
+    std::memcpy(out_score, res + (o_sc - o_idx), (size_t)b * k * 8);
+    std::memcpy(out_count, res + (o_cnt - o_idx), (size_t)b * 4);
     return MIR_OK;
 }
 
