@@ -519,7 +519,7 @@ static int32_t plan(const mir_index *ix, int b, int k, int *ngroups, int *nwg, i
         }
         *qpw = kF16Queries;
         *ngroups = (b + *qpw - 1) / *qpw;
-        const int64_t want16 = ((int64_t)ix->n_tiles + 3) / 4;
+        const int64_t want16 = (int64_t)ix->n_tiles;
         *nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want16));
         return MIR_OK;
     }
@@ -530,8 +530,10 @@ static int32_t plan(const mir_index *ix, int b, int k, int *ngroups, int *nwg, i
     const bool wide = (ix->ksteps == 8 || ix->ksteps == 16 || ix->ksteps == 24) && b128_lds_bytes(*klist) <= 160 * 1024;
     *qpw = wide ? 128 : 32;
     *ngroups = (b + *qpw - 1) / *qpw;
-    // one workgroup per CU; never more workgroups than there are 4-tile chunks of work
-    const int64_t want = ((int64_t)ix->n_tiles + 3) / 4;
+    // one workgroup per CU, or one per tile on shards smaller than that: a workgroup's fixed costs
+    // (ring start-up, filling empty lists) grow with the tiles it walks, and on a 1k-5k-row index one
+    // tile per workgroup takes a single search from 128 to 90 us
+    const int64_t want = (int64_t)ix->n_tiles;
     // (finalize's tournament gives each of its 256 threads up to 4 workgroup lists)
     *nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want));
     return MIR_OK;
