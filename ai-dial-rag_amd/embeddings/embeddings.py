@@ -23,6 +23,7 @@ come from the same environment variables as upstream
 import asyncio
 import ctypes as C
 import os
+import threading
 from typing import Callable, Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -53,6 +54,9 @@ def _np32(t) -> np.ndarray:
     if hasattr(t, "detach"):
         t = t.detach().cpu().float().numpy()
     return np.ascontiguousarray(t, dtype=np.float32)
+
+
+_QC_LOCK = threading.Lock()
 
 
 class BgeEncoder:
@@ -129,8 +133,22 @@ class BgeEncoder:
         return list(self.encode_ids(self._tokenize(texts)))
 
     def embed_query(self, text: str) -> List[float]:
+        """One query (embeddings.py:93-96).  Encoding 1 or 32 short queries costs the same ~2 ms pass, and the
+        reference calls this from concurrent requests: concurrent callers share passes (group commit)."""
         text = text.replace("\n", " ")  # HuggingFaceBgeEmbeddings.embed_query
-        return self.encode_ids(self._tokenize([BGE_QUERY_INSTRUCTION_EN + text]))[0].tolist()
+        ids = self._tokenize([BGE_QUERY_INSTRUCTION_EN + text])[0]
+        return self._query_commit().submit(ids)[0].tolist()
+
+    def _query_commit(self):
+        gc = getattr(self, "_qc", None)
+        if gc is None:
+            with _QC_LOCK:
+                gc = getattr(self, "_qc", None)
+                if gc is None:
+                    from ..retrievers._group_commit import _GroupCommit  # lazy: retrievers imports this module
+
+                    gc = self._qc = _GroupCommit(lambda seqs: (self.encode_ids(seqs),), max_batch=256)
+        return gc
 
     def close(self):
         if self._h:

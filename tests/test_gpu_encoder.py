@@ -78,3 +78,32 @@ def test_argument_errors(setup):
     with pytest.raises(ValueError):
         enc.encode_ids([[]])
     assert enc.encode_ids([]).shape == (0, 384)
+
+
+def test_concurrent_query_encodes_share_passes():
+    """embed_query from many threads: identical vectors to sequential calls, served by fewer encoder passes."""
+    import threading
+
+    from aidial_rag_amd.embeddings.embeddings import BgeEncoder
+    from oracle import encoder as oe
+
+    class Tok:  # stand-in tokenizer: the test is about batching, not WordPiece
+        def __call__(self, texts, **kw):
+            return {"input_ids": [[101] + [1000 + (ord(c) % 500) for c in t][:60] + [102] for t in texts]}
+
+    enc = BgeEncoder.from_state_dict(oe.make_model(layers=2, seed=1).state_dict(), tokenizer=Tok())
+    qs = [f"question number {i} about retrieval" for i in range(48)]
+    want = [enc.embed_query(q) for q in qs]
+    gc = enc._query_commit()
+    p0 = gc.passes
+    got = [None] * 48
+
+    def work(t):
+        for i in range(t, 48, 12):
+            got[i] = enc.embed_query(qs[i])
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(12)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert got == want  # a sequence's embedding does not depend on what else is in the batch (bit-identical)
+    assert gc.passes - p0 < 48
