@@ -278,6 +278,9 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
         const size_t o_ids = take(b.ids.size() * 4), o_ti = take(b.tiles.size() * sizeof(TileInfo)), o_sf = take(b.seq_first.size() * 4);
         const size_t o_a = take(act_b), o_b = take(act_b), o_q = take(act_b), o_k = take(act_b), o_v = take(act_b);
+        // latency path (<= kSmallTiles tiles): Y float32 [tile][384][32] and the FFN's h fragments [tile][96][64] x 16 B
+        const bool small = nt <= kSmallTiles;
+        const size_t o_y = small ? take((size_t)nt * NFB * 16 * 64 * 4) : 0, o_hb = small ? take((size_t)nt * 2 * NHT * 64 * 16) : 0;
         const size_t o_out = take((size_t)(s1 - s0) * H * 4);
         const size_t o_hid = hidden_out ? take((size_t)nt * 32 * H * 4) : 0;
         if (e->ws_cap[slot] < off) {
@@ -312,7 +315,24 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         uint4 *qf = reinterpret_cast<uint4 *>(w + o_q), *kf = reinterpret_cast<uint4 *>(w + o_k), *vf = reinterpret_cast<uint4 *>(w + o_v);
         const dim3 g4((nt + 3) / 4), blk(256);
         embed_ln_kernel<<<g4, blk, 0, s>>>(d_ids, d_ti, nt, e->word, e->pos, e->type0, e->emb_g, e->emb_b, a0);
-        for (int li = 0; li < nl; ++li) {
+        // latency path (encoder_kernels.h, section L): the same products spread over the weight dimension
+        for (int li = 0; li < nl && small; ++li) {
+            const Layer &l = e->L[li];
+            float *Y = reinterpret_cast<float *>(w + o_y);
+            uint4 *hb = reinterpret_cast<uint4 *>(w + o_hb);
+            qkv_small_kernel<<<dim3(36, nt), dim3(64), 0, s>>>(a0, l.wqkv, l.bqkv, qf, kf, vf);
+            {
+                const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);  // a1 = context
+                if (arc != MIR_OK) return arc;
+            }
+            oproj_small_kernel<<<dim3(NFB, nt), dim3(64), 0, s>>>(a1, l.wo, Y);
+            ln_small_kernel<<<dim3(nt), dim3(64), 0, s>>>(Y, a0, l.attn_params, l.attn_params + H, l.attn_params + 2 * H, a1);
+            ffn1_small_kernel<<<dim3(NHT, nt), dim3(64), 0, s>>>(a1, l.wffn, l.ffn_params, hb);
+            ffn2_small_kernel<<<dim3(NFB, nt), dim3(64), 0, s>>>(hb, l.wffn, Y);
+            ln_small_kernel<<<dim3(nt), dim3(64), 0, s>>>(Y, a1, l.ffn_params + FF, l.ffn_params + FF + H,
+                                                          l.ffn_params + FF + 2 * H, a0);
+        }
+        for (int li = 0; li < nl && !small; ++li) {
             const Layer &l = e->L[li];
             qkv_kernel<<<dim3((nt + 4 * QKV_G - 1) / (4 * QKV_G)), blk, 0, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
             {

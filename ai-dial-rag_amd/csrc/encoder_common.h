@@ -59,6 +59,17 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
     const _Float16 x = (_Float16)a, y = (_Float16)b;
     return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
 }
+// pack2 written as the instruction itself.  Left to hipcc, `(_Float16)fmaf(..)` became v_fma_mixlo_f16
+// (ONE rounding, exact -> float16) in ln_small_kernel and fma + v_cvt_pk_f16_f32 (two roundings) in the
+// throughput kernels, so the same LayerNorm rounded differently on the two paths in about one value
+// per 10^5.  The latency kernel therefore pins the two-rounding form; pinning it in the throughput
+// kernels too costs ffn_ln_kernel 34 spilled registers (-15% chunks/s), so those keep the compiler's
+// choice and tests/test_gpu_encoder.py::test_batching_is_invariant watches that it stays the same.
+__device__ __forceinline__ uint32_t pack2_rn(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // registers 8*s2 .. 8*s2+7 of an accumulator -> one float16 fragment
 __device__ __forceinline__ uint4 acc_to_frag(const f32x16 &a, int s2) {
     const int o = 8 * s2;
@@ -104,6 +115,7 @@ struct TileInfo {
 // registers of a group g = r>>2 are four CONSECUTIVE features, so bias / gamma / beta are read as
 // float4 (a quarter of the loads of the per-register form, which made this epilogue ~3000
 // instructions and longer than the output projection's MFMAs).
+template <bool PIN_CVT = false>
 __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 *__restrict__ resid_tile,
                                                   const float *__restrict__ bias, const float *__restrict__ gamma,
                                                   const float *__restrict__ beta, uint4 *__restrict__ out_tile,
@@ -155,9 +167,11 @@ __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 
         }
         if (store) {
             out_tile[(fb * 2 + 0) * 64 + lane] =
-                make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
+                PIN_CVT ? make_uint4(pack2_rn(o[0], o[1]), pack2_rn(o[2], o[3]), pack2_rn(o[4], o[5]), pack2_rn(o[6], o[7]))
+                        : make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
             out_tile[(fb * 2 + 1) * 64 + lane] =
-                make_uint4(pack2(o[8], o[9]), pack2(o[10], o[11]), pack2(o[12], o[13]), pack2(o[14], o[15]));
+                PIN_CVT ? make_uint4(pack2_rn(o[8], o[9]), pack2_rn(o[10], o[11]), pack2_rn(o[12], o[13]), pack2_rn(o[14], o[15]))
+                        : make_uint4(pack2(o[8], o[9]), pack2(o[10], o[11]), pack2(o[12], o[13]), pack2(o[14], o[15]));
         }
     }
 }

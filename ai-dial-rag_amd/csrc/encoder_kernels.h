@@ -345,6 +345,124 @@ __global__ __launch_bounds__(256, 1) void ffn_ln_kernel(const uint4 *__restrict_
                       act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
 }
 
+// ---------------------------------------------------------------- L: latency path for tiny inputs
+// The kernels above are throughput-shaped: a workgroup walks ALL weights of a layer for its 128
+// tokens, so ONE query (a single 32-token tile; `aembed_query`, embeddings.py:93-96) took 2.1 ms with
+// 255 CUs idle.  For at most kSmallTiles token tiles the same products are spread over the weight
+// dimension instead: one WAVE per (weight tile, token tile), weights straight from L2, no LDS.
+//   qkv_small      grid (36, tiles)   24 MFMAs per wave
+//   oproj_small    grid (12, tiles)   24 MFMAs -> pre-LayerNorm float32 tile rows in Y
+//   ffn1_small     grid (48, tiles)   24 MFMAs + GELU -> h fragments
+//   ffn2_small     grid (12, tiles)   96 MFMAs over the h fragments -> Y
+//   ln_small       grid (tiles)       Y + bias + residual -> LayerNorm -> ACT
+// Y: float32 [tile][12 output tiles][16 registers][64 lanes] (the accumulators as they are).
+// Same arithmetic in the same order as the throughput kernels (MFMA chains over k ascending, the same
+// GELU and residual_ln_store): a sequence's embedding is bit-identical on either path, which
+// test_batching_is_invariant holds both to.
+// measured crossover (tools/encoder_latency.py): 64 tiles 1.07 vs 2.38 ms, 256 tiles 1.80 vs 2.49 ms, 512 tiles 2.87 vs 2.62 ms
+constexpr int kSmallTiles = 256;
+
+__global__ __launch_bounds__(64) void qkv_small_kernel(const uint4 *__restrict__ act, const uint4 *__restrict__ wqkv,
+                                                       const float *__restrict__ bqkv, uint4 *__restrict__ qf,
+                                                       uint4 *__restrict__ kf, uint4 *__restrict__ vf) {
+    const int lane = threadIdx.x, h = lane >> 5;
+    const int tile = blockIdx.x, tt = blockIdx.y;
+    const uint4 *xin = act + (size_t)tt * (NFB * 2 * 64) + lane;
+    const uint4 *wp = wqkv + (size_t)tile * (KS_H * 64) + lane;
+    uint4 x[KS_H], w[KS_H];
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) { x[ks] = xin[ks * 64]; w[ks] = wp[ks * 64]; }
+    f32x16 acc = {0};
+    const float *b = bqkv + tile * 32;
+    if (tile >= 24) {  // V: x W (rows = tokens)
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) acc = mfma(x[ks], w[ks], acc);
+        const float bv = b[lane & 31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += bv;
+    } else {           // Q, K: W^T x^T (rows = head features)
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) acc = mfma(w[ks], x[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += b[fi(r, h)];
+    }
+    uint4 *dst = (tile < 12 ? qf : tile < 24 ? kf : vf) + ((size_t)(tt * NH + tile % 12) * 2) * 64 + lane;
+    dst[0] = acc_to_frag(acc, 0);
+    dst[64] = acc_to_frag(acc, 1);
+}
+
+__device__ __forceinline__ void store_acc_rows(float *__restrict__ Y, int tt, int nt, int lane, const f32x16 &acc) {
+    float4 *yo = reinterpret_cast<float4 *>(Y + (((size_t)tt * NFB + nt) * 16) * 64) + lane;  // [4 chunks][64 lanes] float4
+#pragma unroll
+    for (int c = 0; c < 4; ++c) yo[c * 64] = make_float4(acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+}
+
+__global__ __launch_bounds__(64) void oproj_small_kernel(const uint4 *__restrict__ ctx, const uint4 *__restrict__ wo,
+                                                         float *__restrict__ Y) {
+    const int lane = threadIdx.x;
+    const int nt = blockIdx.x, tt = blockIdx.y;
+    const uint4 *cin = ctx + (size_t)tt * (NFB * 2 * 64) + lane;
+    const uint4 *wp = wo + (size_t)nt * (KS_H * 64) + lane;
+    f32x16 acc = {0};
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) acc = mfma(wp[ks * 64], cin[ks * 64], acc);
+    store_acc_rows(Y, tt, nt, lane, acc);
+}
+
+__global__ __launch_bounds__(64) void ffn1_small_kernel(const uint4 *__restrict__ act_in,
+                                                        const unsigned char *__restrict__ wffn,
+                                                        const float *__restrict__ b1, uint4 *__restrict__ hbuf) {
+    const int lane = threadIdx.x, h = lane >> 5;
+    const int ht = blockIdx.x, tt = blockIdx.y;
+    const uint4 *xin = act_in + (size_t)tt * (NFB * 2 * 64) + lane;
+    const uint4 *wp = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * ht) * (24 * 1024)) + lane;  // W1(ht)
+    f32x16 acc = {0};
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) acc = mfma(wp[ks * 64], xin[ks * 64], acc);
+    float g[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = gelu(acc[r] + b1[32 * ht + fi(r, h)]);
+    uint4 *ho = hbuf + ((size_t)tt * (2 * NHT) + 2 * ht) * 64 + lane;
+    ho[0] = make_uint4(pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7]));
+    ho[64] = make_uint4(pack2(g[8], g[9]), pack2(g[10], g[11]), pack2(g[12], g[13]), pack2(g[14], g[15]));
+}
+
+__global__ __launch_bounds__(64) void ffn2_small_kernel(const uint4 *__restrict__ hbuf,
+                                                        const unsigned char *__restrict__ wffn,
+                                                        float *__restrict__ Y) {
+    const int lane = threadIdx.x;
+    const int nt = blockIdx.x, tt = blockIdx.y;
+    const uint4 *hin = hbuf + (size_t)tt * (2 * NHT) * 64 + lane;
+    f32x16 acc = {0};
+#pragma unroll 8
+    for (int ht = 0; ht < NHT; ++ht) {
+        // W2(ht) = flat half 2*ht + 1; its fragment for (output tile nt, s2) is piece nt*2 + s2
+        const uint4 *wp = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * ht + 1) * (24 * 1024)) + (nt * 2) * 64 + lane;
+        acc = mfma(wp[0], hin[(2 * ht + 0) * 64], acc);
+        acc = mfma(wp[64], hin[(2 * ht + 1) * 64], acc);
+    }
+    store_acc_rows(Y, tt, nt, lane, acc);
+}
+
+// Y + bias + residual -> LayerNorm -> ACT; one wave per token tile
+__global__ __launch_bounds__(64) void ln_small_kernel(const float *__restrict__ Y, const uint4 *__restrict__ resid,
+                                                      const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, uint4 *__restrict__ act_out) {
+    const int lane = threadIdx.x, tt = blockIdx.x;
+    f32x16 y[NFB];
+#pragma unroll
+    for (int nt = 0; nt < NFB; ++nt) {
+        const float4 *yi = reinterpret_cast<const float4 *>(Y + (((size_t)tt * NFB + nt) * 16) * 64) + lane;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 v = yi[c * 64];
+            y[nt][4 * c + 0] = v.x; y[nt][4 * c + 1] = v.y; y[nt][4 * c + 2] = v.z; y[nt][4 * c + 3] = v.w;
+        }
+    }
+    residual_ln_store<true>(y, resid + (size_t)tt * (NFB * 2 * 64), bias, gamma, beta, act_out + (size_t)tt * (NFB * 2 * 64), lane,
+                      true);
+}
+
 // ---------------------------------------------------------------- E5: CLS pooling + L2 normalise
 // one wave per sequence: token 0 of the sequence, float32 [384] in natural feature order.
 __global__ __launch_bounds__(64) void pool_normalize_kernel(const uint4 *__restrict__ act,

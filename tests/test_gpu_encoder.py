@@ -60,13 +60,24 @@ def test_embeddings_cls_normalised(setup):
 
 
 def test_batching_is_invariant(setup):
-    """A sequence's embedding does not depend on what else is in the batch (no cross-sequence leakage, padding masked)."""
+    """A sequence's embedding does not depend on what else is in the batch (no cross-sequence leakage, padding
+    masked) NOR on which kernels served it: batches of at most 256 token tiles take the latency kernels
+    (encoder_kernels.h section L), larger ones the throughput kernels, and both must round identically."""
     model, enc, seqs, oe = setup
-    together = enc.encode_ids(seqs)
+    rng = np.random.default_rng(7)
+    filler = [rng.integers(999, 30522, 512).tolist() for _ in range(20)]  # 45 + 320 tiles: throughput kernels
+    together = enc.encode_ids(seqs + filler)[: len(seqs)]
+    small_batch = enc.encode_ids(seqs)  # 45 tiles: latency kernels
+    np.testing.assert_array_equal(together, small_batch)
     alone = np.stack([enc.encode_ids([s])[0] for s in seqs])
     np.testing.assert_array_equal(together, alone)
-    rev = enc.encode_ids(seqs[::-1])[::-1]
+    rev = enc.encode_ids((seqs + filler)[::-1])[::-1][: len(seqs)]
     np.testing.assert_array_equal(together, rev)
+    # and layer by layer (hidden states of every token, not only the pooled CLS row)
+    for layers in (1, 12):
+        _, big = enc.debug_hidden(seqs + filler, layers)
+        _, small = enc.debug_hidden(seqs, layers)
+        np.testing.assert_array_equal(big[: len(small)], small)
 
 
 def test_argument_errors(setup):
