@@ -306,9 +306,9 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         std::memcpy(pn + p_ids, b.ids.data(), b.ids.size() * 4);
         std::memcpy(pn + p_ti, b.tiles.data(), b.tiles.size() * sizeof(TileInfo));
         std::memcpy(pn + p_sf, b.seq_first.data(), b.seq_first.size() * 4);
-        MIR_HIP(hipMemcpyAsync(w + o_ids, pn + p_ids, b.ids.size() * 4, hipMemcpyHostToDevice, s));
-        MIR_HIP(hipMemcpyAsync(w + o_ti, pn + p_ti, b.tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice, s));
-        MIR_HIP(hipMemcpyAsync(w + o_sf, pn + p_sf, b.seq_first.size() * 4, hipMemcpyHostToDevice, s));
+        // [ids | tiles | seq_first] have the same 256-aligned offsets on both sides: one copy
+        MIR_REQUIRE(o_ids == p_ids && o_ti == p_ti && o_sf == p_sf, "staging layout mismatch");
+        MIR_HIP(hipMemcpyAsync(w + o_ids, pn + p_ids, p_sf + b.seq_first.size() * 4, hipMemcpyHostToDevice, s));
         const int32_t *d_ids = reinterpret_cast<int32_t *>(w + o_ids);
         const TileInfo *d_ti = reinterpret_cast<TileInfo *>(w + o_ti);
         uint4 *a0 = reinterpret_cast<uint4 *>(w + o_a), *a1 = reinterpret_cast<uint4 *>(w + o_b);

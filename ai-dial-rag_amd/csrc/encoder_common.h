@@ -121,18 +121,29 @@ __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 
                                                   const float *__restrict__ beta, uint4 *__restrict__ out_tile,
                                                   int lane, bool store) {
     const int h = lane >> 5;
+    // Loads first, arithmetic after: written load-next-to-use, hipcc waited for every one of the ~170 loads of
+    // this epilogue separately (s_waitcnt vmcnt(0) each), which with one wave per SIMD is ~170 exposed round trips.
+    uint4 rr[NFB * 2];
+#pragma unroll
+    for (int i = 0; i < NFB * 2; ++i) rr[i] = resid_tile[i * 64 + lane];
+    auto load4 = [&](const float *p, int fb, float4 (&dst)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const float4 *>(p + 32 * fb + 8 * g + 4 * h);
+    };
+    float4 bcur[4], bnext[4];
+    load4(bias, 0, bcur);
     float sum = 0.f;
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
+        if (fb + 1 < NFB) load4(bias, fb + 1, bnext);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float rv[8];
-            frag_to_floats(resid_tile[(fb * 2 + s2) * 64 + lane], rv);
+            frag_to_floats(rr[fb * 2 + s2], rv);
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 const int g = 2 * s2 + gq;
-                const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * fb + 8 * g + 4 * h);
-                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                const float bb[4] = {bcur[g].x, bcur[g].y, bcur[g].z, bcur[g].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * g + i;
@@ -142,6 +153,8 @@ __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 
                 }
             }
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bcur[g] = bnext[g];
     }
     const float mean = half_sum(sum) * (1.0f / H);
     float sq = 0.f;
@@ -153,18 +166,25 @@ __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 
             y[fb][r] = dlt;
             sq = fmaf(dlt, dlt, sq);
         }
+    float4 gcur[4], ecur[4], gnext[4], enext[4];
+    load4(gamma, 0, gcur);
+    load4(beta, 0, ecur);
     const float rstd = rsqrtf(half_sum(sq) * (1.0f / H) + LN_EPS);
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
+        if (fb + 1 < NFB) {
+            load4(gamma, fb + 1, gnext);
+            load4(beta, fb + 1, enext);
+        }
         float o[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 g4 = *reinterpret_cast<const float4 *>(gamma + 32 * fb + 8 * g + 4 * h);
-            const float4 e4 = *reinterpret_cast<const float4 *>(beta + 32 * fb + 8 * g + 4 * h);
-            const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
+            const float gg[4] = {gcur[g].x, gcur[g].y, gcur[g].z, gcur[g].w}, ee[4] = {ecur[g].x, ecur[g].y, ecur[g].z, ecur[g].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[4 * g + i] = fmaf(y[fb][4 * g + i] * rstd, gg[i], ee[i]);
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { gcur[g] = gnext[g]; ecur[g] = enext[g]; }
         if (store) {
             out_tile[(fb * 2 + 0) * 64 + lane] =
                 PIN_CVT ? make_uint4(pack2_rn(o[0], o[1]), pack2_rn(o[2], o[3]), pack2_rn(o[4], o[5]), pack2_rn(o[6], o[7]))

@@ -361,8 +361,11 @@ __global__ __launch_bounds__(256, 1) void ffn_ln_kernel(const uint4 *__restrict_
 // test_batching_is_invariant holds both to.
 // measured crossover (tools/encoder_latency.py): 64 tiles 1.07 vs 2.38 ms, 256 tiles 1.80 vs 2.49 ms, 512 tiles 2.87 vs 2.62 ms
 constexpr int kSmallTiles = 256;
+// one wave per SIMD is the plan for these kernels (a handful of waves per CU at most): tell the scheduler, or it
+// keeps register pressure low for an occupancy nobody wants and sinks the prefetches back next to their uses
+#define MIR_ONE_WAVE __attribute__((amdgpu_waves_per_eu(1, 1)))
 
-__global__ __launch_bounds__(64) void qkv_small_kernel(const uint4 *__restrict__ act, const uint4 *__restrict__ wqkv,
+__global__ __launch_bounds__(64) MIR_ONE_WAVE void qkv_small_kernel(const uint4 *__restrict__ act, const uint4 *__restrict__ wqkv,
                                                        const float *__restrict__ bqkv, uint4 *__restrict__ qf,
                                                        uint4 *__restrict__ kf, uint4 *__restrict__ vf) {
     const int lane = threadIdx.x, h = lane >> 5;
@@ -397,58 +400,9 @@ __device__ __forceinline__ void store_acc_rows(float *__restrict__ Y, int tt, in
     for (int c = 0; c < 4; ++c) yo[c * 64] = make_float4(acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
 }
 
-__global__ __launch_bounds__(64) void oproj_small_kernel(const uint4 *__restrict__ ctx, const uint4 *__restrict__ wo,
-                                                         float *__restrict__ Y) {
-    const int lane = threadIdx.x;
-    const int nt = blockIdx.x, tt = blockIdx.y;
-    const uint4 *cin = ctx + (size_t)tt * (NFB * 2 * 64) + lane;
-    const uint4 *wp = wo + (size_t)nt * (KS_H * 64) + lane;
-    f32x16 acc = {0};
-#pragma unroll
-    for (int ks = 0; ks < KS_H; ++ks) acc = mfma(wp[ks * 64], cin[ks * 64], acc);
-    store_acc_rows(Y, tt, nt, lane, acc);
-}
-
-__global__ __launch_bounds__(64) void ffn1_small_kernel(const uint4 *__restrict__ act_in,
-                                                        const unsigned char *__restrict__ wffn,
-                                                        const float *__restrict__ b1, uint4 *__restrict__ hbuf) {
-    const int lane = threadIdx.x, h = lane >> 5;
-    const int ht = blockIdx.x, tt = blockIdx.y;
-    const uint4 *xin = act_in + (size_t)tt * (NFB * 2 * 64) + lane;
-    const uint4 *wp = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * ht) * (24 * 1024)) + lane;  // W1(ht)
-    f32x16 acc = {0};
-#pragma unroll
-    for (int ks = 0; ks < KS_H; ++ks) acc = mfma(wp[ks * 64], xin[ks * 64], acc);
-    float g[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) g[r] = gelu(acc[r] + b1[32 * ht + fi(r, h)]);
-    uint4 *ho = hbuf + ((size_t)tt * (2 * NHT) + 2 * ht) * 64 + lane;
-    ho[0] = make_uint4(pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7]));
-    ho[64] = make_uint4(pack2(g[8], g[9]), pack2(g[10], g[11]), pack2(g[12], g[13]), pack2(g[14], g[15]));
-}
-
-__global__ __launch_bounds__(64) void ffn2_small_kernel(const uint4 *__restrict__ hbuf,
-                                                        const unsigned char *__restrict__ wffn,
-                                                        float *__restrict__ Y) {
-    const int lane = threadIdx.x;
-    const int nt = blockIdx.x, tt = blockIdx.y;
-    const uint4 *hin = hbuf + (size_t)tt * (2 * NHT) * 64 + lane;
-    f32x16 acc = {0};
-#pragma unroll 8
-    for (int ht = 0; ht < NHT; ++ht) {
-        // W2(ht) = flat half 2*ht + 1; its fragment for (output tile nt, s2) is piece nt*2 + s2
-        const uint4 *wp = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * ht + 1) * (24 * 1024)) + (nt * 2) * 64 + lane;
-        acc = mfma(wp[0], hin[(2 * ht + 0) * 64], acc);
-        acc = mfma(wp[64], hin[(2 * ht + 1) * 64], acc);
-    }
-    store_acc_rows(Y, tt, nt, lane, acc);
-}
-
-// Y + bias + residual -> LayerNorm -> ACT; one wave per token tile
-__global__ __launch_bounds__(64) void ln_small_kernel(const float *__restrict__ Y, const uint4 *__restrict__ resid,
-                                                      const float *__restrict__ bias, const float *__restrict__ gamma,
-                                                      const float *__restrict__ beta, uint4 *__restrict__ act_out) {
-    const int lane = threadIdx.x, tt = blockIdx.x;
+__device__ __forceinline__ void ln_tile(const float *Y, int tt, const uint4 *__restrict__ resid,
+                                        const float *__restrict__ bias, const float *__restrict__ gamma,
+                                        const float *__restrict__ beta, uint4 *__restrict__ act_out, int lane) {
     f32x16 y[NFB];
 #pragma unroll
     for (int nt = 0; nt < NFB; ++nt) {
@@ -460,7 +414,101 @@ __global__ __launch_bounds__(64) void ln_small_kernel(const float *__restrict__ 
         }
     }
     residual_ln_store<true>(y, resid + (size_t)tt * (NFB * 2 * 64), bias, gamma, beta, act_out + (size_t)tt * (NFB * 2 * 64), lane,
-                      true);
+                            true);
+}
+
+// Y + bias + residual -> LayerNorm -> ACT; one wave per token tile.  (Folding this into the product kernels -
+// the tile's last wave to finish does the LayerNorm, counted with an atomic between two device-scope fences -
+// was measured: the fences write back / invalidate the XCD's L2 per wave and cost more than the launch they
+// save: 1 tile 425 -> 412 us, 64 tiles 739 -> 1368 us.)
+__global__ __launch_bounds__(64) MIR_ONE_WAVE void ln_small_kernel(const float *__restrict__ Y, const uint4 *__restrict__ resid,
+                                                                   const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                                   const float *__restrict__ beta, uint4 *__restrict__ act_out) {
+    ln_tile(Y, blockIdx.x, resid, bias, gamma, beta, act_out, threadIdx.x);
+}
+
+__global__ __launch_bounds__(64) MIR_ONE_WAVE void oproj_small_kernel(const uint4 *__restrict__ ctx, const uint4 *__restrict__ wo,
+                                                                      float *__restrict__ Y) {
+    const int lane = threadIdx.x;
+    const int nt = blockIdx.x, tt = blockIdx.y;
+    const uint4 *cin = ctx + (size_t)tt * (NFB * 2 * 64) + lane;
+    const uint4 *wp = wo + (size_t)nt * (KS_H * 64) + lane;
+    uint4 c[KS_H], w[KS_H];  // every load in flight before the first MFMA (hipcc otherwise waits per k-step)
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) { c[ks] = cin[ks * 64]; w[ks] = wp[ks * 64]; }
+    __builtin_amdgcn_sched_barrier(0);  // the loads stay up here
+    f32x16 acc = {0};
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) acc = mfma(w[ks], c[ks], acc);
+    store_acc_rows(Y, tt, nt, lane, acc);
+}
+
+__global__ __launch_bounds__(64) MIR_ONE_WAVE void ffn1_small_kernel(const uint4 *__restrict__ act_in,
+                                                        const unsigned char *__restrict__ wffn,
+                                                        const float *__restrict__ b1, uint4 *__restrict__ hbuf) {
+    const int lane = threadIdx.x, h = lane >> 5;
+    const int ht = blockIdx.x, tt = blockIdx.y;
+    const uint4 *xin = act_in + (size_t)tt * (NFB * 2 * 64) + lane;
+    const uint4 *wp = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * ht) * (24 * 1024)) + lane;  // W1(ht)
+    uint4 x[KS_H], w[KS_H];
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) { x[ks] = xin[ks * 64]; w[ks] = wp[ks * 64]; }
+    float4 bq[4];  // register group g = four consecutive features 8g + 4h ..
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) bq[gq] = *reinterpret_cast<const float4 *>(b1 + 32 * ht + 8 * gq + 4 * h);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc = {0};
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) acc = mfma(w[ks], x[ks], acc);
+    float g[16];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const float bb[4] = {bq[gq].x, bq[gq].y, bq[gq].z, bq[gq].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[4 * gq + i] = gelu(acc[4 * gq + i] + bb[i]);
+    }
+    uint4 *ho = hbuf + ((size_t)tt * (2 * NHT) + 2 * ht) * 64 + lane;
+    ho[0] = make_uint4(pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7]));
+    ho[64] = make_uint4(pack2(g[8], g[9]), pack2(g[10], g[11]), pack2(g[12], g[13]), pack2(g[14], g[15]));
+}
+
+__global__ __launch_bounds__(64) MIR_ONE_WAVE void ffn2_small_kernel(const uint4 *__restrict__ hbuf,
+                                                        const unsigned char *__restrict__ wffn,
+                                                        float *__restrict__ Y) {
+    const int lane = threadIdx.x;
+    const int nt = blockIdx.x, tt = blockIdx.y;
+    const uint4 *hin = hbuf + (size_t)tt * (2 * NHT) * 64 + lane;
+    // 96 k-steps in 8 chunks of 12, the next chunk's 24 loads in flight while this one's MFMAs run
+    constexpr int CH = 6;  // h tiles per chunk (two buffers of 2 x 12 fragments = 192 of the 256 architectural VGPRs)
+    uint4 wa[2 * CH], ha[2 * CH], wb[2 * CH], hb2[2 * CH];
+    auto load_chunk = [&](int c, uint4 (&w)[2 * CH], uint4 (&hh)[2 * CH]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int ht = c * CH + i;
+            // W2(ht) = flat half 2*ht + 1; its fragment for (output tile nt, s2) is piece nt*2 + s2
+            const uint4 *wp = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * ht + 1) * (24 * 1024)) + (nt * 2) * 64 + lane;
+            w[2 * i] = wp[0];
+            w[2 * i + 1] = wp[64];
+            hh[2 * i] = hin[(2 * ht + 0) * 64];
+            hh[2 * i + 1] = hin[(2 * ht + 1) * 64];
+        }
+    };
+    f32x16 acc = {0};
+    load_chunk(0, wa, ha);
+#pragma unroll
+    for (int c = 0; c < NHT / CH; c += 2) {
+        load_chunk(c + 1, wb, hb2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2 * CH; ++i) acc = mfma(wa[i], ha[i], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NHT / CH) load_chunk(c + 2, wa, ha);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2 * CH; ++i) acc = mfma(wb[i], hb2[i], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    store_acc_rows(Y, tt, nt, lane, acc);
 }
 
 // ---------------------------------------------------------------- E5: CLS pooling + L2 normalise

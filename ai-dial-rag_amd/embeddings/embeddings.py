@@ -133,7 +133,7 @@ class BgeEncoder:
         return list(self.encode_ids(self._tokenize(texts)))
 
     def embed_query(self, text: str) -> List[float]:
-        """One query (embeddings.py:93-96).  Encoding 1 or 16 short queries costs the same ~0.9 ms pass, and the
+        """One query (embeddings.py:93-96).  Encoding 1 or 16 short queries costs the same ~0.45 ms pass, and the
         reference calls this from concurrent requests: concurrent callers share passes (group commit)."""
         text = text.replace("\n", " ")  # HuggingFaceBgeEmbeddings.embed_query
         ids = self._tokenize([BGE_QUERY_INSTRUCTION_EN + text])[0]
