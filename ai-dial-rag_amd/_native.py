@@ -58,6 +58,10 @@ def _load():
         "mir_device_count": ([vp], i32),
         "mir_index_create": ([vp, i64, i32, i32, vp, vp, i32, i64, vp], i32),
         "mir_index_create_from_device": ([vp, i64, i32, i32, vp, vp, i32, i64, vp, vp], i32),
+        "mir_rows_create": ([vp, i64, i32, i32, vp, i32, vp], i32),
+        "mir_rows_info": ([vp, vp, vp, vp, vp, vp], i32),
+        "mir_rows_destroy": ([vp], i32),
+        "mir_index_create_from_rows": ([vp, vp, i32, i32, i64, vp], i32),
         "mir_index_destroy": ([vp], i32),
         "mir_index_info": ([vp, vp, vp, vp, vp, vp], i32),
         "mir_index_search": ([vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], i32),

@@ -103,6 +103,18 @@ struct mir_index {
     double prof_ms = 0.0;
 };
 
+// One document's rows resident in HBM (mir_rows_create): the unit that outlives requests, so that an
+// index over ANY set of documents is composed device-to-device (mir_index_create_from_rows).
+struct mir_rows {
+    int device = 0;
+    int64_t n = 0;
+    int d = 0;
+    int dtype = MIR_DTYPE_F32;
+    void *d_emb = nullptr;       // n x d, as given (float32 or float16)
+    int64_t *d_chunk = nullptr;  // n
+    int64_t hbm_bytes = 0;
+};
+
 namespace mir {
 
 static void free_index(mir_index *ix) {
@@ -543,6 +555,83 @@ static int32_t plan(const mir_index *ix, int b, int k, int *ngroups, int *nwg, i
 
 // ============================================================ C ABI
 
+// ---- composition of an index from per-document row blocks (all in HBM) ----
+struct ConcatItem {
+    const void *src;    // first unit of this piece
+    int64_t dst_unit;   // where it goes, in units of the destination type
+    int32_t n_units;    // <= kConcatPiece
+    int32_t doc_id;     // for the doc-id fill (pieces are in row units there)
+};
+constexpr int kConcatPiece = 1 << 18;
+
+template <typename U>
+__global__ __launch_bounds__(256) void concat_kernel(const ConcatItem *__restrict__ items, U *__restrict__ dst) {
+    const ConcatItem it = items[blockIdx.x];
+    const U *src = static_cast<const U *>(it.src);
+    U *out = dst + it.dst_unit;
+    for (int i = threadIdx.x; i < it.n_units; i += 256) out[i] = src[i];
+}
+__global__ __launch_bounds__(256) void fill_doc_kernel(const ConcatItem *__restrict__ items, int32_t *__restrict__ dst) {
+    const ConcatItem it = items[blockIdx.x];
+    int32_t *out = dst + it.dst_unit;
+    for (int i = threadIdx.x; i < it.n_units; i += 256) out[i] = it.doc_id;
+}
+
+// Where the rows of a new index come from: one matrix (host or device), or row blocks in HBM.
+struct RowSource {
+    const void *emb = nullptr;
+    bool on_device = false;
+    const int64_t *chunk_ids = nullptr;
+    const int32_t *doc_ids = nullptr;
+    const mir_rows *const *parts = nullptr;
+    const int32_t *part_doc_ids = nullptr;
+    int32_t nparts = 0;
+};
+
+// pieces of at most kConcatPiece units covering every part; unit_per_row units per row
+static std::vector<ConcatItem> concat_items(const RowSource &src, int64_t units_per_row, size_t unit_bytes, int which) {
+    std::vector<ConcatItem> items;
+    int64_t row0 = 0;
+    for (int p = 0; p < src.nparts; ++p) {
+        const mir_rows *r = src.parts[p];
+        const char *base = which == 0 ? static_cast<const char *>(r->d_emb) : reinterpret_cast<const char *>(r->d_chunk);
+        const int64_t total = r->n * units_per_row;
+        for (int64_t u = 0; u < total; u += kConcatPiece)
+            items.push_back({base ? base + (size_t)u * unit_bytes : nullptr, row0 * units_per_row + u,
+                             (int32_t)std::min<int64_t>(kConcatPiece, total - u), src.part_doc_ids ? src.part_doc_ids[p] : p});
+        row0 += r->n;
+    }
+    return items;
+}
+
+template <typename Launch>
+static hipError_t run_items(const std::vector<ConcatItem> &items, hipStream_t stream, Launch launch) {
+    if (items.empty()) return hipSuccess;
+    ConcatItem *d_items = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_items), items.size() * sizeof(ConcatItem));
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(ConcatItem), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        launch(d_items, (unsigned)items.size());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // `items` (pageable) and d_items die here
+    (void)hipFree(d_items);
+    return e;
+}
+
+// rows of `src` -> dst (n x d elements of `esize` bytes)
+static hipError_t copy_rows(const RowSource &src, void *dst, int64_t n, int32_t d, size_t esize, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (!src.parts)
+        return hipMemcpyAsync(dst, src.emb, (size_t)n * d * esize, src.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream);
+    const std::vector<ConcatItem> items = concat_items(src, d, esize, 0);
+    return run_items(items, stream, [&](const ConcatItem *di, unsigned ni) {
+        if (esize == 4) concat_kernel<uint32_t><<<dim3(ni), dim3(256), 0, stream>>>(di, static_cast<uint32_t *>(dst));
+        else concat_kernel<uint16_t><<<dim3(ni), dim3(256), 0, stream>>>(di, static_cast<uint16_t *>(dst));
+    });
+}
+
 extern "C" {
 
 int32_t mir_abi_version(void) { return MIR_ABI_VERSION; }
@@ -560,19 +649,20 @@ int32_t mir_device_count(int32_t *out_count) {
     return MIR_OK;
 }
 
-static int32_t create_common(const void *emb, bool emb_on_device, int64_t n, int32_t d, int32_t dtype,
-                             const int64_t *chunk_ids, const int32_t *doc_ids, int32_t device,
-                             int64_t row_offset, hipStream_t stream, mir_index **out) {
+static int32_t create_common(const RowSource &src, int64_t n, int32_t d, int32_t dtype,
+                             int32_t device, int64_t row_offset, hipStream_t stream, mir_index **out) {
     int32_t rc = check_create_args(n, d, dtype, out);
     if (rc != MIR_OK) return rc;
-    MIR_REQUIRE(n == 0 || emb != nullptr, "embeddings pointer is NULL");
+    MIR_REQUIRE(n == 0 || src.emb != nullptr || src.parts != nullptr, "embeddings pointer is NULL");
+    const int64_t *chunk_ids = src.chunk_ids;
+    const int32_t *doc_ids = src.doc_ids;
     int cus = 0;
     rc = use_device(device, &cus);
     if (rc != MIR_OK) return rc;
     mir_index *ix = new (std::nothrow) mir_index();
     MIR_REQUIRE(ix != nullptr, "out of host memory");
     ix->device = device; ix->num_cus = cus; ix->n = n; ix->d = d; ix->dtype = dtype; ix->row_offset = row_offset;
-    const hipMemcpyKind kind = emb_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind kind = src.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     auto fail = [&](int32_t code) {
         free_index(ix);
         return code;
@@ -593,20 +683,20 @@ static int32_t create_common(const void *emb, bool emb_on_device, int64_t n, int
     if (ix->native16) {
         MIR_TRY(hipMalloc(reinterpret_cast<void **>(&ix->d_f16), std::max<size_t>(orig_bytes / 2, 16)));
         ix->hbm_bytes += orig_bytes / 2;
-        if (n > 0) MIR_TRY(hipMemcpyAsync(ix->d_f16, emb, orig_bytes / 2, kind, stream));
+        MIR_TRY(copy_rows(src, ix->d_f16, n, d, 2, stream));
     } else {
     MIR_TRY(hipMalloc(&ix->d_orig, std::max<size_t>(orig_bytes, 16)));
     ix->hbm_bytes += orig_bytes;
     }
     if (ix->native16) {
     } else if (n > 0 && dtype == MIR_DTYPE_F32) {
-        MIR_TRY(hipMemcpyAsync(ix->d_orig, emb, orig_bytes, kind, stream));
+        MIR_TRY(copy_rows(src, ix->d_orig, n, d, 4, stream));
     } else if (n > 0) {
         // float16 input: widened exactly to float32 on the device.  Every float16 is hi + lo in
         // bfloat16 exactly (11 significant bits <= 8 + 8), so the scan is EXACT on such an index.
         void *tmp = nullptr;
         MIR_TRY(hipMalloc(&tmp, orig_bytes / 2));
-        hipError_t e1 = hipMemcpyAsync(tmp, emb, orig_bytes / 2, kind, stream);
+        hipError_t e1 = copy_rows(src, tmp, n, d, 2, stream);
         if (e1 == hipSuccess) {
             const int64_t total = n * (int64_t)d;
             widen_f16_kernel<<<dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), dim3(256), 0, stream>>>(
@@ -616,6 +706,16 @@ static int32_t create_common(const void *emb, bool emb_on_device, int64_t n, int
         if (e1 == hipSuccess) e1 = hipStreamSynchronize(stream);
         (void)hipFree(tmp);
         MIR_TRY(e1);
+    }
+    if (src.parts && n > 0) {  // chunk ids of the blocks, doc id = the block's
+        MIR_TRY(hipMalloc(&ix->d_chunk, (size_t)n * 8));
+        MIR_TRY(hipMalloc(&ix->d_doc, (size_t)n * 4));
+        ix->hbm_bytes += (size_t)n * 12;
+        const std::vector<ConcatItem> items = concat_items(src, 1, 8, 1);
+        MIR_TRY(run_items(items, stream, [&](const ConcatItem *di, unsigned ni) {
+            concat_kernel<uint64_t><<<dim3(ni), dim3(256), 0, stream>>>(di, reinterpret_cast<uint64_t *>(ix->d_chunk));
+            fill_doc_kernel<<<dim3(ni), dim3(256), 0, stream>>>(di, ix->d_doc);
+        }));
     }
     if (chunk_ids && n > 0) {
         MIR_TRY(hipMalloc(&ix->d_chunk, (size_t)n * 8));
@@ -641,14 +741,96 @@ static int32_t create_common(const void *emb, bool emb_on_device, int64_t n, int
 
 int32_t mir_index_create(const void *emb_host, int64_t n, int32_t d, int32_t dtype, const int64_t *chunk_ids_host,
                          const int32_t *doc_ids_host, int32_t device, int64_t row_offset, mir_index **out) {
-    return create_common(emb_host, false, n, d, dtype, chunk_ids_host, doc_ids_host, device, row_offset, nullptr, out);
+    RowSource src;
+    src.emb = emb_host; src.chunk_ids = chunk_ids_host; src.doc_ids = doc_ids_host;
+    return create_common(src, n, d, dtype, device, row_offset, nullptr, out);
 }
 
 int32_t mir_index_create_from_device(const void *emb_device, int64_t n, int32_t d, int32_t dtype,
                                      const int64_t *chunk_ids_device, const int32_t *doc_ids_device,
                                      int32_t device, int64_t row_offset, void *stream, mir_index **out) {
-    return create_common(emb_device, true, n, d, dtype, chunk_ids_device, doc_ids_device, device, row_offset,
-                         static_cast<hipStream_t>(stream), out);
+    RowSource src;
+    src.emb = emb_device; src.on_device = true; src.chunk_ids = chunk_ids_device; src.doc_ids = doc_ids_device;
+    return create_common(src, n, d, dtype, device, row_offset, static_cast<hipStream_t>(stream), out);
+}
+
+// ---- row blocks ----
+int32_t mir_rows_create(const void *emb_host, int64_t n, int32_t d, int32_t dtype, const int64_t *chunk_ids_host,
+                        int32_t device, mir_rows **out) {
+    mir_index *dummy = nullptr;
+    int32_t rc = check_create_args(n, d, dtype, &dummy);
+    if (rc != MIR_OK) return rc;
+    MIR_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    MIR_REQUIRE(n == 0 || emb_host != nullptr, "embeddings pointer is NULL");
+    rc = use_device(device, nullptr);
+    if (rc != MIR_OK) return rc;
+    mir_rows *r = new (std::nothrow) mir_rows();
+    MIR_REQUIRE(r != nullptr, "out of host memory");
+    r->device = device; r->n = n; r->d = d; r->dtype = dtype;
+    const size_t eb = (size_t)n * d * (dtype == MIR_DTYPE_F16 ? 2 : 4);
+    hipError_t e = hipSuccess;
+    if (n > 0) {
+        e = hipMalloc(&r->d_emb, eb);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_chunk), (size_t)n * 8);
+        if (e == hipSuccess) e = hipMemcpy(r->d_emb, emb_host, eb, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            if (chunk_ids_host) {
+                e = hipMemcpy(r->d_chunk, chunk_ids_host, (size_t)n * 8, hipMemcpyHostToDevice);
+            } else {  // NULL = 0..n-1, as mir_index_create
+                std::vector<int64_t> ar((size_t)n);
+                for (int64_t i = 0; i < n; ++i) ar[(size_t)i] = i;
+                e = hipMemcpy(r->d_chunk, ar.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+            }
+        }
+        r->hbm_bytes = (int64_t)eb + n * 8;
+    }
+    if (e != hipSuccess) {
+        set_error("mir_rows_create: %s", hipGetErrorString(e));
+        (void)hipFree(r->d_emb); (void)hipFree(r->d_chunk);
+        delete r;
+        return MIR_ERR_HIP;
+    }
+    *out = r;
+    return MIR_OK;
+}
+
+int32_t mir_rows_info(const mir_rows *rows, int64_t *n, int32_t *d, int32_t *dtype, int32_t *device, int64_t *hbm_bytes) {
+    MIR_REQUIRE(rows != nullptr, "handle is NULL");
+    if (n) *n = rows->n;
+    if (d) *d = rows->d;
+    if (dtype) *dtype = rows->dtype;
+    if (device) *device = rows->device;
+    if (hbm_bytes) *hbm_bytes = rows->hbm_bytes;
+    return MIR_OK;
+}
+
+int32_t mir_rows_destroy(mir_rows *rows) {
+    if (!rows) return MIR_OK;
+    (void)hipSetDevice(rows->device);
+    (void)hipFree(rows->d_emb);
+    (void)hipFree(rows->d_chunk);
+    delete rows;
+    return MIR_OK;
+}
+
+int32_t mir_index_create_from_rows(const mir_rows *const *parts, const int32_t *part_doc_ids, int32_t nparts,
+                                   int32_t device, int64_t row_offset, mir_index **out) {
+    MIR_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    MIR_REQUIRE(nparts >= 1 && parts != nullptr, "no row blocks");
+    int64_t n = 0;
+    for (int p = 0; p < nparts; ++p) {
+        MIR_REQUIRE(parts[p] != nullptr, "row block %d is NULL", p);
+        MIR_REQUIRE(parts[p]->device == device, "row block %d lives on device %d, the index on %d", p, parts[p]->device, device);
+        MIR_REQUIRE(parts[p]->d == parts[0]->d && parts[p]->dtype == parts[0]->dtype,
+                    "row block %d is %d-dimensional dtype %d, block 0 is %d-dimensional dtype %d", p, parts[p]->d,
+                    parts[p]->dtype, parts[0]->d, parts[0]->dtype);
+        n += parts[p]->n;
+    }
+    RowSource src;
+    src.on_device = true; src.parts = parts; src.part_doc_ids = part_doc_ids; src.nparts = nparts;
+    return create_common(src, n, parts[0]->d, parts[0]->dtype, device, row_offset, nullptr, out);
 }
 
 int32_t mir_index_destroy(mir_index *idx) {

@@ -7,6 +7,10 @@ documents hand over the SAME Python objects.  The key here is therefore the iden
 objects (``doc.embeddings_index`` / ``doc.text_index``), which the entry keeps alive so that an id cannot be
 recycled while it is cached.  Least-recently-used entries are dropped once the cached indexes exceed a
 budget of HBM bytes; a dropped index is freed when the last retriever using it is gone.
+
+Kinds: "vector" (a composed index over a tuple of documents), "rows" (ONE document's rows in HBM, the
+blocks a vector index over any new combination of documents is composed from device-to-device:
+embeddings_index.py `_upload`), "bm25" (a BM25 model over a tuple of documents).
 """
 
 import os
@@ -24,17 +28,21 @@ class DeviceCache:
         self._entries: "OrderedDict[Hashable, Tuple[object, int, tuple]]" = OrderedDict()  # key -> (value, bytes, sources)
         self.hits = 0
         self.misses = 0
+        self.by_kind: dict = {}  # kind -> [hits, misses]
 
     def get_or_build(self, kind: str, device: int, sources: Sequence[object], build: Callable[[], Tuple[object, int]]):
         """`sources`: the per-document source objects, in order.  `build() -> (value, hbm_bytes)`."""
         key = (kind, device, tuple(id(s) for s in sources))
         with self._lock:
             hit = self._entries.get(key)
+            per = self.by_kind.setdefault(kind, [0, 0])
             if hit is not None:
                 self._entries.move_to_end(key)
                 self.hits += 1
+                per[0] += 1
                 return hit[0]
             self.misses += 1
+            per[1] += 1
         value, nbytes = build()  # outside the lock: uploads take a while, other keys must not wait
         with self._lock:
             if key not in self._entries:

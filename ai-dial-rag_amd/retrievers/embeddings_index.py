@@ -38,6 +38,49 @@ class DocIndex:
         self.embeddings = embeddings if embeddings is not None else np.array([], dtype=np.float32)
 
 
+class DeviceRows:
+    """Owner of one ``mir_rows`` handle: ONE document's rows (and chunk ids) resident in HBM.  Indexes over any
+    set of documents are composed from these device-to-device (``DeviceIndex.from_rows``)."""
+
+    def __init__(self, handle: C.c_void_p, n: int, d: int, device: int):
+        self._h, self.n, self.d, self.device = handle, n, d, device
+
+    @classmethod
+    def from_host(cls, emb: np.ndarray, chunk_ids=None, device: int = 0):
+        emb = np.asarray(emb)
+        dtype = nat.DTYPE_F16 if emb.dtype == np.float16 else nat.DTYPE_F32
+        emb = np.ascontiguousarray(emb, dtype=np.float16 if dtype == nat.DTYPE_F16 else np.float32)
+        if emb.ndim != 2:
+            raise ValueError(f"embeddings must be [n, d], got {emb.shape}")
+        n, d = emb.shape
+        ci = None if chunk_ids is None else np.ascontiguousarray(chunk_ids, dtype=np.int64)
+        if ci is not None and len(ci) != n:
+            raise ValueError(f"{len(ci)} chunk ids for {n} rows")
+        h = C.c_void_p()
+        nat.check(nat.lib.mir_rows_create(nat.ptr(emb), n, d, dtype, nat.ptr(ci), device, C.byref(h)))
+        return cls(h, n, d, device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def hbm_bytes(self) -> int:
+        b = C.c_int64(0)
+        nat.check(nat.lib.mir_rows_info(self._h, None, None, None, None, C.byref(b)))
+        return int(b.value)
+
+    def close(self):
+        if self._h:
+            nat.lib.mir_rows_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceIndex:
     """Owner of one ``mir_index`` handle (a flattened shard resident in HBM)."""
 
@@ -58,6 +101,20 @@ class DeviceIndex:
         h = C.c_void_p()
         nat.check(nat.lib.mir_index_create(nat.ptr(emb), n, d, dtype, nat.ptr(ci), nat.ptr(di), device, row_offset, C.byref(h)))
         return cls(h, n, d, device)
+
+    @classmethod
+    def from_rows(cls, parts: Sequence["DeviceRows"], doc_ids: Optional[Sequence[int]] = None, device: int = 0,
+                  row_offset: int = 0):
+        """Concatenate row blocks device-to-device, in order; rows of ``parts[p]`` get doc id ``doc_ids[p]`` (default p)."""
+        if not parts:
+            raise ValueError("no row blocks")
+        arr = (C.c_void_p * len(parts))(*[p.handle for p in parts])
+        di = None if doc_ids is None else np.ascontiguousarray(doc_ids, dtype=np.int32)
+        if di is not None and len(di) != len(parts):
+            raise ValueError(f"{len(di)} doc ids for {len(parts)} row blocks")
+        h = C.c_void_p()
+        nat.check(nat.lib.mir_index_create_from_rows(arr, nat.ptr(di), len(parts), device, row_offset, C.byref(h)))
+        return cls(h, sum(p.n for p in parts), parts[0].d, device)
 
     @classmethod
     def from_device_ptr(cls, emb_ptr: int, n: int, d: int, device: int, row_offset: int = 0, chunk_ids_ptr: int = 0,
@@ -159,17 +216,34 @@ class EmbeddingsIndex:
         return self._indexes
 
     def _upload(self):
-        """Flatten non-empty documents in order (embeddings_index.py:67-69) -> (DeviceIndex or None, HBM bytes)."""
-        embs, chunk_ids, doc_ids = [], [], []
-        for i, doc in enumerate(self.doc_indexes):
-            if len(doc.embeddings) == 0:
-                continue
-            e = np.asarray(doc.embeddings, dtype=np.float32)
-            embs.append(e)
-            chunk_ids.append(np.asarray(doc.chunk_ids, dtype=np.int64))
-            doc_ids.append(np.full(len(e), i, dtype=np.int32))
-        if not embs:
+        """Flatten non-empty documents in order (embeddings_index.py:67-69) -> (DeviceIndex or None, HBM bytes).
+
+        With ``cache_sources`` (one source object per document) every document's rows are a `DeviceRows` block
+        cached on its own, so an index over a NEW combination of known documents uploads nothing: it is composed
+        device-to-device.  Without, the documents are flattened on the host and uploaded as one matrix."""
+        docs = [(i, doc) for i, doc in enumerate(self.doc_indexes) if len(doc.embeddings) > 0]
+        if not docs:
             return None, 0
+        srcs = self._cache_sources
+        n_docs = len(self.doc_indexes)
+        if srcs is not None and len(srcs) >= n_docs and len(srcs) % n_docs == 0:
+            from ._device_cache import CACHE
+
+            m = len(srcs) // n_docs  # source objects per document (by-page indexes have two: chunks and page rows)
+
+            def block(doc):
+                def build():
+                    r = DeviceRows.from_host(np.asarray(doc.embeddings), np.asarray(doc.chunk_ids, dtype=np.int64), self.device)
+                    return r, r.hbm_bytes()
+
+                return build
+
+            parts = [CACHE.get_or_build("rows", self.device, srcs[i * m:(i + 1) * m], block(doc)) for i, doc in docs]
+            dev = DeviceIndex.from_rows(parts, [i for i, _ in docs], self.device)
+            return dev, dev.hbm_bytes()
+        embs = [np.asarray(doc.embeddings, dtype=np.float32) for _, doc in docs]
+        chunk_ids = [np.asarray(doc.chunk_ids, dtype=np.int64) for _, doc in docs]
+        doc_ids = [np.full(len(e), i, dtype=np.int32) for (i, _), e in zip(docs, embs)]
         dev = DeviceIndex.from_host(np.concatenate(embs), np.concatenate(chunk_ids), np.concatenate(doc_ids), self.device)
         return dev, dev.hbm_bytes()
 

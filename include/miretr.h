@@ -92,6 +92,23 @@ int32_t mir_index_create_from_device(const void *emb_device, int64_t n, int32_t 
                                      const int64_t *chunk_ids_device, const int32_t *doc_ids_device,
                                      int32_t device, int64_t row_offset, void *stream, mir_index **out);
 
+/* Row blocks: one document's rows resident in HBM, and an index composed from blocks.
+ * The reference rebuilds its matrix inside every request from the DocIndex of each document the
+ * request names (semantic_retriever.py:26-41 -> embeddings_index.py:121-136); requests over
+ * different document sets share most documents.  A block is uploaded once per document
+ * (chunk_ids NULL = 0..n-1); mir_index_create_from_rows concatenates blocks device-to-device in
+ * the order given (= the reference's document order, which fixes the tie-break) and gives every
+ * row of block p the doc id part_doc_ids[p] (NULL = p).  Blocks are copied: they may be destroyed
+ * or reused for other indexes afterwards.  All blocks must share d, dtype and the device. */
+typedef struct mir_rows mir_rows;
+int32_t mir_rows_create(const void *emb_host, int64_t n, int32_t d, int32_t dtype,
+                        const int64_t *chunk_ids_host, int32_t device, mir_rows **out);
+int32_t mir_rows_info(const mir_rows *rows, int64_t *n, int32_t *d, int32_t *dtype, int32_t *device,
+                      int64_t *hbm_bytes);
+int32_t mir_rows_destroy(mir_rows *rows);
+int32_t mir_index_create_from_rows(const mir_rows *const *parts, const int32_t *part_doc_ids,
+                                   int32_t nparts, int32_t device, int64_t row_offset, mir_index **out);
+
 int32_t mir_index_destroy(mir_index *idx);
 
 /* n rows, dimension, dtype, device, bytes of HBM held */

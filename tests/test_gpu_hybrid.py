@@ -149,17 +149,90 @@ def test_indexes_survive_across_requests():
     r1 = s1._find_relevant_documents(q)
     b1 = BM25Retriever.from_doc_records(recs, k=4, preprocess=str.split)
     k1 = b1._get_relevant_documents("w1 w7 w9")
-    assert dc.CACHE.misses - m0 == 2 and dc.CACHE.hits - h0 == 0
+    assert dc.CACHE.misses - m0 == 4 and dc.CACHE.hits - h0 == 0  # vector index + its two row blocks + BM25 model
     s2 = SemanticRetriever.from_doc_records(recs, k=5)
     b2 = BM25Retriever.from_doc_records(recs, k=4, preprocess=str.split)
     assert s2._find_relevant_documents(q) == r1 and b2._get_relevant_documents("w1 w7 w9") == k1
     assert dc.CACHE.hits - h0 == 2 and s2.index._device_index() is s1.index._device_index() and b2.bm25 is b1.bm25
     other = [Rec(100)]
     s3 = SemanticRetriever.from_doc_records(other, k=5)
-    assert s3.index._device_index() is not s1.index._device_index() and dc.CACHE.misses - m0 == 3
+    assert s3.index._device_index() is not s1.index._device_index() and dc.CACHE.misses - m0 == 6  # index + one row block
     # a tiny budget keeps only the most recent entry; evicted indexes stay valid for whoever still holds them
     small = dc.DeviceCache(budget_bytes=1)
     a = small.get_or_build("x", 0, [recs[0]], lambda: ("A", 10))
     b = small.get_or_build("x", 0, [recs[1]], lambda: ("B", 10))
     assert (a, b) == ("A", "B") and len(small) == 1
     assert s1._find_relevant_documents(q) == r1
+
+
+def test_new_document_combinations_are_composed_in_hbm():
+    """A request over a NEW combination of documents uploads only the documents not seen before: every document's
+    rows are a block in HBM (mir_rows) and the index is concatenated device-to-device (mir_index_create_from_rows).
+    The composed index answers exactly like one uploaded flat from the host - ids, order, distances, ties."""
+    import numpy as np
+
+    from aidial_rag_amd.retrievers import _device_cache as dc
+    from aidial_rag_amd.retrievers.embeddings_index import DeviceIndex, DeviceRows, DocIndex, EmbeddingsIndex, ItemEmbeddings
+    from aidial_rag_amd.retrievers.semantic_retriever import SemanticRetriever
+
+    rng = np.random.default_rng(11)
+
+    class Rec:
+        def __init__(self, n):
+            v = rng.standard_normal((n, 384)).astype(np.float32)
+            if n > 4:
+                v[3] = v[1]  # duplicate rows: ties inside a document
+            self.embeddings_index = [ItemEmbeddings(v[i : i + 1]) for i in range(n)]
+            self.text_index = None
+
+    a, b, c, empty = Rec(700), Rec(33), Rec(1500), Rec(0)
+    c.embeddings_index[7] = ItemEmbeddings(np.asarray(a.embeddings_index[1].embeddings))  # ... and across documents
+    dc.CACHE.clear()
+    rows0 = list(dc.CACHE.by_kind.get("rows", [0, 0]))
+    qs = rng.standard_normal((9, 384))
+    first = SemanticRetriever.from_doc_records([a, b], k=7)
+    r_first = [first._find_relevant_documents(q) for q in qs]
+    assert [x - y for x, y in zip(dc.CACHE.by_kind["rows"], rows0)] == [0, 2]
+    second = SemanticRetriever.from_doc_records([c, empty, a], k=7)  # a is known, c is new, the empty one has no block
+    r_second = [second._find_relevant_documents(q) for q in qs]
+    assert [x - y for x, y in zip(dc.CACHE.by_kind["rows"], rows0)] == [1, 3]
+
+    def flat(recs):  # no cache_sources: flattened on the host, uploaded as one matrix
+        from aidial_rag_amd.retrievers.embeddings_index import create_index_by_chunk
+        from aidial_rag_amd.index_record import RetrievalType
+
+        ix = EmbeddingsIndex(RetrievalType.TEXT, [create_index_by_chunk(r.embeddings_index) for r in recs], limit=7)
+        return [ix.find(q) for q in qs]
+
+    assert r_first == flat([a, b]) and r_second == flat([c, a])  # from_doc_records drops records without an index
+    # an empty DocIndex in the middle keeps its position (embeddings_index.py:67-69): doc ids 0 and 2, no block for it
+    from aidial_rag_amd.index_record import RetrievalType
+    from aidial_rag_amd.retrievers.embeddings_index import create_index_by_chunk
+
+    marker = object()
+    holes = EmbeddingsIndex(RetrievalType.TEXT, [create_index_by_chunk(c.embeddings_index), DocIndex(),
+                                                 create_index_by_chunk(a.embeddings_index)], limit=7,
+                            cache_sources=[c.embeddings_index, marker, a.embeddings_index])
+    r_holes = [holes.find(q) for q in qs]
+    assert r_holes == flat([c, empty, a])
+    assert {d.metadata["doc_id"] for r in r_holes for d in r} == {0, 2}
+    assert [x - y for x, y in zip(dc.CACHE.by_kind["rows"], rows0)] == [3, 3]  # both blocks were already in HBM
+
+    # C ABI level, float16 blocks of unequal sizes, every metric: identical arrays to the flat upload
+    parts_host = [rng.standard_normal((n, 840)).astype(np.float16) for n in (5, 1000, 1, 64, 2049)]
+    chunk = [rng.integers(0, 1 << 40, len(p)) for p in parts_host]
+    blocks = [DeviceRows.from_host(p, ci) for p, ci in zip(parts_host, chunk)]
+    doc_ids = [4, 0, 9, 9, 2]
+    composed = DeviceIndex.from_rows(blocks, doc_ids)
+    whole = DeviceIndex.from_host(np.concatenate(parts_host), np.concatenate(chunk),
+                                  np.concatenate([np.full(len(p), d, np.int32) for p, d in zip(parts_host, doc_ids)]))
+    q16 = rng.standard_normal((5, 840))
+    for metric in ("sqeuclidean_dist", "cosine_sim", "inner_product", "euclidean_dist"):
+        for got, want in zip(composed.search(q16, 10, metric), whole.search(q16, 10, metric)):
+            np.testing.assert_array_equal(got, want)
+    for blk in blocks:
+        blk.close()  # blocks are copied at composition: the index outlives them
+    for got, want in zip(composed.search(q16, 10, "cosine_sim"), whole.search(q16, 10, "cosine_sim")):
+        np.testing.assert_array_equal(got, want)
+    with pytest.raises(ValueError):
+        DeviceIndex.from_rows([DeviceRows.from_host(np.zeros((2, 8), np.float32)), DeviceRows.from_host(np.zeros((2, 9), np.float32))])
