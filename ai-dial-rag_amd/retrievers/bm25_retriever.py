@@ -120,6 +120,39 @@ def _build_text_index_chunks(chunks, preprocess: Callable[[str], List[str]]) -> 
     return [TextIndexItem(chunk_index=i, tokenized_text=preprocess(chunk.text)) for i, chunk in enumerate(chunks)]
 
 
+# str -> term id for every token this process has indexed (ids are dense in first-seen order; never reused)
+_VOCAB: Dict[Hashable, int] = {}
+_VOCAB_LOCK = threading.Lock()
+
+
+def _doc_token_ids(text_index) -> Tuple[Tuple[np.ndarray, np.ndarray, np.ndarray], int]:
+    """One document's `text_index` -> ((chunk_index i64[c], token count i64[c], term ids i32[tokens]), bytes held)."""
+    chunk = np.fromiter((item.chunk_index for item in text_index), np.int64, len(text_index))
+    lens = np.fromiter((len(item.tokenized_text) for item in text_index), np.int64, len(text_index))
+    ids = np.empty(int(lens.sum()), np.int32)
+    pos = 0
+    with _VOCAB_LOCK:
+        look = _VOCAB.setdefault
+        for item in text_index:
+            for t in item.tokenized_text:
+                ids[pos] = look(t, len(_VOCAB))
+                pos += 1
+    return (chunk, lens, ids), chunk.nbytes + lens.nbytes + ids.nbytes
+
+
+class _FlatIndexTable:
+    """flat chunk number -> (doc_index, chunk_index), the reference's `text_indexes` list held as two arrays."""
+
+    def __init__(self, doc_of: np.ndarray, chunk_of: np.ndarray):
+        self.doc_of, self.chunk_of = doc_of, chunk_of
+
+    def __len__(self):
+        return len(self.doc_of)
+
+    def __getitem__(self, i: int) -> Tuple[int, int]:
+        return int(self.doc_of[i]), int(self.chunk_of[i])
+
+
 class BM25Retriever:
     """bm25_retriever.py:42-114 (langchain BaseRetriever upstream; the retrieval methods keep their names)."""
 
@@ -151,30 +184,31 @@ class BM25Retriever:
     @classmethod
     def from_doc_records(cls, doc_records, k: int = 4, device: int = 0,
                          preprocess: Optional[Callable[[str], List[str]]] = None) -> "BM25Retriever":
-        # bm25_retriever.py:64-79.  The model (postings in HBM, vocabulary, flat index -> (doc, chunk) table) is
-        # shared across requests that hand over the same text_index objects (retrievers/_device_cache.py);
-        # the reference rebuilds BM25Okapi from scratch in every request.
-        def build():
-            text_indexes, lens, flat = [], [], []
-            vocab: Dict[Hashable, int] = {}
-            for i, item in cls._get_text_index_gen(doc_records):
-                text_indexes.append((i, item.chunk_index))
-                toks = item.tokenized_text
-                lens.append(len(toks))
-                for t in toks:
-                    flat.append(vocab.setdefault(t, len(vocab)))
-            if sum(lens) == 0:
-                raise ValueError("Text index is empty.")
-            indptr = np.zeros(len(lens) + 1, np.int64)
-            indptr[1:] = np.cumsum(lens)
-            bm25 = DeviceBM25.from_token_ids(indptr, np.asarray(flat, np.int32), max(1, len(vocab)), device=device)
-            return (text_indexes, bm25, vocab), bm25.info()["hbm_bytes"]
-
+        # bm25_retriever.py:64-79.  The reference rebuilds BM25Okapi from scratch in every request (a Python loop
+        # over every token of every document).  Here three things outlive the request (retrievers/_device_cache.py):
+        # the model of a given tuple of documents (postings in HBM); every document's token-id arrays, so that a
+        # NEW combination of known documents costs one concatenate + mir_bm25_create and no per-token Python; and
+        # the process-wide str -> term-id vocabulary those arrays are written in.  Term ids a corpus does not use
+        # have no postings and are left out of the idf average by mir_bm25_create, exactly as absent dict keys are.
         from ._device_cache import CACHE
 
+        def build():
+            docs = [(i, CACHE.get_or_build("bm25doc", -1, [doc.text_index], lambda d=doc: _doc_token_ids(d.text_index)))
+                    for i, doc in enumerate(doc_records) if doc.text_index is not None]
+            lens = np.concatenate([p[1] for _, p in docs]) if docs else np.zeros(0, np.int64)
+            if int(lens.sum()) == 0:
+                raise ValueError("Text index is empty.")
+            doc_of = np.concatenate([np.full(len(p[0]), i, np.int64) for i, p in docs])
+            chunk_of = np.concatenate([p[0] for _, p in docs])
+            indptr = np.zeros(len(lens) + 1, np.int64)
+            np.cumsum(lens, out=indptr[1:])
+            ids = np.concatenate([p[2] for _, p in docs])
+            bm25 = DeviceBM25.from_token_ids(indptr, ids, max(1, len(_VOCAB)), device=device)
+            return (_FlatIndexTable(doc_of, chunk_of), bm25), bm25.info()["hbm_bytes"]
+
         sources = [doc.text_index for doc in doc_records]  # None entries included: they shape the doc numbering
-        text_indexes, bm25, vocab = CACHE.get_or_build("bm25", device, sources, build)
-        return cls(text_indexes=text_indexes, k=k, bm25=bm25, vocab=vocab, preprocess=preprocess)
+        text_indexes, bm25 = CACHE.get_or_build("bm25", device, sources, build)
+        return cls(text_indexes=text_indexes, k=k, bm25=bm25, vocab=_VOCAB, preprocess=preprocess)
 
     def _ids(self, tokens: Sequence[Hashable]) -> List[int]:
         return [self.vocab.get(t, -1) for t in tokens]

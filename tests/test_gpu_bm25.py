@@ -38,8 +38,9 @@ def test_small_corpus_scores_and_topn(br):
     o = ob.build(CORPUS)
     info = r.bm25.info()
     assert info["n_docs"] == 5 and info["avgdl"] == o.avgdl and info["average_idf"] == o.average_idf
-    for w, i in r.vocab.items():
-        assert r.bm25.idf()[i] == o.idf[w]
+    idf = r.bm25.idf()
+    for w, v in o.idf.items():  # r.vocab is process-wide: it also knows words of other corpora (no postings here)
+        assert idf[r.vocab[w]] == v
     for q in (["windy", "london", "nope", "london"], ["is"], ["absent"], [], ["london"], ["is", "is", "hello"]):
         got = r.bm25.get_scores(r._ids(q))
         np.testing.assert_array_equal(got, o.get_scores(q))
@@ -278,3 +279,41 @@ def test_concurrent_retriever_calls_share_passes(br):
     [t.join() for t in th]
     assert got == want
     assert gc.passes - passes0 < 96
+
+
+def test_new_document_combination_reuses_token_ids(br):
+    """A model over a NEW combination of documents whose token lists were seen before does no per-token Python:
+    every document's term-id arrays are cached (kind "bm25doc") in a process-wide vocabulary.  Term ids the
+    combination does not use must not disturb idf / average_idf: scores stay bit-identical to rank-bm25's."""
+    from aidial_rag_amd.retrievers import _device_cache as dc
+
+    rng = np.random.default_rng(5)
+    words = [f"t{i}" for i in range(400)]
+
+    def doc(n, lo, hi):
+        return [[words[j] for j in rng.integers(lo, hi, rng.integers(0, 30))] for _ in range(n)]
+
+    a, b, c = Rec(doc(60, 0, 200)), Rec(doc(5, 100, 400)), Rec(doc(90, 150, 300))
+    dc.CACHE.clear()
+    base = list(dc.CACHE.by_kind.get("bm25doc", [0, 0]))
+    delta = lambda: [x - y for x, y in zip(dc.CACHE.by_kind["bm25doc"], base)]
+
+    def check(recs):
+        r = br.BM25Retriever.from_doc_records(recs, k=6, preprocess=str.split)
+        corpus = [item.tokenized_text for rec in recs if rec.text_index is not None for item in rec.text_index]
+        o = ob.build(corpus)
+        info = r.bm25.info()
+        assert info["n_docs"] == len(corpus) and info["avgdl"] == o.avgdl and info["average_idf"] == o.average_idf
+        for q in (["t150", "t160", "t1"], ["t399"], ["t250", "t250", "t120"], ["never"], ["t5", "t180"]):
+            np.testing.assert_array_equal(r.bm25.get_scores(r._ids(q)), o.get_scores(q))
+            np.testing.assert_array_equal(r._get_top_n_indexes(q, 6), ob.top_n_indexes(o.get_scores(q), 6))
+        return r
+
+    check([a, b])
+    assert delta() == [0, 2]
+    r2 = check([c, Rec(None), a])  # a's ids come from the cache; c brings words a and b never had
+    assert delta() == [1, 3]
+    check([b, c])                  # nothing new at all
+    assert delta() == [3, 3]
+    docs = r2._get_relevant_documents("t299")
+    assert docs and all(d.metadata["doc_id"] in (0, 2) for d in docs)

@@ -143,20 +143,25 @@ def test_indexes_survive_across_requests():
 
     recs = [Rec(300), Rec(200)]
     dc.CACHE.clear()
-    m0, h0 = dc.CACHE.misses, dc.CACHE.hits
+    kinds = ("vector", "rows", "bm25", "bm25doc")
+    base = {k: list(dc.CACHE.by_kind.get(k, [0, 0])) for k in kinds}
+    stat = lambda: {k: [x - y for x, y in zip(dc.CACHE.by_kind.get(k, [0, 0]), base[k])] for k in kinds}  # [hits, misses]
     q = rng.standard_normal(384)
     s1 = SemanticRetriever.from_doc_records(recs, k=5)
     r1 = s1._find_relevant_documents(q)
     b1 = BM25Retriever.from_doc_records(recs, k=4, preprocess=str.split)
     k1 = b1._get_relevant_documents("w1 w7 w9")
-    assert dc.CACHE.misses - m0 == 4 and dc.CACHE.hits - h0 == 0  # vector index + its two row blocks + BM25 model
+    # first sight: the vector index and its two row blocks, the BM25 model and the two documents' token-id arrays
+    assert stat() == {"vector": [0, 1], "rows": [0, 2], "bm25": [0, 1], "bm25doc": [0, 2]}
     s2 = SemanticRetriever.from_doc_records(recs, k=5)
     b2 = BM25Retriever.from_doc_records(recs, k=4, preprocess=str.split)
     assert s2._find_relevant_documents(q) == r1 and b2._get_relevant_documents("w1 w7 w9") == k1
-    assert dc.CACHE.hits - h0 == 2 and s2.index._device_index() is s1.index._device_index() and b2.bm25 is b1.bm25
+    assert s2.index._device_index() is s1.index._device_index() and b2.bm25 is b1.bm25
+    assert stat() == {"vector": [1, 1], "rows": [0, 2], "bm25": [1, 1], "bm25doc": [0, 2]}  # nothing below the top level is touched
     other = [Rec(100)]
     s3 = SemanticRetriever.from_doc_records(other, k=5)
-    assert s3.index._device_index() is not s1.index._device_index() and dc.CACHE.misses - m0 == 6  # index + one row block
+    assert s3.index._device_index() is not s1.index._device_index()
+    assert stat()["vector"] == [1, 2] and stat()["rows"] == [0, 3]
     # a tiny budget keeps only the most recent entry; evicted indexes stay valid for whoever still holds them
     small = dc.DeviceCache(budget_bytes=1)
     a = small.get_or_build("x", 0, [recs[0]], lambda: ("A", 10))
