@@ -824,6 +824,26 @@ int32_t mir_bm25_create(const int64_t *indptr, const int32_t *term_ids, int64_t 
     return MIR_OK;
 }
 
+// Host utility for callers that keep term ids in a vocabulary LARGER than one corpus (a process-wide one):
+// rewrites ids[n] to 0..n_used-1 in order of first appearance and fills remap[vocab] (old id -> new id, -1 =
+// not in this corpus).  The per-term tables of a model are sized by its vocab, so a corpus is compacted first.
+int32_t mir_compact_term_ids(const int32_t *ids, int64_t n, int32_t vocab, int32_t *out_ids, int32_t *remap,
+                             int32_t *n_used) {
+    MIR_REQUIRE(vocab >= 0 && n >= 0 && remap != nullptr && n_used != nullptr, "bad argument");
+    MIR_REQUIRE(n == 0 || (ids != nullptr && out_ids != nullptr), "NULL id buffer");
+    for (int32_t t = 0; t < vocab; ++t) remap[t] = -1;
+    int32_t next = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        const int32_t t = ids[j];
+        MIR_REQUIRE(t >= 0 && t < vocab, "term id %d at %lld outside [0, %d)", t, (long long)j, vocab);
+        int32_t c = remap[t];
+        if (c < 0) c = remap[t] = next++;
+        out_ids[j] = c;
+    }
+    *n_used = next;
+    return MIR_OK;
+}
+
 int32_t mir_bm25_destroy(mir_bm25 *h) {
     free_bm25(h);
     return MIR_OK;

@@ -157,11 +157,12 @@ class BM25Retriever:
     """bm25_retriever.py:42-114 (langchain BaseRetriever upstream; the retrieval methods keep their names)."""
 
     def __init__(self, text_indexes: List[Tuple[int, int]], k: int, bm25: DeviceBM25, vocab: Dict[Hashable, int],
-                 preprocess: Optional[Callable[[str], List[str]]] = None):
+                 preprocess: Optional[Callable[[str], List[str]]] = None, remap: Optional[np.ndarray] = None):
         self.text_indexes = text_indexes  # flat index -> (doc_index, chunk_index)
         self.k = k
         self.bm25 = bm25
         self.vocab = vocab
+        self._remap = remap  # vocabulary id -> this model's term id (-1: not in this corpus); None = identity
         self._preprocess = preprocess
         # concurrent single-query calls (bm25_retriever.py:102-104 runs them on executor threads) share passes;
         # one pass serves up to 512 queries, grouped by the n they ask for
@@ -188,8 +189,8 @@ class BM25Retriever:
         # over every token of every document).  Here three things outlive the request (retrievers/_device_cache.py):
         # the model of a given tuple of documents (postings in HBM); every document's token-id arrays, so that a
         # NEW combination of known documents costs one concatenate + mir_bm25_create and no per-token Python; and
-        # the process-wide str -> term-id vocabulary those arrays are written in.  Term ids a corpus does not use
-        # have no postings and are left out of the idf average by mir_bm25_create, exactly as absent dict keys are.
+        # the process-wide str -> term-id vocabulary those arrays are written in (compacted per model to the ids
+        # the corpus uses, in first-appearance order = the order of rank-bm25's dicts: mir_compact_term_ids).
         from ._device_cache import CACHE
 
         def build():
@@ -203,15 +204,30 @@ class BM25Retriever:
             indptr = np.zeros(len(lens) + 1, np.int64)
             np.cumsum(lens, out=indptr[1:])
             ids = np.concatenate([p[2] for _, p in docs])
-            bm25 = DeviceBM25.from_token_ids(indptr, ids, max(1, len(_VOCAB)), device=device)
-            return (_FlatIndexTable(doc_of, chunk_of), bm25), bm25.info()["hbm_bytes"]
+            # the model's per-term tables are sized by its vocabulary: compact the process-wide ids to this corpus
+            remap = np.empty(int(ids.max()) + 1, np.int32)
+            used = C.c_int32()
+            nat.check(nat.lib.mir_compact_term_ids(nat.ptr(ids), len(ids), len(remap), nat.ptr(ids), nat.ptr(remap), C.byref(used)))
+            bm25 = DeviceBM25.from_token_ids(indptr, ids, max(1, used.value), device=device)
+            return (_FlatIndexTable(doc_of, chunk_of), bm25, remap), bm25.info()["hbm_bytes"]
 
         sources = [doc.text_index for doc in doc_records]  # None entries included: they shape the doc numbering
-        text_indexes, bm25 = CACHE.get_or_build("bm25", device, sources, build)
-        return cls(text_indexes=text_indexes, k=k, bm25=bm25, vocab=_VOCAB, preprocess=preprocess)
+        text_indexes, bm25, remap = CACHE.get_or_build("bm25", device, sources, build)
+        return cls(text_indexes=text_indexes, k=k, bm25=bm25, vocab=_VOCAB, preprocess=preprocess, remap=remap)
 
     def _ids(self, tokens: Sequence[Hashable]) -> List[int]:
-        return [self.vocab.get(t, -1) for t in tokens]
+        if self._remap is None:
+            return [self.vocab.get(t, -1) for t in tokens]
+        rm, n = self._remap, len(self._remap)
+        out = []
+        for t in tokens:
+            g = self.vocab.get(t, -1)
+            out.append(int(rm[g]) if 0 <= g < n else -1)
+        return out
+
+    def term_id(self, token: Hashable) -> int:
+        """This model's id of a token, -1 if the corpus does not have it."""
+        return self._ids([token])[0]
 
     def _get_top_n_indexes(self, query: List[str], n: int = 5) -> np.ndarray:
         # bm25_retriever.py:81-84

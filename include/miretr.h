@@ -192,6 +192,12 @@ typedef struct mir_bm25 mir_bm25;
 int32_t mir_bm25_create(const int64_t *indptr_host, const int32_t *term_ids_host, int64_t n_docs, int32_t vocab,
                         double k1, double b, double epsilon, const double *idf_override_host,
                         double avgdl_override, int32_t device, int64_t doc_offset, mir_bm25 **out);
+/* Host utility: term ids written in a vocabulary larger than this corpus (e.g. a process-wide str -> id map
+ * shared by every document the process has tokenised) -> ids 0..n_used-1 in order of first appearance, which is
+ * the order rank-bm25's dicts would have (bm25_retriever.py:78).  remap[vocab]: old id -> new id or -1. */
+int32_t mir_compact_term_ids(const int32_t *ids, int64_t n, int32_t vocab, int32_t *out_ids, int32_t *remap,
+                             int32_t *n_used);
+
 int32_t mir_bm25_destroy(mir_bm25 *h);
 int32_t mir_bm25_info(const mir_bm25 *h, int64_t *n_docs, int32_t *vocab, int64_t *n_postings, double *avgdl,
                       double *average_idf, int64_t *hbm_bytes);

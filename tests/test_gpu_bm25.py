@@ -39,8 +39,9 @@ def test_small_corpus_scores_and_topn(br):
     info = r.bm25.info()
     assert info["n_docs"] == 5 and info["avgdl"] == o.avgdl and info["average_idf"] == o.average_idf
     idf = r.bm25.idf()
-    for w, v in o.idf.items():  # r.vocab is process-wide: it also knows words of other corpora (no postings here)
-        assert idf[r.vocab[w]] == v
+    assert len(idf) == len(o.idf)  # r.vocab is process-wide; the model's own term ids cover exactly this corpus
+    for w, v in o.idf.items():
+        assert idf[r.term_id(w)] == v
     for q in (["windy", "london", "nope", "london"], ["is"], ["absent"], [], ["london"], ["is", "is", "hello"]):
         got = r.bm25.get_scores(r._ids(q))
         np.testing.assert_array_equal(got, o.get_scores(q))
