@@ -74,6 +74,7 @@ def _load():
         "mir_topk_merge_host": ([vp, vp, vp, i32, i64, i32, i32, i32, vp, vp, vp], i32),
         "mir_bm25_create": ([vp, vp, i64, i32, C.c_double, C.c_double, C.c_double, vp, C.c_double, i32, i64, vp], i32),
         "mir_compact_term_ids": ([vp, i64, i32, vp, vp, vp], i32),
+        "mir_stem_english": ([vp, i64, C.c_char, vp, vp], i32),
         "mir_bm25_destroy": ([vp], i32),
         "mir_bm25_info": ([vp, vp, vp, vp, vp, vp, vp], i32),
         "mir_bm25_idf": ([vp, vp], i32),

@@ -192,6 +192,13 @@ typedef struct mir_bm25 mir_bm25;
 int32_t mir_bm25_create(const int64_t *indptr_host, const int32_t *term_ids_host, int64_t n_docs, int32_t vocab,
                         double k1, double b, double epsilon, const double *idf_override_host,
                         double avgdl_override, int32_t device, int64_t doc_offset, mir_bm25 **out);
+/* Host utility: Snowball-English stems of a batch of lower-cased tokens - the per-token step of
+ * keywords_preprocess (aidial_rag/keywords_search.py:13-18, `stemmer.stem(t.lower())`), pure Python in the
+ * reference and the CPU hot spot of its index build (bm25_retriever.py:30-39,112).  Follows NLTK's
+ * EnglishStemmer including its quirks (csrc/stem_english.cpp).  tokens: n_bytes of UTF-8 separated by `sep`
+ * (no trailing separator); out: >= n_bytes bytes, receives the stems in the same form. */
+int32_t mir_stem_english(const char *tokens, int64_t n_bytes, char sep, char *out, int64_t *out_bytes);
+
 /* Host utility: term ids written in a vocabulary larger than this corpus (e.g. a process-wide str -> id map
  * shared by every document the process has tokenised) -> ids 0..n_used-1 in order of first appearance, which is
  * the order rank-bm25's dicts would have (bm25_retriever.py:78).  remap[vocab]: old id -> new id or -1. */
