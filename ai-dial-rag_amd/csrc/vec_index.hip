@@ -145,6 +145,20 @@ static void free_index(mir_index *ix) {
 }
 
 // Build the derived device state from ix->d_orig (already filled) on `stream`.
+// doc_sq / inv_norm / max norm: rows staged through LDS when at least 8 of them fit, else one thread per row
+template <typename T>
+static void launch_row_norms(const T *src, int64_t n, int d, mir_index *ix, hipStream_t stream) {
+    unsigned int *mx = reinterpret_cast<unsigned int *>(ix->d_maxnorm);
+    const int rows_per_wg = std::min<int64_t>(128, kNormsLdsBytes / ((int64_t)norms_row_stride(d) * 4));
+    if (rows_per_wg >= 8) {
+        const size_t lds = (size_t)rows_per_wg * norms_row_stride(d) * 4;
+        row_norms_lds_kernel<T><<<dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)), dim3(256), lds, stream>>>(
+            src, n, d, rows_per_wg, ix->d_docsq, ix->d_invnorm, mx);
+    } else {
+        row_norms_kernel<T><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(src, n, d, ix->d_docsq, ix->d_invnorm, mx);
+    }
+}
+
 static int32_t build_derived(mir_index *ix, hipStream_t stream) {
     const int64_t n = ix->n;
     const int d = ix->d;
@@ -168,14 +182,12 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
             pack_f16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(ix->d_f16, n, d, ix->ksteps, total_lanes,
                                                                             ix->d_split);
             MIR_HIP(hipGetLastError());
-            row_norms_kernel<_Float16><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(
-                ix->d_f16, n, d, ix->d_docsq, ix->d_invnorm, reinterpret_cast<unsigned int *>(ix->d_maxnorm));
+            launch_row_norms(ix->d_f16, n, d, ix, stream);
         } else {
             pack_split_f32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ksteps,
                                                                                   total_lanes, ix->d_split);
             MIR_HIP(hipGetLastError());
-            row_norms_kernel<float><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(
-                ix->d_orig, n, d, ix->d_docsq, ix->d_invnorm, reinterpret_cast<unsigned int *>(ix->d_maxnorm));
+            launch_row_norms(ix->d_orig, n, d, ix, stream);
         }
         MIR_HIP(hipGetLastError());
     }

@@ -168,6 +168,23 @@ __device__ inline float np_pairwise_sq(const T *a, int n) {
     }
 }
 
+// sum of squares in float64, strictly left to right; the loads of 16 elements are issued together (written as
+// one load per add, hipcc waits for each: ~150 cycles per element, 5.4 ms per 2.5M x 384 rows)
+template <typename T>
+__device__ __forceinline__ double seq_sum_sq_f64(const T *a, int d) {
+    double s = 0.0;
+    int j = 0;
+    for (; j + 16 <= d; j += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (float)a[j + u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += (double)v[u] * (double)v[u];
+    }
+    for (; j < d; ++j) s += (double)a[j] * (double)a[j];
+    return s;
+}
+
 // One thread per row: doc_sq (f32, numpy order), inv_norm = 1/max(|d|, 1e-8),
 // and the running maximum row norm (for the scan's error bound).
 // T = float, or _Float16 (a float16 index: the reference up-casts to float32 first, so the values
@@ -182,13 +199,67 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const T *__restrict__ sr
     if (row < n) {
         const T *a = src + row * (int64_t)d;
         doc_sq[row] = np_pairwise_sq<12>(a, d);
-        double s = 0.0;
-        for (int j = 0; j < d; ++j) s += (double)a[j] * (double)a[j];
+        const double s = seq_sum_sq_f64(a, d);
         nrm = (float)sqrt(s);
         nrm = nrm * (1.0f + 1e-6f);  // round up: used as an upper bound
         inv_norm[row] = 1.0f / fmaxf((float)sqrt(s), 1e-8f);
     }
     // wave max, then one atomic per wave (positive floats order as uints)
+    for (int off = 32; off >= 1; off >>= 1) nrm = fmaxf(nrm, __shfl_xor(nrm, off, 64));
+    if ((threadIdx.x & 63) == 0 && nrm > 0.f) atomicMax(max_norm_bits, __float_as_uint(nrm));
+}
+
+// The same per-row arithmetic with the rows staged through LDS: a workgroup copies `rows_per_wg` consecutive rows
+// (one contiguous piece of HBM, read coalesced by all 256 threads), then thread r sums row r out of LDS (row
+// stride odd in banks: no conflicts).  One thread per row straight from HBM reads every row as its own stream of
+// cache lines and reaches ~0.7 TB/s; this form is bound by the copy.  LDS holds float32 whatever T is (the
+// float16 -> float32 conversion is exact and is what the direct kernel feeds its sums too).
+constexpr int kNormsLdsBytes = 64 * 1024;  // two workgroups per CU
+__host__ __device__ inline int norms_row_stride(int d) { return d | 1; }
+template <typename T>
+__global__ __launch_bounds__(256) void row_norms_lds_kernel(const T *__restrict__ src, int64_t n, int d, int rows_per_wg,
+                                                            float *__restrict__ doc_sq, float *__restrict__ inv_norm,
+                                                            unsigned int *__restrict__ max_norm_bits) {
+    extern __shared__ float norms_lds[];
+    const int stride = norms_row_stride(d);
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int rows = (int)(n - row0 < rows_per_wg ? n - row0 : rows_per_wg);
+    const T *base = src + row0 * (int64_t)d;
+    // the rows are one contiguous piece of `total` elements; 16 loads in flight per thread (a load per LDS store
+    // is waited for one by one: 84 exposed HBM round trips per workgroup)
+    const int total = rows * d;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 16) {
+        T v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = e0 + 256 * u;
+            v[u] = e < total ? base[e] : T(0);
+        }
+        int r = e0 / d, c = e0 - r * d;  // one division per batch, then (row, column) advance by 256 elements
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (e0 + 256 * u < total) norms_lds[r * stride + c] = (float)v[u];
+            c += 256;
+            while (c >= d) { c -= d; ++r; }
+        }
+    }
+    __syncthreads();
+    // the two sums of a row are independent: threads [0, rows) of the first half of the workgroup take the float32
+    // pairwise sum, threads [128, 128 + rows) the float64 one (rows <= 128 by construction of rows_per_wg)
+    float nrm = 0.f;
+    const int rt = threadIdx.x & 127;
+    if (rt < rows) {
+        const float *a = norms_lds + rt * stride;
+        const int64_t row = row0 + rt;
+        if (threadIdx.x < 128) {
+            doc_sq[row] = np_pairwise_sq<12>(a, d);
+        } else {
+            const double s = seq_sum_sq_f64(a, d);
+            nrm = (float)sqrt(s);
+            nrm = nrm * (1.0f + 1e-6f);
+            inv_norm[row] = 1.0f / fmaxf((float)sqrt(s), 1e-8f);
+        }
+    }
     for (int off = 32; off >= 1; off >>= 1) nrm = fmaxf(nrm, __shfl_xor(nrm, off, 64));
     if ((threadIdx.x & 63) == 0 && nrm > 0.f) atomicMax(max_norm_bits, __float_as_uint(nrm));
 }
