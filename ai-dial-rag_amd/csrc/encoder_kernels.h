@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256, 1) void oproj_ln_kernel(const uint4 *__restric
 // MFMAs they are written next to.  The sched_group_barrier pattern below ASKS hipcc for
 // {1 ds_read, 1 MFMA, 7 VALU}; the ISA it emits still clusters most of the GELU ahead of the MFMAs
 // (in-kernel stamps: first phase 2.1K cycles for 0.77K cycles of MFMA), so the two are largely
-// serialised.  Fixing the order needs the stage as inline asm - not done yet.
+// serialised.  Forcing the order with the stage as inline asm (one GELU slice per MFMA gap) was built and
+// measured: no faster (the dependent VALU chains stretch each gap), see DESIGN.md 4b.
 constexpr int FFN_HALF_BYTES = 24 * 1024;
 constexpr int FFN_STAGE_BYTES = 2 * FFN_HALF_BYTES;
 constexpr int FFN_PARAM_FLOATS = FF + 3 * H;  // b1 | b2 | gamma | beta
