@@ -439,14 +439,16 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                               int ngroups, int nwg, int klist, int qpw, int32_t *o_doc, int64_t *o_chunk, int64_t *o_row,
                               double *o_dist, int32_t *o_count, int32_t *o_flags, hipStream_t stream) {
     const int d = ix->d;
-    if (qpw != 32) MIR_HIP(hipMemsetAsync(sb.gthr, 0, (size_t)ngroups * 128 * 8, stream));
     const int ntiles32 = ngroups * (qpw / 32);  // 32-query fragment tiles, padded to whole launches
+    unsigned long long *gz = qpw != 32 ? reinterpret_cast<unsigned long long *>(sb.gthr) : nullptr;
+    const int gwords = ngroups * 128;  // zeroed by the first gwords/64 blocks of the prep kernel
+    MIR_REQUIRE(gwords <= 64 * (ntiles32 * ix->ksteps + b), "threshold table larger than the prep grid");
     if (ix->native16)
         prep_queries_f16_kernel<<<dim3(ntiles32 * ix->ksteps + b), dim3(64), 0, stream>>>(
-            dq, b, d, ix->ksteps, ntiles32, sb.qsplit, sb.q_sq, sb.q_norm, sb.qscale);
+            dq, b, d, ix->ksteps, ntiles32, sb.qsplit, sb.q_sq, sb.q_norm, sb.qscale, gz, gwords);
     else
         prep_queries_kernel<<<dim3(ntiles32 * ix->ksteps + b), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, ntiles32,
-                                                                                    sb.qsplit, sb.q_sq, sb.q_norm);
+                                                                                    sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords);
     MIR_HIP(hipGetLastError());
     for (int g = 0; g < ngroups; ++g) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1035,7 +1037,7 @@ int32_t mir_index_metric_eval(mir_index *idx, const double *query_host, int32_t 
     hipError_t e = hipMemcpyAsync(dq, query_host, (size_t)d * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         // ngroups = 0: only the per-query norm block runs
-        prep_queries_kernel<<<dim3(1), dim3(64), 0, s>>>(dq, 1, d, idx->ksteps, 0, nullptr, dsq, dnm);
+        prep_queries_kernel<<<dim3(1), dim3(64), 0, s>>>(dq, 1, d, idx->ksteps, 0, nullptr, dsq, dnm, nullptr, 0);
         if (idx->native16)
             metric_eval_kernel<_Float16><<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(idx->d_f16, idx->d_docsq, n, d,
                                                                                             dq, dsq, dnm, metric, dout);

@@ -272,9 +272,12 @@ __global__ __launch_bounds__(256) void row_norms_lds_kernel(const T *__restrict_
 __global__ __launch_bounds__(64) void prep_queries_kernel(const double *__restrict__ q, int b, int d, int ksteps,
                                                           int ngroups, uint4 *__restrict__ qsplit,
                                                           double *__restrict__ q_sq,
-                                                          double *__restrict__ q_norm) {
+                                                          double *__restrict__ q_norm,
+                                                          unsigned long long *__restrict__ gthr, int gthr_words) {
     int lane = threadIdx.x;
     int blk = blockIdx.x;
+    // starting thresholds of the wide scans: zero = none (was a separate memset node, ~10 us of dependent launch)
+    if (gthr && blk * 64 + lane < gthr_words) gthr[blk * 64 + lane] = 0;
     if (blk < ngroups * ksteps) {
         int s = blk % ksteps;
         int g = blk / ksteps;
@@ -979,23 +982,57 @@ template <typename T>
 __device__ __forceinline__ double exact_metric_wave(const T *__restrict__ row, const double *__restrict__ q,
                                                     int d, int metric, float doc_sq32, double q_sq,
                                                     double q_norm, int lane, double *rank_value) {
+    // Lane l takes elements l, l + 64, ... in that order.  Eight of them are loaded before the first is used:
+    // written load-by-use, every element of a (cold) row was its own exposed HBM round trip.
+    constexpr int U = 8;
     if (metric == MIR_METRIC_COSINE_SIM) {
         double s = 0.0;
-        for (int j = lane; j < d; j += 64) {
-            double x = (double)(float)row[j];
-            s += x * x;
+        for (int j0 = lane; j0 < d; j0 += 64 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = j0 + 64 * u < d ? (float)row[j0 + 64 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (j0 + 64 * u < d) {
+                    const double x = (double)v[u];
+                    s += x * x;
+                }
         }
         s = wave_sum(s);
         const float dn = fmaxf((float)sqrt(s), 1e-8f);
         const double qn = fmax(q_norm, 1e-8);
         double c = 0.0;
-        for (int j = lane; j < d; j += 64) c += (double)__fdiv_rn((float)row[j], dn) * (q[j] / qn);
+        for (int j0 = lane; j0 < d; j0 += 64 * U) {
+            float v[U];
+            double qv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = j0 + 64 * u < d;
+                v[u] = in ? (float)row[j0 + 64 * u] : 0.f;
+                qv[u] = in ? q[j0 + 64 * u] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (j0 + 64 * u < d) c += (double)__fdiv_rn(v[u], dn) * (qv[u] / qn);
+        }
         c = wave_sum(c);
         *rank_value = c * qn;
         return -c;
     }
     double dot = 0.0;
-    for (int j = lane; j < d; j += 64) dot += (double)(float)row[j] * q[j];
+    for (int j0 = lane; j0 < d; j0 += 64 * U) {
+        float v[U];
+        double qv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool in = j0 + 64 * u < d;
+            v[u] = in ? (float)row[j0 + 64 * u] : 0.f;
+            qv[u] = in ? q[j0 + 64 * u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (j0 + 64 * u < d) dot += (double)v[u] * qv[u];
+    }
     dot = wave_sum(dot);
     if (metric == MIR_METRIC_INNER_PRODUCT) {
         *rank_value = dot;
@@ -1059,13 +1096,19 @@ __device__ inline void bitonic_sort_desc(uint64_t *keys, int n, int tid) {
 // carry the row), 0 = empty.  out[0..klist) receives the keys, best first, 0-padded.
 __device__ inline void merge_sorted_lists(const uint64_t *__restrict__ lists, size_t list_stride, int nwg, int klist,
                                           uint64_t *out, uint64_t *red /*[4]*/, int tid) {
+    // cur = head of each owned list; n1, n2 = the two entries behind it, fetched up front with it (one round
+    // trip for all 12 loads).  A load issued inside the loop is waited for at the next barrier by everybody, a
+    // round trip per round; with 256 lists a list rarely gives more than three of the best klist.
     int head[4];
-    uint64_t cur[4];
+    uint64_t cur[4], n1[4], n2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int wg = tid + 256 * j;
+        const uint64_t *l = lists + (size_t)wg * list_stride;
         head[j] = 0;
-        cur[j] = wg < nwg ? lists[(size_t)wg * list_stride] : 0;
+        cur[j] = wg < nwg ? l[0] : 0;
+        n1[j] = (wg < nwg && klist > 1) ? l[1] : 0;
+        n2[j] = (wg < nwg && klist > 2) ? l[2] : 0;
     }
     for (int r = 0; r < klist; ++r) {
         uint64_t mine = cur[0];
@@ -1090,7 +1133,9 @@ __device__ inline void merge_sorted_lists(const uint64_t *__restrict__ lists, si
             for (int j = 0; j < 4; ++j) {
                 if (cur[j] == best) {
                     ++head[j];
-                    cur[j] = head[j] < klist ? lists[(size_t)(tid + 256 * j) * list_stride + head[j]] : 0;
+                    if (head[j] == 1) cur[j] = n1[j];
+                    else if (head[j] == 2) cur[j] = n2[j];
+                    else cur[j] = head[j] < klist ? lists[(size_t)(tid + 256 * j) * list_stride + head[j]] : 0;
                 }
             }
         }
@@ -1219,21 +1264,25 @@ __global__ __launch_bounds__(256) void sample_threshold_kernel(const float *__re
         if (e < n) v = part[((size_t)(e >> 1) * qpw + q) * 2 + (e & 1)];
         vals[e] = (v == v) ? v : -__builtin_inff();
     }
-    if (tid == 0) thr = -__builtin_inff();
-    __syncthreads();
-    for (int e = tid; e < n; e += 256) {
-        const float v = vals[e];
-        int gt = 0, ge = 0;
-        for (int u = 0; u < kMaxVals; u += 4) {
-            const float4 w = *reinterpret_cast<const float4 *>(vals + u);
-            gt += (w.x > v) + (w.y > v) + (w.z > v) + (w.w > v);
-            ge += (w.x >= v) + (w.y >= v) + (w.z >= v) + (w.w >= v);
+    // bitonic sort, descending, one compare-exchange per thread and step (45 steps of ~100 cycles; counting, for
+    // every value, how many of the 512 are greater took three times as long)
+    for (int size = 2; size <= kMaxVals; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            const int lo = 2 * tid - (tid & (stride - 1)), hi = lo + stride;
+            const bool desc = (lo & size) == 0;
+            const float x = vals[lo], y = vals[hi];
+            if ((x < y) == desc) {
+                vals[lo] = y;
+                vals[hi] = x;
+            }
         }
-        if (gt < klist && klist <= ge) thr = v;  // the tie group holding rank klist (one value)
-    }
     __syncthreads();
-    // lowest key of that value: still a lower bound whatever the row
-    if (tid == 0 && thr > -__builtin_inff()) gthr[q] = (unsigned long long)orderable(thr) << 32;
+    // the klist-th largest; the lowest key of that value is still a lower bound whatever the row
+    if (tid == 0 && klist <= kMaxVals) {
+        thr = vals[klist - 1];
+        if (thr > -__builtin_inff()) gthr[q] = (unsigned long long)orderable(thr) << 32;
+    }
 }
 
 // ---------------------------------------------------------------- shard merge

@@ -52,9 +52,11 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(const _Float16 *__restric
 __global__ __launch_bounds__(64) void prep_queries_f16_kernel(const double *__restrict__ q, int b, int d, int ksteps,
                                                               int ntiles32, uint4 *__restrict__ qfrag,
                                                               double *__restrict__ q_sq, double *__restrict__ q_norm,
-                                                              float *__restrict__ qscale_inv) {
+                                                              float *__restrict__ qscale_inv,
+                                                              unsigned long long *__restrict__ gthr, int gthr_words) {
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
+    if (gthr && blk * 64 + lane < gthr_words) gthr[blk * 64 + lane] = 0;  // as prep_queries_kernel
     auto scale_of = [&](int qi) {  // wave-uniform per query only in the second block kind; recomputed per lane here
         double m = 0.0;
         for (int j = 0; j < d; ++j) {

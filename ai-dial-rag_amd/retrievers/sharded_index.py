@@ -76,15 +76,20 @@ class ShardedSearcher:
             )
         return self._bufs[key]
 
-    def search(self, queries, k: int, metric="sqeuclidean_dist"):
+    def search(self, queries, k: int, metric="sqeuclidean_dist", out_flags=None):
         """queries: float64 [b, d] torch tensor on `self.device` (GPU path) or array-like (CPU path).
         Returns (dist[b,k] f64, rows[b,k] i64 global, count[b] i32, flags[b] i32) tensors; asynchronous on
-        the current stream on the GPU path."""
+        the current stream on the GPU path.  `out_flags` (GPU path): an int32 [b] tensor to receive this call's
+        flags instead of the searcher's own buffer, which the next call overwrites."""
         t = self.torch
         metric = Metric(metric).value
         b = int(queries.shape[0])
         off_row, off_cnt, size = _blob_layout(b, k)
         blob, gathered, o_dist, o_row, o_cnt, o_flags = self._buffers(b, k)
+        if out_flags is not None and self.on_gpu:
+            if out_flags.dtype != t.int32 or out_flags.numel() != b or not out_flags.is_contiguous():
+                raise ValueError("out_flags must be a contiguous int32 tensor of b elements")
+            o_flags = out_flags
         if self.on_gpu:
             stream = t.cuda.current_stream(self.device).cuda_stream
             base = blob.data_ptr()

@@ -237,9 +237,12 @@ def main():
 
     searcher = ShardedSearcher(local_index=index)
 
+    # every step's completeness flags land in their own row: no per-step reduction kernels inside the timed loop
+    flags_all = torch.zeros((max(args.warmup, 1) + args.steps, B), dtype=torch.int32, device=device)
+
     def step(i):
         s = (i * B) % (nq_pool - B + 1)
-        return searcher.search(queries[s : s + B], k, args.metric)
+        return searcher.search(queries[s : s + B], k, args.metric, out_flags=flags_all[i])
 
     def barrier():
         if world > 1:
@@ -247,22 +250,18 @@ def main():
         torch.cuda.synchronize()
 
     index.profile(True)  # before the warm-up: event creation is slow and must not be timed
-    flags_total = torch.zeros((), dtype=torch.int64, device=device)
-    for i in range(max(args.warmup, 1)):
-        # exactly the timed loop's body: torch loads each of its kernels lazily on first use
-        # (~70-90 ms once for the int32 sum / int64 add below), which must not land in the timed region
-        out = step(i)
-        flags_total += out[3].sum()
+    n_warm = max(args.warmup, 1)
+    for i in range(n_warm):
+        out = step(i)  # exactly the timed loop's body
     barrier()
     index.profile_read(reset=True)
-    flags_total.zero_()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(args.warmup + i)
-        flags_total += out[3].sum()
+        out = step(n_warm + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    flags_total = flags_all[n_warm:].sum(dtype=torch.int64).reshape(())
     index.profile(False)
     launches, scan_ms = index.profile_read(reset=True)
 
