@@ -145,12 +145,13 @@ static void free_index(mir_index *ix) {
 }
 
 // Build the derived device state from ix->d_orig (already filled) on `stream`.
-// doc_sq / inv_norm / max norm: rows staged through LDS when at least 8 of them fit, else one thread per row
+// doc_sq / inv_norm / max norm: rows staged through LDS when at least 32 of them fit (d <= 511), else one thread
+// per row (measured at d = 1024: 15 rows per workgroup, 37 ms per 6.25M rows against ~18 ms direct)
 template <typename T>
 static void launch_row_norms(const T *src, int64_t n, int d, mir_index *ix, hipStream_t stream) {
     unsigned int *mx = reinterpret_cast<unsigned int *>(ix->d_maxnorm);
     const int rows_per_wg = std::min<int64_t>(128, kNormsLdsBytes / ((int64_t)norms_row_stride(d) * 4));
-    if (rows_per_wg >= 8) {
+    if (rows_per_wg >= 32) {
         const size_t lds = (size_t)rows_per_wg * norms_row_stride(d) * 4;
         row_norms_lds_kernel<T><<<dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)), dim3(256), lds, stream>>>(
             src, n, d, rows_per_wg, ix->d_docsq, ix->d_invnorm, mx);
