@@ -69,3 +69,38 @@ def test_without_nltk_data_the_front_end_refuses():
         ks._nltk_front_end.cache_clear()
         with pytest.raises(ImportError, match="punkt"):
             ks.keywords_preprocess("some text")
+
+
+def test_compact_term_ids_first_appearance_order():
+    """mir_compact_term_ids (host utility of the BM25 build): ids from a larger vocabulary -> 0..n_used-1 in order of
+    first appearance, the order rank-bm25's dicts have; remap marks unused ids with -1."""
+    import ctypes as C
+
+    import numpy as np
+
+    from aidial_rag_amd import _native as nat
+
+    ids = np.array([7, 3, 7, 9, 3, 0, 9, 9, 5], np.int32)
+    out = np.empty_like(ids)
+    remap = np.empty(10, np.int32)
+    used = C.c_int32()
+    nat.check(nat.lib.mir_compact_term_ids(nat.ptr(ids), len(ids), 10, nat.ptr(out), nat.ptr(remap), C.byref(used)))
+    assert used.value == 5
+    assert out.tolist() == [0, 1, 0, 2, 1, 3, 2, 2, 4]
+    assert remap.tolist() == [3, -1, -1, 1, -1, 4, -1, 0, -1, 2]
+    # in place, and against a numpy restatement on random data
+    rng = np.random.default_rng(0)
+    big = rng.integers(0, 5000, 200000).astype(np.int32)
+    _, first = np.unique(big, return_index=True)
+    order = big[np.sort(first)]
+    want_map = np.full(5000, -1, np.int32)
+    want_map[order] = np.arange(len(order), dtype=np.int32)
+    buf = big.copy()
+    remap = np.empty(5000, np.int32)
+    nat.check(nat.lib.mir_compact_term_ids(nat.ptr(buf), len(buf), 5000, nat.ptr(buf), nat.ptr(remap), C.byref(used)))
+    assert used.value == len(order)
+    np.testing.assert_array_equal(remap, want_map)
+    np.testing.assert_array_equal(buf, want_map[big])
+    with pytest.raises(ValueError):
+        bad, scratch = np.array([1, 12], np.int32), np.empty(10, np.int32)
+        nat.check(nat.lib.mir_compact_term_ids(nat.ptr(bad), 2, 10, nat.ptr(bad), nat.ptr(scratch), C.byref(used)))
