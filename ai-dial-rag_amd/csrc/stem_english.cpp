@@ -21,13 +21,15 @@ using U = std::u32string;
 
 inline bool vowel(char32_t c) { return c == U'a' || c == U'e' || c == U'i' || c == U'o' || c == U'u' || c == U'y'; }
 
-inline bool ends(const U &w, const char *suf) {
-    const size_t n = std::strlen(suf);
-    if (w.size() < n) return false;
-    for (size_t i = 0; i < n; ++i)
+inline bool ends_n(const U &w, const char *suf, size_t n) {
+    if (w.size() < n || w.back() != (char32_t)(unsigned char)suf[n - 1]) return false;  // most suffixes fail here
+    for (size_t i = 0; i + 1 < n; ++i)
         if (w[w.size() - n + i] != (char32_t)(unsigned char)suf[i]) return false;
     return true;
 }
+inline bool ends(const U &w, const char *suf) { return ends_n(w, suf, std::strlen(suf)); }  // literals: strlen folds
+struct Suf { const char *s; size_t n; };
+#define SUF(x) Suf{x, sizeof(x) - 1}
 inline bool starts(const U &w, const char *pre) {
     const size_t n = std::strlen(pre);
     if (w.size() < n) return false;
@@ -65,16 +67,13 @@ const Special kSpecial[] = {
 };
 
 // suffix lists in NLTK's match order (first hit ends the step, whether or not it then applies)
-const char *const kStep0[] = {"'s'", "'s", "'"};
-const char *const kStep1a[] = {"sses", "ied", "ies", "us", "ss", "s"};
-const char *const kStep1b[] = {"eedly", "ingly", "edly", "eed", "ing", "ed"};
-const char *const kStep2[] = {"ization", "ational", "fulness", "ousness", "iveness", "tional", "biliti", "lessli",
-                              "entli", "ation", "alism", "aliti", "ousli", "iviti", "fulli", "enci", "anci", "abli",
-                              "izer", "ator", "alli", "bli", "ogi", "li"};
-const char *const kStep3[] = {"ational", "tional", "alize", "icate", "iciti", "ative", "ical", "ness", "ful"};
-const char *const kStep4[] = {"ement", "ance", "ence", "able", "ible", "ment", "ant", "ent", "ism", "ate", "iti", "ous",
-                              "ive", "ize", "ion", "al", "er", "ic"};
-const char *const kDouble[] = {"bb", "dd", "ff", "gg", "mm", "nn", "pp", "rr", "tt"};
+const Suf kStep0[] = {SUF("'s'"), SUF("'s"), SUF("'")};
+const Suf kStep1a[] = {SUF("sses"), SUF("ied"), SUF("ies"), SUF("us"), SUF("ss"), SUF("s")};
+const Suf kStep1b[] = {SUF("eedly"), SUF("ingly"), SUF("edly"), SUF("eed"), SUF("ing"), SUF("ed")};
+const Suf kStep2[] = {SUF("ization"), SUF("ational"), SUF("fulness"), SUF("ousness"), SUF("iveness"), SUF("tional"), SUF("biliti"), SUF("lessli"), SUF("entli"), SUF("ation"), SUF("alism"), SUF("aliti"), SUF("ousli"), SUF("iviti"), SUF("fulli"), SUF("enci"), SUF("anci"), SUF("abli"), SUF("izer"), SUF("ator"), SUF("alli"), SUF("bli"), SUF("ogi"), SUF("li")};
+const Suf kStep3[] = {SUF("ational"), SUF("tional"), SUF("alize"), SUF("icate"), SUF("iciti"), SUF("ative"), SUF("ical"), SUF("ness"), SUF("ful")};
+const Suf kStep4[] = {SUF("ement"), SUF("ance"), SUF("ence"), SUF("able"), SUF("ible"), SUF("ment"), SUF("ant"), SUF("ent"), SUF("ism"), SUF("ate"), SUF("iti"), SUF("ous"), SUF("ive"), SUF("ize"), SUF("ion"), SUF("al"), SUF("er"), SUF("ic")};
+const Suf kDouble[] = {SUF("bb"), SUF("dd"), SUF("ff"), SUF("gg"), SUF("mm"), SUF("nn"), SUF("pp"), SUF("rr"), SUF("tt")};
 
 inline bool is(const char *a, const char *b) { return std::strcmp(a, b) == 0; }
 
@@ -112,15 +111,16 @@ void stem(U &word, U &r1, U &r2) {
     }
 
     // step 0
-    for (const char *suf : kStep0)
-        if (ends(word, suf)) {
-            const size_t n = std::strlen(suf);
+    for (const Suf &sf : kStep0)
+        if (ends_n(word, sf.s, sf.n)) {
+            const size_t n = sf.n;
             chop(word, n); chop(r1, n); chop(r2, n);
             break;
         }
     // step 1a
-    for (const char *suf : kStep1a)
-        if (ends(word, suf)) {
+    for (const Suf &sf : kStep1a)
+        if (ends_n(word, sf.s, sf.n)) {
+            const char *suf = sf.s;
             if (is(suf, "sses")) {
                 chop(word, 2); chop(r1, 2); chop(r2, 2);
             } else if (is(suf, "ied") || is(suf, "ies")) {
@@ -134,11 +134,12 @@ void stem(U &word, U &r1, U &r2) {
             break;
         }
     // step 1b
-    for (const char *suf : kStep1b)
-        if (ends(word, suf)) {
-            const size_t n = std::strlen(suf);
+    for (const Suf &sf : kStep1b)
+        if (ends_n(word, sf.s, sf.n)) {
+            const char *suf = sf.s;
+            const size_t n = sf.n;
             if (is(suf, "eed") || is(suf, "eedly")) {
-                if (ends(r1, suf)) {
+                if (ends_n(r1, sf.s, sf.n)) {
                     chop(word, n); put(word, "ee");
                     region_replace(r1, n, "ee", "");
                     region_replace(r2, n, "ee", "");
@@ -149,7 +150,7 @@ void stem(U &word, U &r1, U &r2) {
                 if (found) {
                     chop(word, n); chop(r1, n); chop(r2, n);
                     bool dbl = false;
-                    for (const char *d : kDouble) dbl = dbl || ends(word, d);
+                    for (const Suf &d : kDouble) dbl = dbl || ends_n(word, d.s, d.n);
                     const size_t L = word.size();
                     if (ends(word, "at") || ends(word, "bl") || ends(word, "iz")) {
                         word.push_back(U'e');
@@ -175,10 +176,11 @@ void stem(U &word, U &r1, U &r2) {
         if (!r2.empty()) r2.back() = U'i';
     }
     // step 2
-    for (const char *suf : kStep2)
-        if (ends(word, suf)) {
-            if (ends(r1, suf)) {
-                const size_t n = std::strlen(suf);
+    for (const Suf &sf : kStep2)
+        if (ends_n(word, sf.s, sf.n)) {
+            const char *suf = sf.s;
+            if (ends_n(r1, sf.s, sf.n)) {
+                const size_t n = sf.n;
                 auto all3 = [&](size_t k) { chop(word, k); chop(r1, k); chop(r2, k); };
                 auto repl = [&](const char *neu, const char *r2_otherwise) {
                     chop(word, n); put(word, neu);
@@ -208,10 +210,11 @@ void stem(U &word, U &r1, U &r2) {
             break;
         }
     // step 3
-    for (const char *suf : kStep3)
-        if (ends(word, suf)) {
-            if (ends(r1, suf)) {
-                const size_t n = std::strlen(suf);
+    for (const Suf &sf : kStep3)
+        if (ends_n(word, sf.s, sf.n)) {
+            const char *suf = sf.s;
+            if (ends_n(r1, sf.s, sf.n)) {
+                const size_t n = sf.n;
                 auto all3 = [&](size_t k) { chop(word, k); chop(r1, k); chop(r2, k); };
                 auto repl = [&](const char *neu) {
                     chop(word, n); put(word, neu);
@@ -223,15 +226,16 @@ void stem(U &word, U &r1, U &r2) {
                 else if (is(suf, "alize")) all3(3);
                 else if (is(suf, "icate") || is(suf, "iciti") || is(suf, "ical")) repl("ic");
                 else if (is(suf, "ful") || is(suf, "ness")) all3(n);
-                else if (is(suf, "ative") && ends(r2, suf)) all3(5);
+                else if (is(suf, "ative") && ends_n(r2, sf.s, sf.n)) all3(5);
             }
             break;
         }
     // step 4
-    for (const char *suf : kStep4)
-        if (ends(word, suf)) {
-            if (ends(r2, suf)) {
-                const size_t n = std::strlen(suf);
+    for (const Suf &sf : kStep4)
+        if (ends_n(word, sf.s, sf.n)) {
+            const char *suf = sf.s;
+            if (ends_n(r2, sf.s, sf.n)) {
+                const size_t n = sf.n;
                 if (is(suf, "ion")) {
                     const char32_t c = word[word.size() - 4];
                     if (c == U's' || c == U't') { chop(word, 3); chop(r1, 3); chop(r2, 3); }
