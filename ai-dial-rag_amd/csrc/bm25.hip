@@ -15,6 +15,7 @@
 //   t_tile u32[V][T+1]             offset (inside the term's range) of the first
 //                                  posting whose document falls in tile >= j
 //   idf    f64[V]
+// The layout is built on the device from the token-id documents (bm25_build.hip); the idf on the host.
 // Scoring never materialises the dense float64[N] score vector the reference
 // builds per query.  A workgroup owns one tile of 8192 consecutive documents:
 // it accumulates the tile's scores in LDS, one query term after the other in
@@ -35,6 +36,7 @@
 #include <new>
 #include <vector>
 
+#include "bm25_build.h"
 #include "common.h"
 
 namespace mir {
@@ -707,55 +709,40 @@ int32_t mir_bm25_create(const int64_t *indptr, const int32_t *term_ids, int64_t 
         return MIR_ERR_EMPTY;
     }
     MIR_REQUIRE(total == 0 || term_ids != nullptr, "term_ids is NULL");
-    const int64_t t_base = n_docs ? indptr[0] : 0;
     for (int64_t i = 0; i < n_docs; ++i)
         MIR_REQUIRE(indptr[i + 1] >= indptr[i], "indptr is not monotone at %lld", (long long)i);
-    for (int64_t j = 0; j < total; ++j)
-        MIR_REQUIRE(term_ids[t_base + j] >= 0 && term_ids[t_base + j] < vocab, "term id %d at %lld outside [0, %d)",
-                    term_ids[t_base + j], (long long)j, vocab);
     int32_t rc = use_device(device, nullptr);
     if (rc != MIR_OK) return rc;
 
-    // ---- BM25._initialize: per-document tf, df in first-appearance order ----
-    std::vector<int64_t> df(vocab, 0);
-    std::vector<int64_t> last_doc(vocab, -1);
-    std::vector<int64_t> slot(vocab, 0);
-    std::vector<int32_t> order;                 // terms in order of first appearance (dict insertion order)
-    std::vector<int32_t> e_term; std::vector<int32_t> e_tf; std::vector<int64_t> e_ptr(n_docs + 1, 0);
-    e_term.reserve((size_t)total); e_tf.reserve((size_t)total);
-    for (int64_t i = 0; i < n_docs; ++i) {
-        for (int64_t j = indptr[i]; j < indptr[i + 1]; ++j) {
-            const int32_t t = term_ids[j];
-            if (last_doc[t] != i) {
-                last_doc[t] = i;
-                slot[t] = (int64_t)e_term.size();
-                e_term.push_back(t);
-                e_tf.push_back(1);
-                if (df[t] == 0) order.push_back(t);
-                ++df[t];
-            } else {
-                ++e_tf[slot[t]];
-            }
-        }
-        e_ptr[i + 1] = (int64_t)e_term.size();
-    }
-    const int64_t P = (int64_t)e_term.size();
-
     mir_bm25 *h = new (std::nothrow) mir_bm25();
     MIR_REQUIRE(h != nullptr, "out of host memory");
-    h->device = device; h->n_docs = n_docs; h->vocab = vocab; h->n_postings = P; h->doc_offset = doc_offset;
-    h->ntiles = (int)std::max<int64_t>(1, (n_docs + kBm25Tile - 1) / kBm25Tile);
+    h->device = device; h->n_docs = n_docs; h->vocab = vocab; h->doc_offset = doc_offset;
+    h->avgdl = idf_override ? avgdl_override : (double)total / (double)n_docs;
+
+    // ---- postings, weights, per-term and per-tile offsets: built on the device (bm25_build.hip) ----
+    Bm25Built built;
+    rc = bm25_build_device(indptr, term_ids, n_docs, vocab, k1, b, h->avgdl, kBm25Tile, &built);
+    h->p_doc = built.p_doc; h->p_w = built.p_w; h->t_ptr = built.t_ptr; h->t_tile = built.t_tile;  // freed with h
+    h->n_postings = built.n_postings; h->ntiles = std::max(1, built.ntiles); h->hbm_bytes += built.hbm_bytes;
+    if (rc != MIR_OK) {
+        free_bm25(h);
+        return rc;
+    }
+
+    // ---- BM25Okapi._calc_idf on the host: V logarithms, summed in order of first appearance (dict order) ----
     h->h_idf.assign(vocab, 0.0);
     if (idf_override) {
         std::memcpy(h->h_idf.data(), idf_override, sizeof(double) * vocab);
-        h->avgdl = avgdl_override;
     } else {
-        h->avgdl = (double)total / (double)n_docs;
-        // BM25Okapi._calc_idf
+        std::vector<int32_t> order;
+        for (int32_t t = 0; t < vocab; ++t)
+            if (built.t_ptr_host[t + 1] > built.t_ptr_host[t]) order.push_back(t);
+        std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return built.first_pos[x] < built.first_pos[y]; });
         double idf_sum = 0.0;
         std::vector<int32_t> negative;
         for (int32_t t : order) {
-            const double v = std::log((double)(n_docs - df[t]) + 0.5) - std::log((double)df[t] + 0.5);
+            const int64_t df = built.t_ptr_host[t + 1] - built.t_ptr_host[t];
+            const double v = std::log((double)(n_docs - df) + 0.5) - std::log((double)df + 0.5);
             h->h_idf[t] = v;
             idf_sum += v;
             if (v < 0) negative.push_back(t);
@@ -763,36 +750,6 @@ int32_t mir_bm25_create(const int64_t *indptr, const int32_t *term_ids, int64_t 
         h->average_idf = idf_sum / (double)order.size();
         const double eps = epsilon * h->average_idf;
         for (int32_t t : negative) h->h_idf[t] = eps;
-    }
-
-    // ---- postings by term (documents ascending), weights in the package's operation order ----
-    std::vector<int64_t> t_ptr(vocab + 1, 0);
-    for (int t = 0; t < vocab; ++t) t_ptr[t + 1] = t_ptr[t] + df[t];
-    std::vector<int64_t> fill(t_ptr.begin(), t_ptr.end() - 1);
-    std::vector<int32_t> p_doc((size_t)P);
-    std::vector<double> p_w((size_t)P);
-    for (int64_t i = 0; i < n_docs; ++i) {
-        const double dl = (double)(indptr[i + 1] - indptr[i]);
-        const double denom_len = k1 * ((1.0 - b) + (b * dl) / h->avgdl);
-        for (int64_t e = e_ptr[i]; e < e_ptr[i + 1]; ++e) {
-            const double tf = (double)e_tf[e];
-            const int64_t pos = fill[e_term[e]]++;
-            p_doc[pos] = (int32_t)i;
-            p_w[pos] = (tf * (k1 + 1.0)) / (tf + denom_len);
-        }
-    }
-    // ---- per-term tile offsets ----
-    const int T = h->ntiles;
-    MIR_REQUIRE((int64_t)vocab * (T + 1) < ((int64_t)1 << 33), "vocab x tiles table too large (%d x %d)", vocab, T + 1);
-    std::vector<uint32_t> t_tile((size_t)vocab * (T + 1));
-    for (int t = 0; t < vocab; ++t) {
-        uint32_t *row = t_tile.data() + (size_t)t * (T + 1);
-        int64_t p = t_ptr[t];
-        for (int j = 0; j <= T; ++j) {
-            const int64_t bound = (int64_t)j * kBm25Tile;
-            while (p < t_ptr[t + 1] && p_doc[p] < bound) ++p;
-            row[j] = (uint32_t)(p - t_ptr[t]);
-        }
     }
 
     auto fail = [&](int32_t code) {
@@ -813,10 +770,6 @@ int32_t mir_bm25_create(const int64_t *indptr, const int32_t *term_ids, int64_t 
         h->hbm_bytes += bytes;
         return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
-    MIR_TRY(up((void **)&h->p_doc, p_doc.data(), (size_t)P * 4));
-    MIR_TRY(up((void **)&h->p_w, p_w.data(), (size_t)P * 8));
-    MIR_TRY(up((void **)&h->t_ptr, t_ptr.data(), (size_t)(vocab + 1) * 8));
-    MIR_TRY(up((void **)&h->t_tile, t_tile.data(), t_tile.size() * 4));
     MIR_TRY(up((void **)&h->idf, h->h_idf.data(), (size_t)vocab * 8));
     MIR_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 #undef MIR_TRY

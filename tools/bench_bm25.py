@@ -26,7 +26,7 @@ def make_queries(nq):
         if i % 20 == 5: q.append(q[0])
         out.append(q)
     return out
-res = {"n_docs": n, "vocab": vocab, "postings": info["n_postings"], "hbm_bytes": info["hbm_bytes"], "build_s_host": round(t_build, 2), "runs": []}
+res = {"n_docs": n, "vocab": vocab, "postings": info["n_postings"], "hbm_bytes": info["hbm_bytes"], "build_s": round(t_build, 2), "runs": []}
 o = ob.BM25OkapiCSR(indptr, toks, vocab)
 df = o.df
 for B in (1, 64, 512, 4096):
