@@ -139,7 +139,7 @@ int32_t bm25_build_device(const int64_t *indptr, const int32_t *term_ids, int64_
     BUILD_TRY(tmp.take((void **)&d_first, (size_t)vocab * 8));
     BUILD_TRY(tmp.take((void **)&d_bad, 16));
     BUILD_TRY(tmp.take((void **)&d_nruns, 16));
-    BUILD_TRY(hipMemcpyAsync(d_indptr, indptr, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+    if (n_docs) BUILD_TRY(hipMemcpyAsync(d_indptr, indptr, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
     if (total) BUILD_TRY(hipMemcpyAsync(d_terms, term_ids + indptr[0], (size_t)total * 4, hipMemcpyHostToDevice, s));
     BUILD_TRY(hipMemsetAsync(d_bad, 0, 16, s));
     BUILD_TRY(hipMemsetAsync(d_nruns, 0, 16, s));
