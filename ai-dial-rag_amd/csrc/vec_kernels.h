@@ -1104,11 +1104,12 @@ __device__ inline void merge_sorted_lists(const uint64_t *__restrict__ lists, si
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int wg = tid + 256 * j;
+        const bool mine_j = wg < nwg;
         const uint64_t *l = lists + (size_t)wg * list_stride;
         head[j] = 0;
-        cur[j] = wg < nwg ? l[0] : 0;
-        n1[j] = (wg < nwg && klist > 1) ? l[1] : 0;
-        n2[j] = (wg < nwg && klist > 2) ? l[2] : 0;
+        cur[j] = mine_j ? l[0] : 0;
+        n1[j] = (mine_j && klist > 1) ? l[1] : 0;
+        n2[j] = (mine_j && klist > 2) ? l[2] : 0;
     }
     for (int r = 0; r < klist; ++r) {
         uint64_t mine = cur[0];
@@ -1171,6 +1172,9 @@ struct FinalizeArgs {
 };
 
 // grid = b (one block per query), block = 256, static LDS 64 KiB + small.
+// Where its ~27 us go (128 queries, 256 lists of 12): ~5 dispatch, ~10 the 12 tournament rounds (a 64-bit
+// wave max through ds_bpermute + two barriers each), the rest dependent HBM hops (list heads, candidate rows,
+// norms).  Re-scoring on 16 waves instead of 4 and prefetching the lists' next entries changed nothing measurable.
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     __shared__ uint64_t keys[kMaxList];
     __shared__ uint64_t red[4];
