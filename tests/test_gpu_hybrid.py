@@ -241,3 +241,43 @@ def test_new_document_combinations_are_composed_in_hbm():
         np.testing.assert_array_equal(got, want)
     with pytest.raises(ValueError):
         DeviceIndex.from_rows([DeviceRows.from_host(np.zeros((2, 8), np.float32)), DeviceRows.from_host(np.zeros((2, 9), np.float32))])
+
+
+def test_row_block_edges():
+    """mir_rows / mir_index_create_from_rows edge cases: an empty block in the middle, chunk ids defaulting to
+    0..n-1, float16 blocks that are widened (d <= 512), a single one-row block, and argument errors."""
+    import numpy as np
+
+    from aidial_rag_amd.retrievers.embeddings_index import DeviceIndex, DeviceRows
+
+    rng = np.random.default_rng(21)
+    a = rng.standard_normal((70, 48)).astype(np.float32)
+    c = rng.standard_normal((1, 48)).astype(np.float32)
+    empty = np.zeros((0, 48), np.float32)
+    blocks = [DeviceRows.from_host(a), DeviceRows.from_host(empty), DeviceRows.from_host(c)]
+    assert [b.n for b in blocks] == [70, 0, 1] and blocks[1].hbm_bytes() == 0
+    ix = DeviceIndex.from_rows(blocks)  # doc ids default to the block's position, chunk ids to the row within it
+    q = rng.standard_normal((3, 48))
+    doc, chunk, row, dist, cnt, _ = ix.search(q, 5, "sqeuclidean_dist")
+    whole = DeviceIndex.from_host(np.concatenate([a, c]), np.concatenate([np.arange(70), np.arange(1)]),
+                                  np.concatenate([np.zeros(70, np.int32), np.full(1, 2, np.int32)]))
+    for got, want in zip((doc, chunk, row, dist, cnt), whole.search(q, 5, "sqeuclidean_dist")):
+        np.testing.assert_array_equal(got, want)
+    # one block of one row
+    one = DeviceIndex.from_rows([blocks[2]], [7])
+    d1, c1, _, _, n1, _ = one.search(q[:1], 3, "cosine_sim")
+    assert n1[0] == 1 and d1[0, 0] == 7 and c1[0, 0] == 0
+    # float16 blocks below the float16-native width: widened exactly, same answers as the flat float16 upload
+    h = [rng.standard_normal((n, 96)).astype(np.float16) for n in (33, 5)]
+    comp = DeviceIndex.from_rows([DeviceRows.from_host(x) for x in h])
+    flat = DeviceIndex.from_host(np.concatenate(h), np.concatenate([np.arange(33), np.arange(5)]),
+                                 np.concatenate([np.zeros(33, np.int32), np.ones(5, np.int32)]))
+    q96 = rng.standard_normal((4, 96))
+    for got, want in zip(comp.search(q96, 6, "inner_product"), flat.search(q96, 6, "inner_product")):
+        np.testing.assert_array_equal(got, want)
+    with pytest.raises(ValueError):
+        DeviceIndex.from_rows([])
+    with pytest.raises(ValueError):
+        DeviceRows.from_host(np.zeros((3, 4), np.float32), chunk_ids=[1, 2])
+    with pytest.raises(ValueError):
+        DeviceIndex.from_rows([blocks[0], DeviceRows.from_host(np.zeros((2, 48), np.float16))])  # dtype mismatch
