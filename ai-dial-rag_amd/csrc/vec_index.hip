@@ -1081,9 +1081,15 @@ int32_t mir_topk_merge_device(const double *dist, const int64_t *row, const int3
     const int64_t sd = shard_stride_bytes ? shard_stride_bytes : (int64_t)b * k * 8;
     const int64_t sr = shard_stride_bytes ? shard_stride_bytes : (int64_t)b * k * 8;
     const int64_t sc = shard_stride_bytes ? shard_stride_bytes : (int64_t)b * 4;
-    merge_topk_kernel<<<dim3(b), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
-        reinterpret_cast<const char *>(dist), reinterpret_cast<const char *>(row),
-        reinterpret_cast<const char *>(count), s, sd, sr, sc, b, k, descending_scores, out_dist, out_row, out_count);
+    const int64_t nk = (int64_t)s * k;
+    if (nk <= kMergeLds)
+        merge_topk_kernel<<<dim3(b), dim3(nk <= 64 ? 64 : nk <= 128 ? 128 : 256), 0, static_cast<hipStream_t>(stream)>>>(
+            reinterpret_cast<const char *>(dist), reinterpret_cast<const char *>(row),
+            reinterpret_cast<const char *>(count), s, sd, sr, sc, b, k, descending_scores, out_dist, out_row, out_count);
+    else
+        merge_topk_global_kernel<<<dim3(b), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
+            reinterpret_cast<const char *>(dist), reinterpret_cast<const char *>(row),
+            reinterpret_cast<const char *>(count), s, sd, sr, sc, b, k, descending_scores, out_dist, out_row, out_count);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }

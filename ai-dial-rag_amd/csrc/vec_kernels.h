@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(256) void sample_threshold_kernel(const float *__re
 
 // One block of 64 threads per query: merge s lists of <= k (dist, row) into k.
 // Shard sh's arrays start `sh * stride` bytes after the base pointers.
-__global__ __launch_bounds__(64) void merge_topk_kernel(const char *__restrict__ dist_b,
+__global__ __launch_bounds__(64) void merge_topk_global_kernel(const char *__restrict__ dist_b,
                                                         const char *__restrict__ row_b,
                                                         const char *__restrict__ count_b, int s,
                                                         int64_t stride_d, int64_t stride_r, int64_t stride_c,
@@ -1338,6 +1338,84 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const char *__restrict__
         }
     }
     if (threadIdx.x == 0) out_count[qi] = kout;
+}
+
+// The same merge with the s*k candidates staged in LDS first (s*k <= kMergeLds): the kernel above re-reads every
+// candidate from global memory inside its rank loop - 2*s*k dependent loads per thread, 21 us at s = 8, k = 10,
+// on the critical path of every step of an 8-GPU search (after the all-gather).
+constexpr int kMergeLds = 1024;
+// float64 -> uint64 whose unsigned order is the reference's: numbers ascending (-0 = +0), NaN last
+__device__ __forceinline__ uint64_t merge_key(double d) {
+    if (d != d) return ~0ull;
+    const uint64_t u = (uint64_t)__double_as_longlong(d + 0.0);  // -0.0 + 0.0 = +0.0
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__global__ __launch_bounds__(256) void merge_topk_kernel(const char *__restrict__ dist_b, const char *__restrict__ row_b,
+                                                         const char *__restrict__ count_b, int s, int64_t stride_d,
+                                                         int64_t stride_r, int64_t stride_c, int b, int k, int descending,
+                                                         double *__restrict__ out_dist, int64_t *__restrict__ out_row,
+                                                         int32_t *__restrict__ out_count) {
+    __shared__ double sd[kMergeLds];
+    __shared__ uint64_t skey[kMergeLds];
+    __shared__ int64_t sr[kMergeLds];
+    __shared__ int scnt[kMergeLds];  // per shard (s <= s*k)
+    const int qi = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int n = s * k;
+    for (int sh = tid; sh < s; sh += nthr) scnt[sh] = reinterpret_cast<const int32_t *>(count_b + sh * stride_c)[qi];
+    __syncthreads();
+    // candidate (shard sh, position p) -> slot sh*k + p; four loads in flight per thread
+    for (int e0 = tid; e0 < n; e0 += nthr * 4) {
+        double dv[4];
+        int64_t rv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + nthr * u;
+            dv[u] = 0.0; rv[u] = 0;
+            if (e < n) {
+                const int sh = e / k, p = e - sh * k;
+                if (p < scnt[sh]) {
+                    dv[u] = reinterpret_cast<const double *>(dist_b + sh * stride_d)[(size_t)qi * k + p];
+                    rv[u] = reinterpret_cast<const int64_t *>(row_b + sh * stride_r)[(size_t)qi * k + p];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + nthr * u;
+            if (e < n) {
+                sd[e] = dv[u];
+                sr[e] = rv[u];
+                // descending scores (BM25; never NaN): larger first, ties to the LARGER row - invert both orders
+                skey[e] = descending ? ~merge_key(dv[u]) : merge_key(dv[u]);
+            }
+        }
+    }
+    __syncthreads();
+    int total = 0;
+    for (int sh = 0; sh < s; ++sh) total += scnt[sh];
+    const int kout = total < k ? total : k;
+    for (int e = tid; e < n; e += nthr) {
+        const int sh = e / k, p = e - sh * k;
+        if (p >= scnt[sh]) continue;
+        const uint64_t km = skey[e];
+        const int64_t rm = sr[e];
+        int rank = 0;
+        for (int s2 = 0; s2 < s; ++s2) {
+            const int c2 = scnt[s2];
+            for (int p2 = 0; p2 < c2; ++p2) {
+                const int e2 = s2 * k + p2;
+                const uint64_t k2 = skey[e2];
+                const int64_t r2 = sr[e2];
+                const bool row_before = descending ? r2 > rm : r2 < rm;
+                rank += (k2 < km || (k2 == km && row_before)) ? 1 : 0;  // e2 == e: equal key, same row -> 0
+            }
+        }
+        if (rank < kout) {
+            out_dist[(size_t)qi * k + rank] = sd[e];
+            out_row[(size_t)qi * k + rank] = rm;
+        }
+    }
+    if (tid == 0) out_count[qi] = kout;
 }
 
 }  // namespace mir
