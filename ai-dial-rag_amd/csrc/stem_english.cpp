@@ -200,11 +200,11 @@ void stem(U &word, U &r1, U &r2) {
                 else if (is(suf, "ousli") || is(suf, "ousness")) repl("ous", "");
                 else if (is(suf, "iveness") || is(suf, "iviti")) repl("ive", "e");
                 else if (is(suf, "biliti") || is(suf, "bli")) repl("ble", "");
-                else if (is(suf, "ogi")) { if (word[word.size() - 4] == U'l') all3(1); }
+                else if (is(suf, "ogi")) { if (word.size() >= 4 && word[word.size() - 4] == U'l') all3(1); }
                 else if (is(suf, "fulli") || is(suf, "lessli")) all3(2);
                 else if (is(suf, "li")) {
-                    const char32_t c = word[word.size() - 3];
-                    if (c < 128 && std::strchr("cdeghkmnrt", (int)c) != nullptr) all3(2);
+                    const char32_t c = word.size() >= 3 ? word[word.size() - 3] : 0;
+                    if (c != 0 && c < 128 && std::strchr("cdeghkmnrt", (int)c) != nullptr) all3(2);
                 }
             }
             break;
@@ -237,7 +237,7 @@ void stem(U &word, U &r1, U &r2) {
             if (ends_n(r2, sf.s, sf.n)) {
                 const size_t n = sf.n;
                 if (is(suf, "ion")) {
-                    const char32_t c = word[word.size() - 4];
+                    const char32_t c = word.size() >= 4 ? word[word.size() - 4] : 0;  // (Python would raise on a 3-letter word)
                     if (c == U's' || c == U't') { chop(word, 3); chop(r1, 3); chop(r2, 3); }
                 } else {
                     chop(word, n); chop(r1, n); chop(r2, n);
