@@ -4,7 +4,7 @@ Run with an interpreter that has nltk (this image: /opt/conda/bin/python3.9, nlt
 3.9.1, pyproject.toml).  NLTK is a third-party dependency of the reference (keywords_search.py:1-11), not a
 reference file.  Words: every alphabetic word of the Python standard library's sources and of this repository's
 Markdown files, plus synthetic words built from stems x every suffix the algorithm knows, apostrophes, y/Y cases,
-the gener/commun/arsen prefixes, non-ASCII letters and non-words.
+the gener/commun/arsen prefixes, non-ASCII letters, non-words and 20 000 random strings over the letters the rules test.
 """
 import glob, gzip, itertools, json, os, re, sys
 
@@ -42,6 +42,11 @@ for a, b, c in itertools.product(["gener", "commun", "arsen", "un", "re"], ["at"
     words.add(a + b + c)
 words.update([",", ".", "``", "''", "n't", "'re", "'ll", "i.e.", "e.g.", "u.s.a", "co-operate", "state-of-the-art", "1990s",
               "3rd", "‘quoted’", "‛x", "ﬁnally", "ångström", "日本語", "日本語ing", "ied", "ies", "yyy", "ayayay"])
+import random
+rnd = random.Random(1)  # random short strings over the letters the rules look at: they reach the corners real words miss
+alpha = "aeiouybcdlnrst'gmz"
+for _ in range(20000):
+    words.add("".join(rnd.choice(alpha) for _ in range(rnd.randint(0, 9))))
 stemmer = SnowballStemmer("english")
 pairs = [[w, stemmer.stem(w)] for w in sorted(words)]
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "snowball_english.json.gz")
