@@ -8,6 +8,10 @@ fused scan + top-k over this rank's row shard, float64 re-score, and (N > 1)
 one RCCL all-gather of per-shard partial top-k plus a local merge.  The index
 and the queries are resident in HBM before the timed region.  The total index
 is fixed at --rows as N grows ("strong" scaling: the shard is rows / N).
+Before the W warm-up steps the same step runs untimed until 12 launches have
+been made in all (`preconditioning_steps` in the output): from idle the GPU
+takes ~10 launches to reach its steady clock, and a short --warmup would
+otherwise time that ramp.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the scan)
 from HIP events recorded on its launch stream inside the timed region;
@@ -26,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CHUNK_ROWS = 500_000   # corpus is generated in fixed global chunks so every N sees the same rows
+PRECONDITION_STEPS = 12  # untimed launches before timing starts (W of them are the warm-up steps), see main()
 
 
 def parse():
@@ -151,7 +156,7 @@ def c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex,
     queries = torch.randn((B, d), generator=g, dtype=torch.float32, device=device).double().contiguous()
     searcher = ShardedSearcher(local_index=index)
     index.profile(True)
-    for _ in range(2):
+    for _ in range(PRECONDITION_STEPS):
         out = searcher.search(queries, k, "sqeuclidean_dist")
     barrier()
     index.profile_read(reset=True)
@@ -251,6 +256,12 @@ def main():
 
     index.profile(True)  # before the warm-up: event creation is slow and must not be timed
     n_warm = max(args.warmup, 1)
+    # Preconditioning, before the W warm-up steps and untimed like them: from idle the GPU needs ~10 launches
+    # (~30 ms) to reach its steady clock / power state - measured with --steps 5: scan 3.48 ms per launch after 2
+    # warm-up steps, 3.17 after 5, 3.02 after 8, 2.90 after 12, 2.89 after 20 - so a short --warmup would time the ramp.
+    precondition = max(0, PRECONDITION_STEPS - n_warm)
+    for i in range(precondition):
+        step(i % n_warm)
     for i in range(n_warm):
         out = step(i)  # exactly the timed loop's body
     barrier()
@@ -324,6 +335,7 @@ def main():
             "launches": launches,
         },
         "uncertain_queries": int(flags_total.item()),
+        "preconditioning_steps": precondition,
         "index_build_s": {"generate": round(t_gen, 2), "upload_pack_norms": round(t_build, 2)},
     }
 
