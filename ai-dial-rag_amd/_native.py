@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_PKG_DIR, "libmiretr.so")
 MIR_OK, MIR_ERR_INVALID, MIR_ERR_HIP, MIR_ERR_NO_DEVICE, MIR_ERR_EMPTY, MIR_ERR_UNSUPPORTED = range(6)
 METRIC_CODES = {"cosine_sim": 0, "euclidean_dist": 1, "sqeuclidean_dist": 2, "inner_product": 3}
 DTYPE_F32, DTYPE_F16 = 0, 1
-FLAG_UNCERTAIN = 1
+FLAG_UNCERTAIN = 1  # never returned since ABI 2
+FLAG_EXACT_PASS = 2  # the query was answered by the exact pass (exact_topk_kernel)
 ABI_VERSION = 1
 
 
@@ -76,6 +77,7 @@ def _load():
         "mir_compact_term_ids": ([vp, i64, i32, vp, vp, vp], i32),
         "mir_stem_english": ([vp, i64, C.c_char, vp, vp], i32),
         "mir_bm25_destroy": ([vp], i32),
+        "mir_bm25_tune": ([vp, i32], i32),
         "mir_bm25_info": ([vp, vp, vp, vp, vp, vp, vp], i32),
         "mir_bm25_idf": ([vp, vp], i32),
         "mir_bm25_scores": ([vp, vp, i32, vp], i32),

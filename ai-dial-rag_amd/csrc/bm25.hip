@@ -651,6 +651,7 @@ struct mir_bm25 {
     char *pin = nullptr;       // pinned host staging of mir_bm25_search: queries in, results out, one copy each
     size_t pin_cap = 0;
     hipStream_t stream = nullptr;
+    int qc_pin = 0;  // mir_bm25_tune: queries per workgroup of the fast pass (0 = chosen per call)
 };
 
 namespace mir {
@@ -797,6 +798,15 @@ int32_t mir_compact_term_ids(const int32_t *ids, int64_t n, int32_t vocab, int32
     return MIR_OK;
 }
 
+int32_t mir_bm25_tune(mir_bm25 *h, int32_t queries_per_workgroup) {
+    MIR_REQUIRE(h != nullptr, "handle is NULL");
+    MIR_REQUIRE(queries_per_workgroup >= 0 && queries_per_workgroup <= kBm25QcMax, "queries_per_workgroup=%d outside [0, %d]",
+                queries_per_workgroup, kBm25QcMax);
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->qc_pin = queries_per_workgroup;
+    return MIR_OK;
+}
+
 int32_t mir_bm25_destroy(mir_bm25 *h) {
     free_bm25(h);
     return MIR_OK;
@@ -840,6 +850,7 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     //    queries per workgroup: as many as still leave ~8 workgroups per CU of parallelism
     int qc = (int)((int64_t)b * T / 2048);
     qc = qc < 1 ? 1 : (qc > kBm25QcMax ? kBm25QcMax : qc);
+    if (h->qc_pin > 0) qc = h->qc_pin;  // tests pin the pipeline depth (short pipelines x long query queues)
     bm25_sparse_kernel<<<dim3(T, (b + qc - 1) / qc), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, b, qc, k, part_score,
                                                                         part_idx, part_cnt);
     MIR_HIP(hipGetLastError());

@@ -231,7 +231,15 @@ struct SearchBuffers {
     double *q_norm;  // [b]
     float *qscale;   // [b] 1 / (query scale) of the float16-native scan
     uint64_t *part;  // [ngroups][nwg][qpw][klist]
-    uint64_t *gthr;  // [ngroups][128] shared per-query thresholds of the 128-query scan
+    uint64_t *gthr;  // [ngroups][128] shared per-query thresholds of the 128-query scan; the control words below
+                     // follow it in ONE allocation, which the prep kernel zeroes (ctl_words)
+    int32_t *nflag;  // [2] number of queries handed to the exact pass
+    uint32_t *arrive;  // [b] arrival counters of the exact pass
+    int ctl_words;   // 64-bit words from gthr to the end of arrive
+    int32_t *flagged;  // [b]
+    double *bound_dist;  // [b] exact pass, k > 64: last result of the previous round
+    uint32_t *bound_row; // [b]
+    uint64_t *part_exact;  // [b][exact grid][64][2]
     uint64_t *part_sample;  // [kSampleWgs][128][klist], reused by every launch (stream-ordered)
     int32_t *o_doc;  // host API staging of outputs, [b][k]
     int64_t *o_chunk;
@@ -241,8 +249,17 @@ struct SearchBuffers {
     int32_t *o_flags;  // [b]
 };
 
-static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int ksteps, int ngroups, int nwg,
-                    int klist, int qpw, bool host_api) {
+// How a search runs (plan()): `ngroups` launches of the filter scan, `qpw` queries each, on `nwg` workgroups
+// with candidate lists of `klist`; exact_only = no filter scan at all (k beyond the lists): every query takes
+// the exact pass.
+struct SearchPlan {
+    int ngroups = 0, nwg = 1, klist = 2, qpw = 32;
+    int exact_grid = 1;       // workgroups of exact_topk_kernel
+    bool exact_only = false;
+};
+
+static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int ksteps, const SearchPlan &pl, bool host_api) {
+    const int ngroups = pl.ngroups, nwg = pl.nwg, klist = pl.klist, qpw = pl.qpw;
     Carver c{base};
     sb.q = host_api ? c.take<double>((size_t)b * d) : nullptr;
     sb.qsplit = c.take<uint4>((size_t)ngroups * (qpw / 32) * ksteps * 128);
@@ -250,7 +267,15 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.q_norm = c.take<double>(b);
     sb.qscale = c.take<float>((size_t)ngroups * 128);
     sb.part = c.take<uint64_t>((size_t)ngroups * nwg * qpw * klist);
-    sb.gthr = c.take<uint64_t>((size_t)ngroups * 128);
+    const size_t gthr_words = (size_t)ngroups * 128, arrive_words = ((size_t)b + 1) / 2;
+    sb.ctl_words = (int)(gthr_words + 1 + arrive_words);
+    sb.gthr = c.take<uint64_t>((size_t)sb.ctl_words);
+    sb.nflag = base ? reinterpret_cast<int32_t *>(sb.gthr + gthr_words) : nullptr;
+    sb.arrive = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1) : nullptr;
+    sb.flagged = c.take<int32_t>(b);
+    sb.bound_dist = c.take<double>(b);
+    sb.bound_row = c.take<uint32_t>(b);
+    sb.part_exact = c.take<uint64_t>((size_t)b * pl.exact_grid * std::min(k, kExactRound) * 2);
     sb.part_sample = c.take<uint64_t>((size_t)kSampleWgs * 128 * klist);
     if (host_api) {
         sb.o_doc = c.take<int32_t>((size_t)b * k);
@@ -437,13 +462,37 @@ static int32_t check_search_args(const mir_index *ix, const void *queries, int32
 
 // Enqueue prep + scan(s) + finalize for device-resident queries/outputs.
 static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int metric, const SearchBuffers &sb,
-                              int ngroups, int nwg, int klist, int qpw, int32_t *o_doc, int64_t *o_chunk, int64_t *o_row,
+                              const SearchPlan &pl, int32_t *o_doc, int64_t *o_chunk, int64_t *o_row,
                               double *o_dist, int32_t *o_count, int32_t *o_flags, hipStream_t stream) {
+    const int ngroups = pl.ngroups, nwg = pl.nwg, klist = pl.klist, qpw = pl.qpw;
     const int d = ix->d;
     const int ntiles32 = ngroups * (qpw / 32);  // 32-query fragment tiles, padded to whole launches
-    unsigned long long *gz = qpw != 32 ? reinterpret_cast<unsigned long long *>(sb.gthr) : nullptr;
-    const int gwords = ngroups * 128;  // zeroed by the first gwords/64 blocks of the prep kernel
-    MIR_REQUIRE(gwords <= 64 * (ntiles32 * ix->ksteps + b), "threshold table larger than the prep grid");
+    // thresholds of the wide scans + the exact pass's control words: zeroed by the first blocks of the prep kernel
+    unsigned long long *gz = reinterpret_cast<unsigned long long *>(sb.gthr);
+    const int gwords = sb.ctl_words;
+    MIR_REQUIRE(gwords <= 64 * (ntiles32 * ix->ksteps + b), "control words larger than the prep grid");
+    ExactArgs ea;
+    ea.docs = ix->d_orig; ea.docs16 = ix->d_f16; ea.doc_sq = ix->d_docsq; ea.n_rows = (uint32_t)ix->n; ea.d = d;
+    ea.metric = metric; ea.q = dq; ea.q_sq = sb.q_sq; ea.q_norm = sb.q_norm; ea.nflag = sb.nflag; ea.flagged = sb.flagged;
+    ea.k = k; ea.round = 0; ea.list_stride = std::min(k, kExactRound); ea.part = sb.part_exact; ea.arrive = sb.arrive;
+    ea.bound_dist = sb.bound_dist; ea.bound_row = sb.bound_row; ea.chunk_ids = ix->d_chunk; ea.doc_ids = ix->d_doc;
+    ea.row_offset = ix->row_offset; ea.out_doc = o_doc; ea.out_chunk = o_chunk; ea.out_row = o_row; ea.out_dist = o_dist;
+    ea.out_count = o_count; ea.out_flags = o_flags;
+    if (pl.exact_only) {
+        // k beyond the filter's candidate lists: no scan; every query is the reference's own computation.
+        // ceil(min(k, n) / 64) rounds, each one pass over the rows per query.
+        prep_queries_kernel<<<dim3(b), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, 0, nullptr, sb.q_sq, sb.q_norm, gz, gwords);
+        flag_all_kernel<<<dim3((b + 255) / 256), dim3(256), 0, stream>>>(b, sb.nflag, sb.flagged);
+        MIR_HIP(hipGetLastError());
+        const int64_t found = std::min<int64_t>(k, ix->n);
+        const int rounds = (int)std::max<int64_t>(1, (found + kExactRound - 1) / kExactRound);
+        for (int r = 0; r < rounds; ++r) {
+            ea.round = r;
+            exact_topk_kernel<<<dim3(pl.exact_grid), dim3(kExactThreads), 0, stream>>>(ea);
+            MIR_HIP(hipGetLastError());
+        }
+        return MIR_OK;
+    }
     if (ix->native16)
         prep_queries_f16_kernel<<<dim3(ntiles32 * ix->ksteps + b), dim3(64), 0, stream>>>(
             dq, b, d, ix->ksteps, ntiles32, sb.qsplit, sb.q_sq, sb.q_norm, sb.qscale, gz, gwords);
@@ -526,43 +575,50 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     fa.q = dq; fa.q_sq = sb.q_sq; fa.q_norm = sb.q_norm;
     fa.chunk_ids = ix->d_chunk; fa.doc_ids = ix->d_doc; fa.row_offset = ix->row_offset;
     fa.out_doc = o_doc; fa.out_chunk = o_chunk; fa.out_row = o_row; fa.out_dist = o_dist;
-    fa.out_count = o_count; fa.out_flags = o_flags;
+    fa.out_count = o_count; fa.out_flags = o_flags; fa.nflag = sb.nflag; fa.flagged = sb.flagged;
     finalize_kernel<<<dim3(b), dim3(256), 0, stream>>>(fa);
+    MIR_HIP(hipGetLastError());
+    // queries whose candidate set finalize could not prove complete: exact pass, gated on the device (it exits at
+    // once when there are none)
+    exact_topk_kernel<<<dim3(pl.exact_grid), dim3(kExactThreads), 0, stream>>>(ea);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }
 
-static int32_t plan(const mir_index *ix, int b, int k, int *ngroups, int *nwg, int *klist, int *qpw) {
-    if (k + kListMargin > kMaxList && ix->n > (int64_t)(kMaxList)) {
-        set_error("k=%d exceeds the scan's candidate list (max k = %d) for an index of %lld rows", k,
-                  kMaxList - kListMargin, (long long)ix->n);
-        return MIR_ERR_UNSUPPORTED;
+static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
+    // one exact-pass workgroup per CU, fewer on small shards (a workgroup's 16 waves take a row each)
+    pl->exact_grid = (int)std::max<int64_t>(1, std::min<int64_t>(ix->num_cus, (ix->n + kExactWaves - 1) / kExactWaves));
+    pl->klist = std::min(k + kListMargin, kMaxList);
+    // The reference takes any `limit` (embeddings_index.py:58,81).  Beyond what the filter's per-lane candidate
+    // lists hold (LDS), an index that could actually return that many rows is searched by the exact pass alone.
+    const bool lists_fit = k + kListMargin <= kMaxList && (!ix->native16 || f16_lds_bytes(pl->klist) <= 160 * 1024);
+    if (!lists_fit && (ix->native16 || ix->n > (int64_t)kMaxList)) {  // (float32, n <= 64: every row fits the lists)
+        pl->exact_only = true;
+        pl->ngroups = 0;
+        pl->qpw = 32;
+        pl->nwg = 1;
+        return MIR_OK;
     }
-    *klist = std::min(k + kListMargin, kMaxList);
     if (ix->native16) {  // one kernel, 64 queries per pass; its LDS holds lists up to k = 28
-        if (f16_lds_bytes(*klist) > 160 * 1024) {
-            set_error("k=%d exceeds the float16 scan's candidate list (max k = %d)", k, 36 - kListMargin);
-            return MIR_ERR_UNSUPPORTED;
-        }
-        *qpw = kF16Queries;
-        *ngroups = (b + *qpw - 1) / *qpw;
+        pl->qpw = kF16Queries;
+        pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
         const int64_t want16 = (int64_t)ix->n_tiles;
-        *nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want16));
+        pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want16));
         return MIR_OK;
     }
     // The 128-query kernel whenever it fits (d padded to a multiple of 128 on the register-resident
     // kernels, lists + DMA ring within 160 KiB of LDS) - also for 1..32 queries: with idle query tiles
     // it is simply the better streamer (LDS-DMA ring, nt policy: 2.31 ms per 10M x 384 pass against
     // 2.64 ms for the 32-query register-ring kernel, which remains for the other shapes and k > 12).
-    const bool wide = (ix->ksteps == 8 || ix->ksteps == 16 || ix->ksteps == 24) && b128_lds_bytes(*klist) <= 160 * 1024;
-    *qpw = wide ? 128 : 32;
-    *ngroups = (b + *qpw - 1) / *qpw;
+    const bool wide = (ix->ksteps == 8 || ix->ksteps == 16 || ix->ksteps == 24) && b128_lds_bytes(pl->klist) <= 160 * 1024;
+    pl->qpw = wide ? 128 : 32;
+    pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
     // one workgroup per CU, or one per tile on shards smaller than that: a workgroup's fixed costs
     // (ring start-up, filling empty lists) grow with the tiles it walks, and on a 1k-5k-row index one
     // tile per workgroup takes a single search from 128 to 90 us
     const int64_t want = (int64_t)ix->n_tiles;
     // (finalize's tournament gives each of its 256 threads up to 4 workgroup lists)
-    *nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want));
+    pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want));
     return MIR_OK;
 }
 
@@ -930,16 +986,16 @@ int32_t mir_index_search_device(mir_index *idx, const double *queries_device, in
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     rc = use_device(idx->device, nullptr);
     if (rc != MIR_OK) return rc;
-    int ngroups, nwg, klist, qpw;
-    rc = plan(idx, b, k, &ngroups, &nwg, &klist, &qpw);
+    SearchPlan pl;
+    rc = plan(idx, b, k, &pl);
     if (rc != MIR_OK) return rc;
     SearchBuffers sb;
-    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, ngroups, nwg, klist, qpw, false);
+    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, pl, false);
     Workspace *w = nullptr;
     rc = acquire_ws(idx, stream, need, &w);
     if (rc != MIR_OK) return rc;
-    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, ngroups, nwg, klist, qpw, false);
-    rc = enqueue_search(idx, queries_device, b, k, metric, sb, ngroups, nwg, klist, qpw, out_doc, out_chunk, out_row,
+    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, pl, false);
+    rc = enqueue_search(idx, queries_device, b, k, metric, sb, pl, out_doc, out_chunk, out_row,
                         out_dist, out_count, out_flags, stream);
     release_ws(idx, w, stream, true);
     return rc;
@@ -953,15 +1009,15 @@ int32_t mir_index_search(mir_index *idx, const double *queries_host, int32_t b, 
     if (b == 0) return MIR_OK;
     rc = use_device(idx->device, nullptr);
     if (rc != MIR_OK) return rc;
-    int ngroups, nwg, klist, qpw;
-    rc = plan(idx, b, k, &ngroups, &nwg, &klist, &qpw);
+    SearchPlan pl;
+    rc = plan(idx, b, k, &pl);
     if (rc != MIR_OK) return rc;
     SearchBuffers sb;
-    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, ngroups, nwg, klist, qpw, true);
+    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, pl, true);
     Workspace *w = nullptr;
     rc = acquire_ws(idx, nullptr, need, &w);
     if (rc != MIR_OK) return rc;
-    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, ngroups, nwg, klist, qpw, true);
+    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, pl, true);
     hipStream_t s = w->stream;
     auto bail = [&](int32_t code) {
         (void)hipStreamSynchronize(s);
@@ -993,7 +1049,7 @@ int32_t mir_index_search(mir_index *idx, const double *queries_host, int32_t b, 
     }
     std::memcpy(w->pin, queries_host, q_bytes);
     MIR_TRY(hipMemcpyAsync(sb.q, w->pin, q_bytes, hipMemcpyHostToDevice, s));
-    rc = enqueue_search(idx, sb.q, b, k, metric, sb, ngroups, nwg, klist, qpw, out_doc ? sb.o_doc : nullptr,
+    rc = enqueue_search(idx, sb.q, b, k, metric, sb, pl, out_doc ? sb.o_doc : nullptr,
                         out_chunk ? sb.o_chunk : nullptr, out_row ? sb.o_row : nullptr,
                         out_dist ? sb.o_dist : nullptr, sb.o_count, sb.o_flags, s);
     if (rc != MIR_OK) return bail(rc);

@@ -1169,6 +1169,8 @@ struct FinalizeArgs {
     double *out_dist;
     int32_t *out_count;
     int32_t *out_flags;
+    int32_t *nflag;         // number of queries handed to the exact pass (zeroed by the prep kernel)
+    int32_t *flagged;       // [b] their indices, in arrival order
 };
 
 // grid = b (one block per query), block = 256, static LDS 64 KiB + small.
@@ -1246,8 +1248,190 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
             const double vk = s_vk;
             if (!(tau + eps < vk)) flag = MIR_FLAG_UNCERTAIN;
         }
+        // An unproven query is handed to exact_topk_kernel (enqueued right behind this kernel), which
+        // overwrites its outputs and flag; the reference is always exact (embeddings_index.py:51-60).
+        if (flag) a.flagged[atomicAdd(a.nflag, 1)] = qi;
         if (a.out_flags) a.out_flags[qi] = flag;
     }
+}
+
+// ---------------------------------------------------------------- exact pass
+// The filter scan + completeness check above PROVES its result for almost every query; the rest -
+// more than klist - k rows inside the scan's error band at the cut (near-duplicate chunks, boiler-plate
+// pages), exact ties across the cut - and every query whose k exceeds the scan's candidate lists
+// take this pass: the reference's own computation (embeddings_index.py:51-60,62-89: the metric in
+// float64 for EVERY row, then the stable order on (distance, row)), with no assumption on the data.
+//
+// grid = #CUs x 1024 threads; a wave walks rows wave, wave + #waves, ... in ascending order, computes
+// the reference formula for each (exact_metric_wave) and keeps its best `kk` <= 64 in REGISTERS, one
+// entry per lane, sorted (insert = ballot + popcount + one shuffle).  Per workgroup the 16 wave lists
+// are merged in LDS and written out; the last workgroup to arrive (device-scope fence + counter)
+// merges the per-workgroup lists the same way and writes the query's results.  Device-gated: the kernel
+// reads the number of flagged queries and exits at once when it is 0 (one empty dispatch, ~5 us).
+// k > 64 runs as ceil(k / 64) rounds; round r only admits rows strictly after the last result of
+// round r - 1 in the (distance, row) order.
+constexpr int kExactThreads = 1024;
+constexpr int kExactWaves = kExactThreads / 64;
+constexpr int kExactRound = 64;
+
+struct ExactArgs {
+    const float *docs;         // f32 [n][d], or null with
+    const _Float16 *docs16;    // f16 [n][d]
+    const float *doc_sq;
+    uint32_t n_rows;
+    int d;
+    int metric;
+    const double *q;           // [b][d]
+    const double *q_sq;
+    const double *q_norm;
+    const int32_t *nflag;
+    const int32_t *flagged;
+    int k;
+    int round;
+    int list_stride;           // min(k, kExactRound)
+    uint64_t *part;            // [b][grid][list_stride][2]: {dist bits, valid << 32 | row}
+    uint32_t *arrive;          // [b], zero between launches
+    double *bound_dist;        // [b] last result of the previous round
+    uint32_t *bound_row;       // [b]
+    const int64_t *chunk_ids;
+    const int32_t *doc_ids;
+    int64_t row_offset;
+    int32_t *out_doc;
+    int64_t *out_chunk;
+    int64_t *out_row;
+    double *out_dist;
+    int32_t *out_count;
+    int32_t *out_flags;
+};
+
+// lane i of the wave holds the i-th best entry (i < cnt); every argument is wave-uniform
+__device__ __forceinline__ void exact_wave_insert(double nd, uint32_t nr, int kk, int lane, double &my_d, uint32_t &my_r,
+                                                  int &cnt) {
+    const unsigned long long before = __ballot(lane < cnt && dist_before(my_d, my_r, nd, nr));
+    const int pos = __popcll(before);  // sorted: the entries before the new one are lanes [0, pos)
+    if (pos >= kk) return;
+    const double up_d = __shfl_up(my_d, 1, 64);
+    const uint32_t up_r = __shfl_up(my_r, 1, 64);
+    if (lane > pos) {
+        my_d = up_d;
+        my_r = up_r;
+    } else if (lane == pos) {
+        my_d = nd;
+        my_r = nr;
+    }
+    cnt = cnt < kk ? cnt + 1 : kk;
+}
+
+// The workgroup's 16 wave lists -> rank of this thread's entry among all valid ones (-1: none)
+__device__ __forceinline__ int exact_block_rank(double my_d, uint32_t my_r, int cnt, double *s_d, uint32_t *s_r, int *s_cnt,
+                                                int tid, int *total_out) {
+    const int lane = tid & 63, wave = tid >> 6;
+    __syncthreads();  // previous use of the staging arrays is over
+    s_d[tid] = my_d;
+    s_r[tid] = my_r;
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    int total = 0, rank = 0;
+    const bool valid = lane < cnt;
+    for (int w = 0; w < kExactWaves; ++w) {
+        const int c = s_cnt[w];
+        total += c;
+        if (valid)
+            for (int l = 0; l < c; ++l) rank += dist_before(s_d[w * 64 + l], s_r[w * 64 + l], my_d, my_r) ? 1 : 0;
+    }
+    *total_out = total;
+    return valid ? rank : -1;
+}
+
+__global__ __launch_bounds__(kExactThreads) void exact_topk_kernel(ExactArgs a) {
+    __shared__ double s_d[kExactThreads];
+    __shared__ uint32_t s_r[kExactThreads];
+    __shared__ int s_cnt[kExactWaves];
+    __shared__ int s_last;
+    const int nf = *a.nflag;
+    if (nf == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kk = min(kExactRound, a.k - kExactRound * a.round);
+    const uint32_t G = gridDim.x;
+    for (int f = 0; f < nf; ++f) {
+        const int qi = a.flagged[f];
+        const double *q = a.q + (size_t)qi * a.d;
+        const double q_sq = a.q_sq[qi], q_norm = a.q_norm[qi];
+        const bool bounded = a.round > 0;
+        const double b_d = bounded ? a.bound_dist[qi] : 0.0;
+        const uint32_t b_r = bounded ? a.bound_row[qi] : 0u;
+        double my_d = 0.0;
+        uint32_t my_r = 0;
+        int cnt = 0;
+        for (uint32_t row = blockIdx.x * kExactWaves + wave; row < a.n_rows; row += G * kExactWaves) {
+            double rv;
+            const double dist = a.docs16 ? exact_metric_wave(a.docs16 + (size_t)row * a.d, q, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lane, &rv)
+                                         : exact_metric_wave(a.docs + (size_t)row * a.d, q, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lane, &rv);
+            if (bounded && !dist_before(b_d, b_r, dist, row)) continue;
+            exact_wave_insert(dist, row, kk, lane, my_d, my_r, cnt);
+        }
+        int total;
+        int rank = exact_block_rank(my_d, my_r, cnt, s_d, s_r, s_cnt, tid, &total);
+        uint64_t *mine = a.part + ((size_t)f * G + blockIdx.x) * a.list_stride * 2;
+        if (rank >= 0 && rank < kk) {
+            mine[2 * rank] = (uint64_t)__double_as_longlong(my_d);
+            mine[2 * rank + 1] = (1ull << 32) | my_r;
+        }
+        if (tid < kk && tid >= total) {
+            mine[2 * tid] = 0;
+            mine[2 * tid + 1] = 0;
+        }
+        __threadfence();  // this workgroup's list is visible device-wide before its arrival is
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(&a.arrive[f], 1u) == G - 1;
+        __syncthreads();
+        if (!s_last) continue;  // uniform per workgroup
+        __threadfence();
+        // ---- the last workgroup: merge the G lists (each sorted, invalid entries last) ----
+        my_d = 0.0;
+        my_r = 0;
+        cnt = 0;
+        for (uint32_t g = wave; g < G; g += kExactWaves) {
+            const uint64_t *l = a.part + ((size_t)f * G + g) * a.list_stride * 2;
+            for (int j = 0; j < kk; ++j) {
+                const uint64_t w1 = __hip_atomic_load(l + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(w1 >> 32)) break;
+                const double dj = __longlong_as_double((long long)__hip_atomic_load(l + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const int before = cnt;
+                const double worst_d = __shfl(my_d, kk - 1, 64);
+                const uint32_t worst_r = __shfl(my_r, kk - 1, 64);
+                if (before == kk && !dist_before(dj, (uint32_t)w1, worst_d, worst_r)) break;  // the rest of this list is worse still
+                exact_wave_insert(dj, (uint32_t)w1, kk, lane, my_d, my_r, cnt);
+            }
+        }
+        rank = exact_block_rank(my_d, my_r, cnt, s_d, s_r, s_cnt, tid, &total);
+        const int kout = total < kk ? total : kk;
+        if (rank >= 0 && rank < kout) {
+            const size_t o = (size_t)qi * a.k + (size_t)kExactRound * a.round + rank;
+            if (a.out_row) a.out_row[o] = a.row_offset + (int64_t)my_r;
+            if (a.out_dist) a.out_dist[o] = my_d;
+            if (a.out_doc) a.out_doc[o] = a.doc_ids ? a.doc_ids[my_r] : 0;
+            if (a.out_chunk) a.out_chunk[o] = a.chunk_ids ? a.chunk_ids[my_r] : (int64_t)my_r;
+            if (rank == kout - 1) {
+                a.bound_dist[qi] = my_d;
+                a.bound_row[qi] = my_r;
+            }
+        }
+        if (tid == 0) {
+            a.arrive[f] = 0;
+            if (a.round == 0) {
+                if (a.out_count) a.out_count[qi] = (int)((uint32_t)a.k < a.n_rows ? (uint32_t)a.k : a.n_rows);
+                if (a.out_flags) a.out_flags[qi] = MIR_FLAG_EXACT_PASS;
+            }
+        }
+    }
+}
+
+// every query takes the exact pass (k beyond the scan's candidate lists)
+__global__ __launch_bounds__(256) void flag_all_kernel(int b, int32_t *__restrict__ nflag, int32_t *__restrict__ flagged) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < b) flagged[i] = i;
+    if (i == 0) *nflag = b;
 }
 
 // ---------------------------------------------------------------- sample thresholds

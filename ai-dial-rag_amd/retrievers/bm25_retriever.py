@@ -51,6 +51,10 @@ class DeviceBM25:
         return {"n_docs": n.value, "vocab": v.value, "n_postings": p.value, "avgdl": a.value, "average_idf": ai.value,
                 "hbm_bytes": hb.value}
 
+    def tune(self, queries_per_workgroup: int = 0) -> None:
+        """Pin the fast pass's pipeline depth (1..64 queries per workgroup; 0 = per call).  Results do not depend on it."""
+        nat.check(nat.lib.mir_bm25_tune(self._h, queries_per_workgroup))
+
     def idf(self) -> np.ndarray:
         out = np.zeros(self.vocab, np.float64)
         nat.check(nat.lib.mir_bm25_idf(self._h, nat.ptr(out)))

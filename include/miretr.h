@@ -57,11 +57,14 @@ extern "C" {
 #define MIR_DTYPE_F32 0
 #define MIR_DTYPE_F16 1
 
-/* per-query result flags (out_flags) */
-#define MIR_FLAG_UNCERTAIN 1 /* the a-posteriori exactness check could not prove
-                                the candidate set complete (exact ties at the
-                                cut, or scores denser than the scan's error
-                                bound); results are still the best found */
+/* per-query result flags (out_flags).  Results are ALWAYS the reference's: the
+ * filter scan proves its candidate set complete for almost every query; a query
+ * it cannot prove (more near-ties at the cut than its lists hold, or k beyond
+ * the lists) is recomputed by the exact pass - the reference formula in float64
+ * over every row, stable order on (distance, row) - before the call returns /
+ * in stream order.  The flag only reports which route a query took. */
+#define MIR_FLAG_UNCERTAIN 1  /* never returned since ABI 2 (kept for callers of ABI 1) */
+#define MIR_FLAG_EXACT_PASS 2 /* answered by the exact pass */
 
 int32_t mir_abi_version(void);
 const char *mir_last_error(void);
@@ -122,7 +125,8 @@ int32_t mir_index_info(const mir_index *idx, int64_t *n, int32_t *d, int32_t *dt
  *   out_doc / out_chunk : the (doc_id, chunk_id) pairs, best first
  *   out_row             : global flattened row (row_offset + local row)
  *   out_dist            : the metric value in float64 (reference promotion)
- * out_count[q] = min(k, n).  out_flags may be NULL.
+ * out_count[q] = min(k, n).  Any k >= 1 (the reference takes any `limit`,
+ * embeddings_index.py:58,81).  out_flags may be NULL.
  * Any of out_doc / out_chunk / out_row / out_dist may be NULL. */
 int32_t mir_index_search(mir_index *idx, const double *queries_host, int32_t b, int32_t k, int32_t metric,
                          int32_t *out_doc, int64_t *out_chunk, int64_t *out_row, double *out_dist,
@@ -206,6 +210,10 @@ int32_t mir_compact_term_ids(const int32_t *ids, int64_t n, int32_t vocab, int32
                              int32_t *n_used);
 
 int32_t mir_bm25_destroy(mir_bm25 *h);
+/* Tuning / test hook: how many queries one workgroup of the fast scoring pass walks through its document tile
+ * (the depth of its software pipeline), 1..64; 0 = chosen per call from the batch size (the default).  Results do
+ * not depend on it. */
+int32_t mir_bm25_tune(mir_bm25 *h, int32_t queries_per_workgroup);
 int32_t mir_bm25_info(const mir_bm25 *h, int64_t *n_docs, int32_t *vocab, int64_t *n_postings, double *avgdl,
                       double *average_idf, int64_t *hbm_bytes);
 /* the model's idf table, float64[vocab] (0 for terms that never occur) */

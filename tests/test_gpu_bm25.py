@@ -174,6 +174,42 @@ def test_frequent_terms_large_batch(br, batch):
         np.testing.assert_array_equal(sc[i], want[top])
 
 
+@pytest.mark.parametrize("qc", [1, 2, 3, 64])
+def test_short_pipelines_long_query_queues(br, qc):
+    """The shape of the round-1 development fault (gpurun_out/f2.log: grid (123 tiles, ceil(4096 / 3)) = 3 queries per
+    workgroup, 4096 queries of very frequent terms): the fast pass with its pipeline depth pinned
+    to 1, 2, 3 (prologue and epilogue overlap; tails of 1 and 2 queries: 4099 = 3 * 1366 + 1) and to the maximum,
+    over 8 tiles with every tile listing more touched documents than the candidate list holds, out-of-vocabulary
+    and repeated terms mixed in.  Bit-identical to the oracle on a strided sample and across the pinned depths."""
+    indptr, toks = synth(60000, 3000, 21)
+    dev = br.DeviceBM25.from_token_ids(indptr, toks, 3000)
+    o = ob.BM25OkapiCSR(indptr, toks, 3000)
+    rng = np.random.default_rng(23)
+    batch = 4099
+    qs = [[int(t) for t in rng.integers(0, 40, rng.integers(1, 7))] for _ in range(batch)]
+    for i in range(5, batch, 97):
+        qs[i][0] = 3000 + i  # out of vocabulary
+    for i in range(11, batch, 101):
+        qs[i] = qs[i] + qs[i][:1]  # repeated term
+    qs[batch - 1] = []  # an empty query at the very end of the queue
+    auto = dev.search(qs, 10)
+    dev.tune(qc)
+    try:
+        idx, sc, cnt = dev.search(qs, 10)
+    finally:
+        dev.tune(0)
+    np.testing.assert_array_equal(idx, auto[0])
+    np.testing.assert_array_equal(sc, auto[1])
+    np.testing.assert_array_equal(cnt, auto[2])
+    for i in list(range(0, batch, 41)) + [batch - 3, batch - 2, batch - 1]:
+        want = o.get_scores(qs[i])
+        top = ob.top_n_indexes(want, 10)
+        np.testing.assert_array_equal(idx[i], top, err_msg=f"qc={qc} query {i} {qs[i]}")
+        np.testing.assert_array_equal(sc[i], want[top])
+    with pytest.raises(ValueError):
+        dev.tune(65)
+
+
 def test_device_buffer_api_matches_host_api(br):
     """mir_bm25_search_device: queries, results and scratch in HBM, asynchronous on the caller's stream."""
     import torch

@@ -401,11 +401,17 @@ def test_register_ring_kernel_large_k(amd, metric):
         np.testing.assert_allclose(dist[i], wdist, rtol=0, atol=2e-7)
 
 
-def test_k_above_list_capacity_is_refused_not_wrong(amd):
+def test_k_above_list_capacity_takes_the_exact_pass(amd):
+    """k beyond the filter's candidate lists is answered by the exact pass alone (tests/test_gpu_exact_pass.py)."""
+    from oracle import embeddings_index as oi
+
     rng = np.random.default_rng(4)
-    dev = amd.ei.DeviceIndex.from_host(unit(rng.standard_normal((500, 32))))
-    with pytest.raises(NotImplementedError):
-        dev.search(rng.standard_normal((1, 32)), 100, "inner_product")
+    docs = unit(rng.standard_normal((500, 32)))
+    dev = amd.ei.DeviceIndex.from_host(docs)
+    q = rng.standard_normal((1, 32))
+    _, _, rows, _, cnt, flags = dev.search(q, 100, "inner_product")
+    assert cnt[0] == 100 and flags[0] == amd.nat.FLAG_EXACT_PASS
+    np.testing.assert_array_equal(rows[0], oi.find_flat(q[0], docs, "inner_product", 100)[0])
     small = amd.ei.DeviceIndex.from_host(unit(rng.standard_normal((40, 32))))
     _, _, rows, _, cnt, _ = small.search(rng.standard_normal((1, 32)), 100, "inner_product")
     assert cnt[0] == 40 and sorted(rows[0, :40]) == list(range(40))
