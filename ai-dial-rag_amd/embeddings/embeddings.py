@@ -35,6 +35,8 @@ EMBEDDINGS_BATCH_SIZE = 128  # embeddings.py:24-26 (outer batch; the GPU path pa
 EMBEDDING_LENGTH = 384       # embeddings.py:69 finds this by encoding ""; bge-small-en is 384 by construction
 BGE_QUERY_INSTRUCTION_EN = "Represent this question for searching relevant passages: "
 MAX_TOKENS = 512
+DOC_BATCHES_PER_PASS = 64    # outer batches one shared encode may carry (8192 chunks ~ 18 full passes of the kernels)
+BUILD_IN_FLIGHT = 32         # outer batches `build_embeddings` keeps in flight (their tokenisation runs in threads)
 
 BGE_EMBEDDINGS_MODEL_NAME_OR_PATH = os.environ.get("BGE_EMBEDDINGS_MODEL_PATH", "epam/bge-small-en")
 
@@ -125,12 +127,39 @@ class BgeEncoder:
         return enc["input_ids"]
 
     def embed_documents(self, texts: List[str]) -> List[List[float]]:
-        texts = [t.replace("\n", " ") for t in texts]  # HuggingFaceBgeEmbeddings.embed_documents
-        return self.encode_ids(self._tokenize(texts)).tolist()
+        return [e.tolist() for e in self.embed_documents_numpy(texts)]
 
     def embed_documents_numpy(self, texts: List[str]) -> List[np.ndarray]:
-        texts = [t.replace("\n", " ") for t in texts]
-        return list(self.encode_ids(self._tokenize(texts)))
+        """One outer batch of chunk texts (embeddings.py:79-91; the reference's callers hand 128 at a time,
+        batched.py:35-53).  A throughput pass of the encoder costs the same whatever its fill (every workgroup
+        walks all weights; a full pass is 3072 token tiles ~ 450 chunks of 220 tokens), so concurrent outer
+        batches - several documents being indexed, or `build_embeddings` keeping its batches in flight - are
+        tokenised in their own threads and share passes (group commit).  An embedding does not depend on what
+        else rides in its pass (tests/test_gpu_encoder.py::test_batching_is_invariant)."""
+        if not texts:
+            return []
+        texts = [t.replace("\n", " ") for t in texts]  # HuggingFaceBgeEmbeddings.embed_documents
+        return list(self._doc_commit().submit(self._tokenize(texts))[0])
+
+    def _doc_commit(self):
+        gc = getattr(self, "_dc", None)
+        if gc is None:
+            with _QC_LOCK:
+                gc = getattr(self, "_dc", None)
+                if gc is None:
+                    from ..retrievers._group_commit import _GroupCommit  # lazy: retrievers imports this module
+
+                    def run(batches):  # list of outer batches (lists of token-id sequences) -> one encode
+                        flat = [s for b in batches for s in b]
+                        emb = self.encode_ids(flat)
+                        out, at = [], 0
+                        for b in batches:
+                            out.append(emb[at : at + len(b)])
+                            at += len(b)
+                        return (out,)
+
+                    gc = self._dc = _GroupCommit(run, max_batch=DOC_BATCHES_PER_PASS)
+        return gc
 
     def embed_query(self, text: str) -> List[float]:
         """One query (embeddings.py:93-96).  Encoding 1 or 16 short queries costs the same ~0.45 ms pass, and the
@@ -186,6 +215,24 @@ def bge_embedding_impl() -> BgeEncoder:
     return _impl
 
 
+_indexing_pool = None
+
+
+def _indexing_executor():
+    """Threads that tokenise one outer batch each and then wait for their shared encoder pass.  Separate from the
+    default executor (where `find` and BM25 run, semantic_retriever.py:54-56) like the reference's
+    indexing_embeddings_pool (cpu_pools.py:25-30, 50-53) - but not ONE thread: the GPU pass is shared, the CPU work
+    before it (tokenisation) is what the threads parallelise."""
+    global _indexing_pool
+    if _indexing_pool is None:
+        with _QC_LOCK:
+            if _indexing_pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+
+                _indexing_pool = ThreadPoolExecutor(max_workers=BUILD_IN_FLIGHT, thread_name_prefix="bge-index")
+    return _indexing_pool
+
+
 class AsyncEmbeddings:
     """embeddings.py:72-96.  The sync methods raise upstream too."""
 
@@ -196,10 +243,10 @@ class AsyncEmbeddings:
         raise NotImplementedError()
 
     async def aembed_documents(self, texts: List[str]) -> List[List[float]]:
-        return await asyncio.get_running_loop().run_in_executor(None, bge_embedding_impl().embed_documents, texts)
+        return await asyncio.get_running_loop().run_in_executor(_indexing_executor(), bge_embedding_impl().embed_documents, texts)
 
     async def aembed_documents_numpy(self, texts: List[str]) -> List[np.ndarray]:
-        return await asyncio.get_running_loop().run_in_executor(None, bge_embedding_impl().embed_documents_numpy, texts)
+        return await asyncio.get_running_loop().run_in_executor(_indexing_executor(), bge_embedding_impl().embed_documents_numpy, texts)
 
     async def aembed_query(self, text: str) -> List[float]:
         return await asyncio.get_running_loop().run_in_executor(None, bge_embedding_impl().embed_query, text)
@@ -208,15 +255,47 @@ class AsyncEmbeddings:
 bge_embedding = AsyncEmbeddings()
 
 
+def _progress(n_batches: int, stageio):
+    """The reference's TqdmProgressBar (batched.py:9-28): one line per update, no carriage returns."""
+    if stageio is None:
+        return None
+    from tqdm.std import tqdm as std_tqdm
+
+    class Bar(std_tqdm):
+        @staticmethod
+        def status_printer(file):
+            return file.write
+
+    return Bar(total=n_batches, file=stageio, bar_format="{l_bar}{r_bar}\n", mininterval=10, maxinterval=30, smoothing=0.5, position=0)
+
+
 async def build_embeddings(texts: Iterable[str], stageio=None) -> List[np.ndarray]:
-    """embeddings.py:102-108: outer batches of EMBEDDINGS_BATCH_SIZE, strictly one after the other (batched.py:42-53)."""
+    """embeddings.py:102-108 + batched.py:35-53: the texts go through `aembed_documents_numpy` in outer batches of
+    EMBEDDINGS_BATCH_SIZE, results in order, progress per batch.  The reference awaits one batch at a time because
+    each is a heavy CPU job; here a batch is ~0.3 of one GPU pass, so up to BUILD_IN_FLIGHT batches are kept in
+    flight and coalesce into full passes inside `BgeEncoder.embed_documents_numpy` - what a caller sees (batch
+    size, order, progress lines) is unchanged."""
+    texts = list(texts)
+    batches = [texts[i : i + EMBEDDINGS_BATCH_SIZE] for i in range(0, len(texts), EMBEDDINGS_BATCH_SIZE)]
+    gate = asyncio.Semaphore(BUILD_IN_FLIGHT)
+
+    async def one(batch):
+        async with gate:
+            return await bge_embedding.aembed_documents_numpy(batch)
+
+    tasks = [asyncio.ensure_future(one(b)) for b in batches]
+    bar = _progress(len(batches), stageio)
     out: List[np.ndarray] = []
-    batch: List[str] = []
-    for t in texts:
-        batch.append(t)
-        if len(batch) == EMBEDDINGS_BATCH_SIZE:
-            out.extend(await bge_embedding.aembed_documents_numpy(batch))
-            batch = []
-    if batch:
-        out.extend(await bge_embedding.aembed_documents_numpy(batch))
+    try:
+        for t in tasks:
+            out.extend(await t)
+            if bar is not None:
+                bar.update(1)
+    except BaseException:
+        for t in tasks:
+            t.cancel()
+        raise
+    finally:
+        if bar is not None:
+            bar.close()
     return out

@@ -207,7 +207,7 @@ class EmbeddingsIndex:
         self._built = False
         self._lock = threading.Lock()
         self._cache_sources = tuple(cache_sources) if cache_sources is not None else None
-        self._commit = _GroupCommit(lambda qs: self.search_arrays(np.stack(qs)))
+        self._commit = _GroupCommit(lambda qs: self.search_arrays(np.stack(qs)), validate=self._check_query)
 
     @property
     def doc_indexes(self) -> List[DocIndex]:
@@ -259,8 +259,20 @@ class EmbeddingsIndex:
                 self._built = True
             return self._dev
 
+    def _check_query(self, query) -> np.ndarray:
+        """Shape / dtype of ONE query, checked in the caller's thread before it joins a shared pass: a malformed
+        query raises for its own caller only."""
+        q = np.asarray(query, dtype=np.float64)
+        if q.ndim != 1:
+            raise ValueError(f"query must be one vector, got shape {q.shape}")
+        dev = self._device_index()
+        if dev is not None and q.shape[0] != dev.d:
+            raise ValueError(f"query shape {q.shape} does not match index dimension {dev.d}")
+        return q
+
     def search_arrays(self, queries: np.ndarray):
-        """B queries -> (doc_ids, chunk_ids, dist, count, flags) arrays, best first."""
+        """B queries -> (doc_ids, chunk_ids, dist, count, flags) arrays, best first.  flags: 0, or
+        nat.FLAG_EXACT_PASS for a query the exact pass answered; results are the reference's either way."""
         Metric(self.metric)  # unknown metric -> ValueError, as embeddings_index.py:54
         dev = self._device_index()
         if dev is None:
@@ -282,7 +294,7 @@ class EmbeddingsIndex:
         """One query (embeddings_index.py:62-89).  Concurrent callers share search passes (`_GroupCommit`);
         the result of a query does not depend on what else rides in its pass."""
         Metric(self.metric)
-        doc, chunk, _dist, cnt, _flags = self._commit.submit(np.asarray(query, dtype=np.float64))
+        doc, chunk, _dist, cnt, _flags = self._commit.submit(query)
         return [to_metadata_doc(int(doc[j]), int(chunk[j]), retrieval_type=self.retrieval_type) for j in range(int(cnt))]
 
 

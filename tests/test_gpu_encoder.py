@@ -118,3 +118,64 @@ def test_concurrent_query_encodes_share_passes():
     [t.join() for t in th]
     assert got == want  # a sequence's embedding does not depend on what else is in the batch (bit-identical)
     assert gc.passes - p0 < 48
+
+
+def _write_model_dir(path, model):
+    """A local Hugging Face directory as BGE_EMBEDDINGS_MODEL_PATH expects (embeddings.py:30-32 upstream): random
+    weights of the bge-small-en shape + a small WordPiece vocabulary (no real checkpoint exists offline)."""
+    import json
+    import os
+
+    from safetensors.numpy import save_file
+
+    os.makedirs(path, exist_ok=True)
+    save_file({k: v.detach().numpy().copy() for k, v in model.state_dict().items()}, os.path.join(path, "model.safetensors"))
+    words = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    words += list("abcdefghijklmnopqrstuvwxyz0123456789.,!?;:'\"()-") + ["##" + c for c in "abcdefghijklmnopqrstuvwxyz0123456789"]
+    words += ["the", "alps", "climate", "what", "is", "in", "of", "and", "mountain", "range", "##s", "##ing", "##ed", "##ly",
+              "represent", "this", "question", "for", "searching", "relevant", "passages", "snow", "valley", "river"]
+    open(os.path.join(path, "vocab.txt"), "w").write("\n".join(words) + "\n")
+    json.dump({"tokenizer_class": "BertTokenizer", "do_lower_case": True, "model_max_length": 512},
+              open(os.path.join(path, "tokenizer_config.json"), "w"))
+    return words
+
+
+def test_build_embeddings_through_the_product_surface(setup, tmp_path, monkeypatch):
+    """`build_embeddings` / `aembed_query` as SemanticRetriever.build_index and _aget_relevant_documents call them
+    (semantic_retriever.py:52-66 upstream), with the encoder loaded the way the product loads it: from the local
+    model directory named by BGE_EMBEDDINGS_MODEL_PATH, device from BGE_EMBEDDINGS_DEVICE=auto.  700 chunks = 6 outer
+    batches of 128 that coalesce into shared passes; every embedding equals a float32 transformers forward of the
+    same tokens (cosine >= 0.9995) and is independent of the batching."""
+    import asyncio
+    import io
+
+    from aidial_rag_amd.embeddings import embeddings as emb
+
+    model, _enc, _seqs, oe = setup
+    words = _write_model_dir(str(tmp_path / "bge"), model)
+    monkeypatch.setattr(emb, "BGE_EMBEDDINGS_MODEL_NAME_OR_PATH", str(tmp_path / "bge"))
+    monkeypatch.setenv("BGE_EMBEDDINGS_DEVICE", "auto")
+    emb.set_bge_embedding_impl(None)
+    try:
+        impl = emb.bge_embedding_impl()  # from_pretrained_dir + AutoTokenizer
+        assert impl.layers == 12 and impl.tokenizer is not None
+        rng = np.random.default_rng(5)
+        plain = [w for w in words[104:] if not w.startswith("##") and len(w) > 1]
+        texts = [" ".join(rng.choice(plain, rng.integers(3, 120))) + (".\nnext line" if i % 3 == 0 else "") for i in range(700)]
+        stage = io.StringIO()
+        got = asyncio.run(emb.build_embeddings(texts, stage))
+        assert len(got) == 700 and "6/6" in stage.getvalue()
+        ids = impl.tokenizer([t.replace("\n", " ") for t in texts], add_special_tokens=True, truncation=True, max_length=512)["input_ids"]
+        assert impl._doc_commit().passes < 6  # outer batches shared passes
+        pick = list(range(0, 700, 23))
+        want = oe.embed(model, [ids[i] for i in pick])
+        cos = (np.stack([got[i] for i in pick]) * want).sum(1)
+        assert cos.min() > 0.9995, cos
+        alone = impl.encode_ids([ids[i] for i in pick])
+        np.testing.assert_array_equal(np.stack([got[i] for i in pick]), alone)  # batching-invariant, bit for bit
+        q = asyncio.run(emb.bge_embedding.aembed_query("what is the climate\nin the alps?"))
+        assert isinstance(q, list) and len(q) == 384 and isinstance(q[0], float)
+        qids = impl.tokenizer([emb.BGE_QUERY_INSTRUCTION_EN + "what is the climate in the alps?"])["input_ids"]
+        assert float(np.dot(np.asarray(q, np.float32), oe.embed(model, qids)[0])) > 0.9995
+    finally:
+        emb.set_bge_embedding_impl(None)
