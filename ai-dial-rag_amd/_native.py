@@ -78,6 +78,9 @@ def _load():
         "mir_stem_english": ([vp, i64, C.c_char, vp, vp], i32),
         "mir_bm25_destroy": ([vp], i32),
         "mir_bm25_tune": ([vp, i32], i32),
+        "mir_bm25_corpus_stats": ([vp, vp, vp, vp, vp], i32),
+        "mir_bm25_idf_from_stats": ([vp, vp, i32, i64, C.c_double, vp, vp], i32),
+        "mir_bm25_set_global_stats": ([vp, vp, C.c_double, C.c_double], i32),
         "mir_bm25_info": ([vp, vp, vp, vp, vp, vp, vp], i32),
         "mir_bm25_idf": ([vp, vp], i32),
         "mir_bm25_scores": ([vp, vp, i32, vp], i32),
@@ -91,6 +94,7 @@ def _load():
         "mir_encoder_encode_to_device": ([vp, vp, vp, i32, i32, vp, vp], i32),
         "mir_encoder_debug_hidden": ([vp, vp, vp, i32, i32, vp, vp, i64], i32),
         "mir_rrf_fuse": ([vp, vp, vp, i32, i32, vp, vp, vp], i32),
+        "mir_rrf_fuse_batch": ([vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp], i32),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "bm25_build.h"
+#include <cstdint>
 #include "common.h"
 
 namespace mir {
@@ -644,6 +645,11 @@ struct mir_bm25 {
     int64_t *t_ptr = nullptr;
     uint32_t *t_tile = nullptr;
     double *idf = nullptr;
+    int32_t *p_tf = nullptr;      // term frequency per posting and tokens per document: what the weights derive from
+    int32_t *d_doclen = nullptr;  // (mir_bm25_set_global_stats re-derives them for a sharded corpus's global avgdl)
+    double k1 = 1.5, b = 0.75, epsilon = 0.25;
+    int64_t total_tokens = 0;
+    std::vector<int64_t> h_df, h_first;  // per term: documents containing it, position of its first token (INT64_MAX = absent)
     int64_t hbm_bytes = 0;
     std::mutex mu;  // serialises use of the scratch below (searches on one handle run one at a time)
     void *scratch = nullptr;
@@ -664,6 +670,8 @@ static void free_bm25(mir_bm25 *h) {
     (void)hipFree(h->t_ptr);
     (void)hipFree(h->t_tile);
     (void)hipFree(h->idf);
+    (void)hipFree(h->p_tf);
+    (void)hipFree(h->d_doclen);
     (void)hipFree(h->scratch);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -690,6 +698,35 @@ static int32_t ensure_scratch(mir_bm25 *h, size_t need) {
 }  // namespace mir
 
 extern "C" {
+
+// BM25Okapi._calc_idf (rank-bm25 0.2.2) from corpus statistics: idf = ln(N - n + 0.5) - ln(n + 0.5) through libm (the
+// package's math.log), summed in order of first appearance - the insertion order of the package's dict, which fixes the
+// float64 rounding of the average - and terms with a negative idf floored to epsilon * average.  Used by
+// mir_bm25_create on its own documents and, with all-reduced statistics, by every rank of a document-sharded corpus.
+int32_t mir_bm25_idf_from_stats(const int64_t *df, const int64_t *first_pos, int32_t vocab, int64_t n_docs, double epsilon,
+                                double *out_idf, double *out_average_idf) {
+    MIR_REQUIRE(df && first_pos && out_idf && vocab >= 1 && n_docs >= 0, "bad argument");
+    std::vector<int32_t> order;
+    for (int32_t t = 0; t < vocab; ++t) {
+        out_idf[t] = 0.0;
+        MIR_REQUIRE(df[t] >= 0 && df[t] <= n_docs, "df[%d]=%lld outside [0, %lld]", t, (long long)df[t], (long long)n_docs);
+        if (df[t] > 0) order.push_back(t);
+    }
+    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return first_pos[x] < first_pos[y] || (first_pos[x] == first_pos[y] && x < y); });
+    double idf_sum = 0.0;
+    std::vector<int32_t> negative;
+    for (int32_t t : order) {
+        const double v = std::log((double)(n_docs - df[t]) + 0.5) - std::log((double)df[t] + 0.5);
+        out_idf[t] = v;
+        idf_sum += v;
+        if (v < 0) negative.push_back(t);
+    }
+    const double avg = order.empty() ? 0.0 : idf_sum / (double)order.size();
+    const double eps = epsilon * avg;
+    for (int32_t t : negative) out_idf[t] = eps;
+    if (out_average_idf) *out_average_idf = avg;
+    return MIR_OK;
+}
 
 // Builds the model from token-id documents.  `indptr[i]:indptr[i+1]` slices the
 // tokens of document i in text order.  If `idf_override` is non-NULL it supplies
@@ -724,6 +761,7 @@ int32_t mir_bm25_create(const int64_t *indptr, const int32_t *term_ids, int64_t 
     Bm25Built built;
     rc = bm25_build_device(indptr, term_ids, n_docs, vocab, k1, b, h->avgdl, kBm25Tile, &built);
     h->p_doc = built.p_doc; h->p_w = built.p_w; h->t_ptr = built.t_ptr; h->t_tile = built.t_tile;  // freed with h
+    h->p_tf = built.p_tf; h->d_doclen = built.doc_len; h->k1 = k1; h->b = b; h->epsilon = epsilon; h->total_tokens = total;
     h->n_postings = built.n_postings; h->ntiles = std::max(1, built.ntiles); h->hbm_bytes += built.hbm_bytes;
     if (rc != MIR_OK) {
         free_bm25(h);
@@ -731,26 +769,21 @@ int32_t mir_bm25_create(const int64_t *indptr, const int32_t *term_ids, int64_t 
     }
 
     // ---- BM25Okapi._calc_idf on the host: V logarithms, summed in order of first appearance (dict order) ----
+    h->h_df.assign(vocab, 0);
+    h->h_first.assign(vocab, INT64_MAX);
+    for (int32_t t = 0; t < vocab; ++t) {
+        h->h_df[t] = built.t_ptr_host[t + 1] - built.t_ptr_host[t];
+        if (h->h_df[t] > 0) h->h_first[t] = (int64_t)built.first_pos[t];
+    }
     h->h_idf.assign(vocab, 0.0);
     if (idf_override) {
         std::memcpy(h->h_idf.data(), idf_override, sizeof(double) * vocab);
     } else {
-        std::vector<int32_t> order;
-        for (int32_t t = 0; t < vocab; ++t)
-            if (built.t_ptr_host[t + 1] > built.t_ptr_host[t]) order.push_back(t);
-        std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return built.first_pos[x] < built.first_pos[y]; });
-        double idf_sum = 0.0;
-        std::vector<int32_t> negative;
-        for (int32_t t : order) {
-            const int64_t df = built.t_ptr_host[t + 1] - built.t_ptr_host[t];
-            const double v = std::log((double)(n_docs - df) + 0.5) - std::log((double)df + 0.5);
-            h->h_idf[t] = v;
-            idf_sum += v;
-            if (v < 0) negative.push_back(t);
+        rc = mir_bm25_idf_from_stats(h->h_df.data(), h->h_first.data(), vocab, n_docs, epsilon, h->h_idf.data(), &h->average_idf);
+        if (rc != MIR_OK) {
+            free_bm25(h);
+            return rc;
         }
-        h->average_idf = idf_sum / (double)order.size();
-        const double eps = epsilon * h->average_idf;
-        for (int32_t t : negative) h->h_idf[t] = eps;
     }
 
     auto fail = [&](int32_t code) {
@@ -795,6 +828,32 @@ int32_t mir_compact_term_ids(const int32_t *ids, int64_t n, int32_t vocab, int32
         out_ids[j] = c;
     }
     *n_used = next;
+    return MIR_OK;
+}
+
+int32_t mir_bm25_corpus_stats(const mir_bm25 *h, int64_t *out_df, int64_t *out_first_pos, int64_t *out_total_tokens,
+                              int64_t *out_n_docs) {
+    MIR_REQUIRE(h != nullptr, "handle is NULL");
+    if (out_df) std::memcpy(out_df, h->h_df.data(), sizeof(int64_t) * h->vocab);
+    if (out_first_pos) std::memcpy(out_first_pos, h->h_first.data(), sizeof(int64_t) * h->vocab);
+    if (out_total_tokens) *out_total_tokens = h->total_tokens;
+    if (out_n_docs) *out_n_docs = h->n_docs;
+    return MIR_OK;
+}
+
+int32_t mir_bm25_set_global_stats(mir_bm25 *h, const double *idf_host, double avgdl, double average_idf) {
+    MIR_REQUIRE(h != nullptr && idf_host != nullptr, "NULL argument");
+    MIR_REQUIRE(avgdl > 0.0, "avgdl=%g must be positive", avgdl);
+    int32_t rc = use_device(h->device, nullptr);
+    if (rc != MIR_OK) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    rc = bm25_reweight_device(h->p_doc, h->p_tf, h->d_doclen, h->n_postings, h->k1, h->b, avgdl, h->p_w, h->stream);
+    if (rc != MIR_OK) return rc;
+    MIR_HIP(hipMemcpyAsync(h->idf, idf_host, sizeof(double) * h->vocab, hipMemcpyHostToDevice, h->stream));
+    MIR_HIP(hipStreamSynchronize(h->stream));
+    std::memcpy(h->h_idf.data(), idf_host, sizeof(double) * h->vocab);
+    h->avgdl = avgdl;
+    h->average_idf = average_idf;
     return MIR_OK;
 }
 

@@ -56,13 +56,31 @@ __global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *p, in
 __global__ __launch_bounds__(256) void postings_kernel(const uint64_t *__restrict__ uniq, const int32_t *__restrict__ tf,
                                                        int64_t n_post, const int64_t *__restrict__ indptr, double k1,
                                                        double b, double avgdl, int32_t *__restrict__ p_doc,
-                                                       double *__restrict__ p_w) {
+                                                       double *__restrict__ p_w, int32_t *__restrict__ p_tf) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_post; i += (int64_t)gridDim.x * 256) {
         const uint32_t doc = (uint32_t)uniq[i];
         const double dl = (double)(indptr[doc + 1] - indptr[doc]);
         const double denom_len = k1 * ((1.0 - b) + (b * dl) / avgdl);
         const double f = (double)tf[i];
         p_doc[i] = (int32_t)doc;
+        p_tf[i] = tf[i];
+        p_w[i] = (f * (k1 + 1.0)) / (f + denom_len);
+    }
+}
+
+__global__ __launch_bounds__(256) void doc_len_kernel(const int64_t *__restrict__ indptr, int64_t n_docs, int32_t *__restrict__ doc_len) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_docs; i += (int64_t)gridDim.x * 256)
+        doc_len[i] = (int32_t)(indptr[i + 1] - indptr[i]);
+}
+
+// the same expression as postings_kernel, operation for operation, for another avgdl
+__global__ __launch_bounds__(256) void reweight_kernel(const int32_t *__restrict__ p_doc, const int32_t *__restrict__ p_tf,
+                                                       const int32_t *__restrict__ doc_len, int64_t n_post, double k1, double b,
+                                                       double avgdl, double *__restrict__ p_w) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_post; i += (int64_t)gridDim.x * 256) {
+        const double dl = (double)doc_len[p_doc[i]];
+        const double denom_len = k1 * ((1.0 - b) + (b * dl) / avgdl);
+        const double f = (double)p_tf[i];
         p_w[i] = (f * (k1 + 1.0)) / (f + denom_len);
     }
 }
@@ -174,13 +192,20 @@ int32_t bm25_build_device(const int64_t *indptr, const int32_t *term_ids, int64_
     // products: owned by the caller from here on (freed by it on failure too)
     BUILD_TRY(hipMalloc((void **)&out->p_doc, std::max<size_t>((size_t)n_post * 4, 16)));
     BUILD_TRY(hipMalloc((void **)&out->p_w, std::max<size_t>((size_t)n_post * 8, 16)));
+    BUILD_TRY(hipMalloc((void **)&out->p_tf, std::max<size_t>((size_t)n_post * 4, 16)));
+    BUILD_TRY(hipMalloc((void **)&out->doc_len, std::max<size_t>((size_t)n_docs * 4, 16)));
     BUILD_TRY(hipMalloc((void **)&out->t_ptr, (size_t)(vocab + 1) * 8));
     BUILD_TRY(hipMalloc((void **)&out->t_tile, (size_t)vocab * (T + 1) * 4));
     out->n_postings = n_post;
     out->ntiles = T;
-    out->hbm_bytes = n_post * 12 + (int64_t)(vocab + 1) * 8 + (int64_t)vocab * (T + 1) * 4;
+    out->hbm_bytes = n_post * 16 + n_docs * 4 + (int64_t)(vocab + 1) * 8 + (int64_t)vocab * (T + 1) * 4;
     if (n_post) {
-        postings_kernel<<<dim3(grid_for(n_post)), dim3(256), 0, s>>>(d_uniq, d_tf, n_post, d_indptr, k1, b, avgdl, out->p_doc, out->p_w);
+        postings_kernel<<<dim3(grid_for(n_post)), dim3(256), 0, s>>>(d_uniq, d_tf, n_post, d_indptr, k1, b, avgdl, out->p_doc, out->p_w,
+                                                                    out->p_tf);
+        BUILD_TRY(hipGetLastError());
+    }
+    if (n_docs) {
+        doc_len_kernel<<<dim3(grid_for(n_docs)), dim3(256), 0, s>>>(d_indptr, n_docs, out->doc_len);
         BUILD_TRY(hipGetLastError());
     }
     term_offsets_kernel<<<dim3((unsigned)((vocab + 1 + 255) / 256)), dim3(256), 0, s>>>(d_uniq, n_post, vocab, out->t_ptr);
@@ -194,6 +219,15 @@ int32_t bm25_build_device(const int64_t *indptr, const int32_t *term_ids, int64_
     BUILD_TRY(hipMemcpyAsync(out->t_ptr_host.data(), out->t_ptr, (size_t)(vocab + 1) * 8, hipMemcpyDeviceToHost, s));
     BUILD_TRY(hipMemcpyAsync(out->first_pos.data(), d_first, (size_t)vocab * 8, hipMemcpyDeviceToHost, s));
     BUILD_TRY(hipStreamSynchronize(s));
+    return MIR_OK;
+}
+
+int32_t bm25_reweight_device(const int32_t *p_doc, const int32_t *p_tf, const int32_t *doc_len, int64_t n_postings, double k1,
+                             double b, double avgdl, double *p_w, void *stream) {
+    if (n_postings == 0) return MIR_OK;
+    reweight_kernel<<<dim3(grid_for(n_postings)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(p_doc, p_tf, doc_len, n_postings, k1,
+                                                                                                 b, avgdl, p_w);
+    BUILD_TRY(hipGetLastError());
     return MIR_OK;
 }
 

@@ -56,3 +56,22 @@ extern "C" int32_t mir_rrf_fuse(const int64_t *keys, const int32_t *list_ptr, co
     *out_count = (int32_t)order.size();
     return MIR_OK;
 }
+
+// b independent fusions in one call (a batch of queries, each with n_lists result lists): query q's lists are
+// list_ptr[q * (n_lists + 1) .. +n_lists], offsets into `keys` relative to key_base[q]; outputs are [b][cap] with
+// cap = the largest total of one query.  One ctypes crossing per batch instead of one per query (~5 us each).
+extern "C" int32_t mir_rrf_fuse_batch(const int64_t *keys, const int64_t *key_base, const int32_t *list_ptr, const double *weights,
+                                      int32_t n_lists, int32_t c, int32_t b, int32_t cap, int64_t *out_keys, double *out_scores,
+                                      int32_t *out_count) {
+    MIR_REQUIRE(b >= 0 && cap >= 0 && n_lists >= 0, "bad shape");
+    MIR_REQUIRE(b == 0 || (key_base && list_ptr && out_count), "NULL buffer");
+    for (int32_t q = 0; q < b; ++q) {
+        const int32_t *lp = list_ptr + (size_t)q * (n_lists + 1);
+        MIR_REQUIRE(lp[n_lists] <= cap, "query %d has %d items, cap is %d", q, lp[n_lists], cap);
+        int32_t rc = mir_rrf_fuse(keys ? keys + 2 * key_base[q] : nullptr, lp, weights, n_lists, c,
+                                  out_keys ? out_keys + (size_t)q * cap * 2 : nullptr,
+                                  out_scores ? out_scores + (size_t)q * cap : nullptr, out_count + q);
+        if (rc != MIR_OK) return rc;
+    }
+    return MIR_OK;
+}

@@ -51,6 +51,22 @@ class DeviceBM25:
         return {"n_docs": n.value, "vocab": v.value, "n_postings": p.value, "avgdl": a.value, "average_idf": ai.value,
                 "hbm_bytes": hb.value}
 
+    def corpus_stats(self):
+        """-> (df int64[vocab], first_pos int64[vocab] (INT64_MAX = absent), total_tokens, n_docs) of THIS model's
+        documents: what a document-sharded corpus all-reduces (retrievers/sharded_bm25.py)."""
+        df = np.zeros(self.vocab, np.int64)
+        first = np.zeros(self.vocab, np.int64)
+        tot, n = C.c_int64(0), C.c_int64(0)
+        nat.check(nat.lib.mir_bm25_corpus_stats(self._h, nat.ptr(df), nat.ptr(first), C.byref(tot), C.byref(n)))
+        return df, first, int(tot.value), int(n.value)
+
+    def set_global_stats(self, idf: np.ndarray, avgdl: float, average_idf: float = 0.0) -> None:
+        """Install global idf[vocab] / avgdl (posting weights are re-derived on the device)."""
+        idf = np.ascontiguousarray(idf, dtype=np.float64)
+        if len(idf) != self.vocab:
+            raise ValueError("idf must have `vocab` entries")
+        nat.check(nat.lib.mir_bm25_set_global_stats(self._h, nat.ptr(idf), float(avgdl), float(average_idf)))
+
     def tune(self, queries_per_workgroup: int = 0) -> None:
         """Pin the fast pass's pipeline depth (1..64 queries per workgroup; 0 = per call).  Results do not depend on it."""
         nat.check(nat.lib.mir_bm25_tune(self._h, queries_per_workgroup))

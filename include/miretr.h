@@ -209,6 +209,22 @@ int32_t mir_stem_english(const char *tokens, int64_t n_bytes, char sep, char *ou
 int32_t mir_compact_term_ids(const int32_t *ids, int64_t n, int32_t vocab, int32_t *out_ids, int32_t *remap,
                              int32_t *n_used);
 
+/* Document-sharded corpus (one model per GPU over a contiguous range of documents; idf, its average and the
+ * average document length are GLOBAL statistics).  Either pass them to mir_bm25_create as overrides, or
+ * build the shard first and install them afterwards:
+ *   mir_bm25_corpus_stats      this model's per-term document frequency df[vocab], position of each term's first token
+ *                              in this model's token stream (INT64_MAX = absent), token and document counts - the
+ *                              quantities to all-reduce (SUM, MIN of shard-offset positions, SUM, SUM);
+ *   mir_bm25_idf_from_stats    host: BM25Okapi._calc_idf (rank-bm25 0.2.2, behind bm25_retriever.py:78) from such
+ *                              statistics - the routine mir_bm25_create itself uses, so a sharded model's idf is
+ *                              bit-identical to the unsharded one's;
+ *   mir_bm25_set_global_stats  re-derives the posting weights for `avgdl` on the device and installs idf[vocab]. */
+int32_t mir_bm25_corpus_stats(const mir_bm25 *h, int64_t *out_df, int64_t *out_first_pos, int64_t *out_total_tokens,
+                              int64_t *out_n_docs);
+int32_t mir_bm25_idf_from_stats(const int64_t *df, const int64_t *first_pos, int32_t vocab, int64_t n_docs, double epsilon,
+                                double *out_idf, double *out_average_idf);
+int32_t mir_bm25_set_global_stats(mir_bm25 *h, const double *idf_host, double avgdl, double average_idf);
+
 int32_t mir_bm25_destroy(mir_bm25 *h);
 /* Tuning / test hook: how many queries one workgroup of the fast scoring pass walks through its document tile
  * (the depth of its software pipeline), 1..64; 0 = chosen per call from the batch size (the default).  Results do
@@ -245,6 +261,11 @@ int32_t mir_bm25_search_device(mir_bm25 *h, const int32_t *q_terms_device, const
  * ---------------------------------------------------------------------- */
 int32_t mir_rrf_fuse(const int64_t *keys, const int32_t *list_ptr, const double *weights, int32_t n_lists,
                      int32_t c, int64_t *out_keys, double *out_scores, int32_t *out_count);
+/* The same for b queries in one call: query q's lists are list_ptr[q * (n_lists + 1) ..], offsets relative to
+ * key_base[q] (in keys, i.e. pairs); outputs [b][cap][2], [b][cap], [b]; cap >= the items of any one query. */
+int32_t mir_rrf_fuse_batch(const int64_t *keys, const int64_t *key_base, const int32_t *list_ptr, const double *weights,
+                           int32_t n_lists, int32_t c, int32_t b, int32_t cap, int64_t *out_keys, double *out_scores,
+                           int32_t *out_count);
 
 /* ------------------------------------------------------------------------
  * Text encoder: replaces the sentence-transformers forward behind

@@ -271,6 +271,52 @@ def test_sharded_stats_override(br):
     np.testing.assert_array_equal(od, fs)
 
 
+def test_sharded_build_then_global_stats(br):
+    """The sharded build of config C4 (retrievers/sharded_bm25.py) on one GPU: three document shards built with
+    placeholder statistics (one of them EMPTY of tokens), their corpus statistics combined as the all-reduce would,
+    the library's idf routine, global statistics installed on the device (posting weights re-derived for the global
+    avgdl) -> scores and idf bit-identical to the unsharded model; ShardedBM25 (world 1) over device buffers agrees."""
+    import torch
+
+    from aidial_rag_amd.retrievers import sharded_bm25 as sbm
+
+    indptr, toks = synth(20000, 3000, 9)
+    indptr = np.concatenate([indptr, np.full(50, indptr[-1])])  # 50 empty documents at the end: the third shard
+    n = len(indptr) - 1
+    full = br.DeviceBM25.from_token_ids(indptr, toks, 3000)
+    cuts = [0, 9000, 20000, n]
+    shards, stats = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        sh = br.DeviceBM25.from_token_ids(indptr[lo : hi + 1] - indptr[lo], toks[indptr[lo] : indptr[hi]], 3000,
+                                          idf=np.zeros(3000), avgdl=1.0, doc_offset=lo)
+        shards.append(sh)
+        stats.append(sh.corpus_stats())
+    assert stats[2][2] == 0 and stats[2][3] == 50
+    imax = np.iinfo(np.int64).max
+    df = sum(s[0] for s in stats)
+    offs = np.cumsum([0] + [s[2] for s in stats])
+    first = np.min([np.where(s[1] == imax, imax, s[1] + o) for s, o in zip(stats, offs)], axis=0)
+    total, n_docs = sum(s[2] for s in stats), sum(s[3] for s in stats)
+    idf, avg_idf = sbm.idf_from_stats(df, first, n_docs)
+    np.testing.assert_array_equal(idf, full.idf())
+    assert avg_idf == full.info()["average_idf"] and total / n_docs == full.info()["avgdl"]
+    for sh in shards:
+        sh.set_global_stats(idf, total / n_docs, avg_idf)
+        assert sh.info()["avgdl"] == full.info()["avgdl"]
+    qs = queries(3000, 12, 10)
+    for q in qs:
+        np.testing.assert_array_equal(np.concatenate([sh.get_scores(q) for sh in shards]), full.get_scores(q))
+    # ShardedBM25 with a single rank over the unsharded model: device-buffer search + device merge
+    s1 = sbm.ShardedBM25(local_model=full)
+    flat = torch.tensor(np.concatenate([np.asarray(q, np.int32) for q in qs]), dtype=torch.int32, device="cuda")
+    ptr = torch.tensor(np.concatenate(([0], np.cumsum([len(q) for q in qs]))), dtype=torch.int32, device="cuda")
+    sc, idx, cnt = s1.search(flat, 10, ptr)
+    torch.cuda.synchronize()
+    fi, fs, fc = full.search(qs, 10)
+    np.testing.assert_array_equal(idx.cpu().numpy(), fi)
+    np.testing.assert_array_equal(sc.cpu().numpy(), fs)
+
+
 def test_full_size_1m_documents_50k_vocabulary(br):
     """BASELINE config C3 at full size (1M chunks, 50k-term vocabulary, SURVEY 8(d) corpus and query mix):
     float64 scores and top-10 bit-identical to the CSR restatement for a 64-query batch."""
