@@ -52,6 +52,13 @@ def parse():
                     help="rows PER GPU of the float16 d=1024 leg (BASELINE config 5: 50M over 8 GPUs); 0 = skip")
     ap.add_argument("--encode-chunks", type=int, default=8192,
                     help="chunks per GPU for the index-build (encoder) leg of the metric; 0 = skip")
+    ap.add_argument("--bm25-docs", type=int, default=1_000_000,
+                    help="documents of the BM25 leg (BASELINE config 3: 1M chunks, 50k-term vocabulary), single GPU only; 0 = skip")
+    ap.add_argument("--hybrid-docs", type=int, default=1_250_000,
+                    help="chunks PER GPU of the hybrid leg (BASELINE config 4: 10M chunks over 8 GPUs = 1.25M each: vector "
+                         "rows + BM25 documents + fusion); 0 = skip")
+    ap.add_argument("--no-cpu-legs", dest="cpu_legs", action="store_false",
+                    help="skip the BM25 and encoder CPU baselines (the vector one is governed by --cpu-rows)")
     return ap.parse_args()
 
 
@@ -188,8 +195,262 @@ def c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex,
                      "avg_launch_ms": round(avg_ms, 4), "achieved": round(bytes_pass / (avg_ms * 1e-3) / 1e9, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_pass / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "launches": launches},
-        "uncertain_queries": flags,
+        "exact_pass_queries": flags // 2,
     }
+
+
+BM25_VOCAB = 50_000
+
+
+def gen_bm25_corpus(np, torch, device, n_docs, seed):
+    """SURVEY.md 8(d) BM25 corpus at token-id level: doc length clip(round(N(150, 40)), 1, 400), 0.1 % empty documents,
+    term ids Zipf(s = 1.07) truncated to the 50k vocabulary (ids past it fold onto the last one, as
+    `minimum(zipf - 1, vocab - 1)` does).  Sampled on the GPU by inverse CDF (numpy's rejection sampler needs ~10 s per
+    150M tokens on the host); returned as host arrays, which is what mir_bm25_create takes."""
+    from scipy.special import zeta
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lens = torch.clamp(torch.round(torch.normal(150.0, 40.0, (n_docs,), generator=g, device=device)), 1, 400).to(torch.int64)
+    lens[torch.rand(n_docs, generator=g, device=device) < 0.001] = 0
+    indptr = torch.zeros(n_docs + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(lens, 0)
+    total = int(indptr[-1].item())
+    k = torch.arange(1, BM25_VOCAB, dtype=torch.float64, device=device)
+    cdf = torch.cumsum(k.pow(-1.07), 0) / float(zeta(1.07, 1))  # P(X <= k), k = 1 .. vocab-1; the rest is the last id
+    toks = torch.empty(total, dtype=torch.int32, device=device)
+    for a in range(0, total, 1 << 26):
+        u = torch.rand(min(1 << 26, total - a), generator=g, device=device, dtype=torch.float64)
+        toks[a : a + len(u)] = torch.searchsorted(cdf, u).to(torch.int32)  # 0-based id = rank - 1; u > cdf[-1] -> vocab-1
+    return indptr.cpu().numpy(), toks.cpu().numpy()
+
+
+def bm25_queries(np, nq, seed):
+    """SURVEY.md 8(d) query mix: 2-8 terms, half from the mid-frequency band, 5 % with an out-of-vocabulary id, 5 %
+    with a repeated term."""
+    qr = np.random.default_rng(seed)
+    out = []
+    for i in range(nq):
+        L = int(qr.integers(2, 9))
+        q = [int(t) for t in (qr.integers(50, 5000, L) if i % 2 else qr.integers(0, BM25_VOCAB, L))]
+        if i % 20 == 3:
+            q[0] = BM25_VOCAB + 7
+        if i % 20 == 5:
+            q.append(q[0])
+        out.append(q)
+    return out
+
+
+def bm25_leg(np, torch, args, local_rank):
+    """BASELINE config 3: BM25 scoring + top-k over 1M chunks / 50k-term vocabulary on one GPU, queries and results
+    resident in HBM (mir_bm25_search_device on the current stream)."""
+    from aidial_rag_amd.retrievers.bm25_retriever import DeviceBM25
+
+    device = torch.device("cuda", local_rank)
+    t0 = time.perf_counter()
+    indptr, toks = gen_bm25_corpus(np, torch, device, args.bm25_docs, 777)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dev = DeviceBM25.from_token_ids(indptr, toks, BM25_VOCAB, device=local_rank)
+    t_build = time.perf_counter() - t0
+    info = dev.info()
+    df, _, _, _ = dev.corpus_stats()
+    stream = torch.cuda.current_stream().cuda_stream
+    k = args.k
+    runs = []
+    for B in (1, 64, 4096):
+        qs = bm25_queries(np, B, 778 + B)
+        flat = torch.tensor(np.concatenate([np.asarray(q, np.int32) for q in qs]), dtype=torch.int32, device=device)
+        ptr = torch.tensor(np.concatenate(([0], np.cumsum([len(q) for q in qs]))), dtype=torch.int32, device=device)
+        o_idx = torch.zeros((B, k), dtype=torch.int64, device=device)
+        o_sc = torch.zeros((B, k), dtype=torch.float64, device=device)
+        o_cnt = torch.zeros(B, dtype=torch.int32, device=device)
+        ws = torch.zeros((dev.workspace_bytes(B, k) + 7) // 8, dtype=torch.int64, device=device)
+        call = lambda: dev.search_device(flat.data_ptr(), ptr.data_ptr(), B, k, o_idx.data_ptr(), o_sc.data_ptr(),  # noqa: E731
+                                         o_cnt.data_ptr(), ws.data_ptr(), stream)
+        reps = max(3, 2048 // B)
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        touched = float(np.mean([sum(int(df[t]) for t in q if 0 <= t < BM25_VOCAB) for q in qs]))
+        runs.append({"queries_per_step": B, "qps": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+                     "postings_per_query": round(touched, 1), "algorithmic_bytes_per_query": round(12 * touched, 1),
+                     "postings_GBps": round(12 * touched * B / dt / 1e9, 2),
+                     "frac_of_hbm_peak": round(12 * touched * B / dt / 1e9 / HBM_PEAK_GBS, 5)})
+    res = {
+        "workload": f"BM25Okapi top-{k} over {args.bm25_docs} synthetic chunks, {BM25_VOCAB}-term vocabulary (Zipf 1.07), "
+                    "SURVEY 8(d) query mix, float64 scores",
+        "postings": info["n_postings"], "index_hbm_bytes": info["hbm_bytes"],
+        "build_s": {"generate_on_gpu": round(t_gen, 2), "device_build_incl_upload": round(t_build, 2)},
+        "runs": runs,
+        # what bounds it: per (tile, query) a workgroup adds ~postings/ntiles float64 values into LDS one term after the
+        # other (a barrier per term) and ranks the touched documents; HBM is far from busy (frac_of_hbm_peak above)
+        "bound": "lds+latency (per-term LDS accumulation and block top-k, not HBM)",
+        "bound_evidence": "profiles/r02_bm25_pmc.md",
+    }
+    return res, dev, (indptr, toks)
+
+
+def bm25_cpu_baseline(np, corpus, dev_full, args, local_rank):
+    """The reference's own BM25 path - rank-bm25's dict loops (restated in oracle/bm25.py: BM25Okapi.__init__ and
+    get_scores, then the reversed stable argsort) - on ONE host core over the first documents of the same corpus,
+    and the GPU's bit-identity on that sample."""
+    from aidial_rag_amd.retrievers.bm25_retriever import DeviceBM25
+    from oracle import bm25 as ob
+
+    indptr, toks = corpus
+    n = min(20_000, len(indptr) - 1)
+    ip, tk = indptr[: n + 1], toks[: indptr[n]]
+    docs = [tk[ip[i] : ip[i + 1]].tolist() for i in range(n)]
+    t0 = time.perf_counter()
+    o = ob.BM25Okapi(docs)
+    t_build = time.perf_counter() - t0
+    qs = bm25_queries(np, 48, 991)
+    t0 = time.perf_counter()
+    want = [o.get_scores(q) for q in qs]
+    tops = [ob.top_n_indexes(w, args.k) for w in want]
+    dt = time.perf_counter() - t0
+    dev = DeviceBM25.from_token_ids(ip, tk, BM25_VOCAB, device=local_rank)
+    idx, sc, cnt = dev.search(qs, args.k)
+    same = all(np.array_equal(idx[i], tops[i]) and np.array_equal(sc[i], want[i][tops[i]]) for i in range(len(qs)))
+    dev.close()
+    qps = len(qs) / dt
+    return {"value": round(qps, 3), "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"{len(qs)} queries over the first {n} of {len(indptr) - 1} documents, rank-bm25 0.2.2 dict loops restated "
+                      f"(model build {t_build:.2f} s per REQUEST in the reference); cost is linear in documents: "
+                      f"~{qps * n / (len(indptr) - 1):.3f} queries/s at full size",
+            "gpu_scores_and_topk_bit_identical_on_sample": bool(same)}
+
+
+def encoder_cpu_baseline(np, torch):
+    """The reference's CPU encoder path (sentence-transformers -> transformers BertModel, embeddings.py:52-66; its
+    production backend is OpenVINO, absent here) as float32 torch eager on all host cores: one outer batch of 128
+    chunks (embeddings.py:24-26), padded, CLS + L2 normalise."""
+    from oracle import encoder as oe
+
+    model = oe.make_model(layers=12, seed=0)
+    rng = np.random.default_rng(99)
+    lens = np.clip(np.round(rng.normal(220, 60, 128)), 8, 512).astype(np.int64)
+    L = int(lens.max())
+    ids = torch.zeros((128, L), dtype=torch.long)
+    mask = torch.zeros((128, L), dtype=torch.long)
+    for i, n in enumerate(lens):
+        ids[i, :n] = torch.from_numpy(rng.integers(999, 30522, n))
+        mask[i, :n] = 1
+    with torch.no_grad():
+        model(input_ids=ids[:8], attention_mask=mask[:8])  # warm-up
+        t0 = time.perf_counter()
+        out = model(input_ids=ids, attention_mask=mask).last_hidden_state[:, 0]
+        out = out / out.norm(dim=1, keepdim=True)
+        dt = time.perf_counter() - t0
+    return {"value": round(128 / dt, 2), "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"one outer batch of 128 synthetic chunks (mean {lens.mean():.0f} tokens, padded to {L}), transformers "
+                      "BertModel float32, torch eager (the reference's OpenVINO backend is not installed)"}
+
+
+def build_embeddings_leg(np, torch, args, local_rank, tmpdir):
+    """The index-build rate THROUGH THE PRODUCT SURFACE: texts -> `build_embeddings` (embeddings.py:102-108: outer batches
+    of 128, WordPiece tokenisation on the host, shared encoder passes) -> List[np.ndarray].  Synthetic WordPiece
+    vocabulary (no real one exists offline), random-init weights."""
+    import asyncio
+    import json as js
+
+    from transformers import AutoTokenizer
+
+    from aidial_rag_amd.embeddings import embeddings as emb
+
+    os.makedirs(tmpdir, exist_ok=True)
+    rng = np.random.default_rng(7)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    words = ["".join(rng.choice(list(letters), rng.integers(2, 9))) for _ in range(20000)]
+    vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list(letters) + \
+            ["##" + c for c in letters] + sorted(set(words))
+    open(os.path.join(tmpdir, "vocab.txt"), "w").write("\n".join(vocab) + "\n")
+    js.dump({"tokenizer_class": "BertTokenizer", "do_lower_case": True, "model_max_length": 512},
+            open(os.path.join(tmpdir, "tokenizer_config.json"), "w"))
+    tok = AutoTokenizer.from_pretrained(tmpdir)
+    enc = emb.BgeEncoder.from_state_dict(random_bge_small_state_dict(np), tokenizer=tok, device=local_rank)
+    emb.set_bge_embedding_impl(enc)
+    try:
+        n = args.encode_chunks
+        lens = np.clip(np.round(rng.normal(218, 60, n)), 6, 510).astype(np.int64)  # words ~ tokens with this vocabulary
+        texts = [" ".join(rng.choice(words, L)) for L in lens]
+        asyncio.run(emb.build_embeddings(texts[:256]))  # warm-up
+        p0 = enc._doc_commit().passes
+        t0 = time.perf_counter()
+        out = asyncio.run(emb.build_embeddings(texts))
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        ids = tok(texts[:1024], add_special_tokens=True, truncation=True, max_length=512)["input_ids"]
+        t_tok = (time.perf_counter() - t1) / 1024
+        return {"chunks_per_s": round(n / dt, 1), "chunks": n, "outer_batch": emb.EMBEDDINGS_BATCH_SIZE,
+                "shared_encoder_passes": enc._doc_commit().passes - p0,
+                "mean_tokens_per_chunk": round(float(np.mean([len(x) for x in ids])), 1),
+                "host_tokenise_us_per_chunk_1thread": round(t_tok * 1e6, 1),
+                "note": "texts in, List[np.ndarray] out; includes WordPiece tokenisation (transformers BertTokenizer) and result hand-over",
+                "ok": bool(len(out) == n)}
+    finally:
+        emb.set_bge_embedding_impl(None)
+        enc.close()
+
+
+def hybrid_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher):
+    """BASELINE config 4: hybrid semantic + BM25 + fusion, chunks sharded by row / document across the GPUs (weak
+    scaling: --hybrid-docs chunks per GPU; 8 GPUs x 1.25M = the 10M chunks of C4).  A step = B queries through the
+    vector leg (scan + exact re-score + all-gather + merge), the BM25 leg (per-shard scoring + top-k, all-gather,
+    merge with the reversed tie-break) and the host fusion of the two k = 7 lists (retrieval_chain.py:203-245)."""
+    from aidial_rag_amd.retrievers.sharded_bm25 import ShardedBM25, ShardedHybrid
+
+    device = torch.device("cuda", local_rank)
+    n_loc, d, B, k = args.hybrid_docs, args.dim, args.batch, 7
+    lo = rank * n_loc
+    g = torch.Generator(device=device)
+    g.manual_seed(555 + rank)
+    rows = torch.randn((n_loc, d), generator=g, dtype=torch.float32, device=device)
+    rows /= rows.norm(dim=1, keepdim=True)
+    index = DeviceIndex.from_device_ptr(rows.data_ptr(), n_loc, d, local_rank, row_offset=lo,
+                                        stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    del rows
+    indptr, toks = gen_bm25_corpus(np, torch, device, n_loc, 9000 + rank)
+    t0 = time.perf_counter()
+    kw = ShardedBM25.build(indptr, toks, BM25_VOCAB, doc_offset=lo, device_index=local_rank)
+    t_build = time.perf_counter() - t0
+    del indptr, toks
+    hy = ShardedHybrid(ShardedSearcher(local_index=index), kw, k=k)
+    g.manual_seed(4321)
+    q = torch.randn((B, d), generator=g, dtype=torch.float32, device=device)
+    q = (q / q.norm(dim=1, keepdim=True)).double().contiguous()
+    qs = bm25_queries(np, B, 778)
+    flat = torch.tensor(np.concatenate([np.asarray(x, np.int32) for x in qs]), dtype=torch.int32, device=device)
+    ptr = torch.tensor(np.concatenate(([0], np.cumsum([len(x) for x in qs]))), dtype=torch.int32, device=device)
+    for _ in range(PRECONDITION_STEPS):
+        out = hy.search(q, args.metric, flat, ptr)
+    barrier()
+    steps = 20
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = hy.search(q, args.metric, flat, ptr)
+    barrier()
+    el = time.perf_counter() - t0
+    tm = torch.tensor([el], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    el = float(tm.item())
+    fused_ids, _, fused_cnt, v, t = out
+    index.close()
+    kw.model.close()
+    return {"workload": f"hybrid: {n_loc} chunks per GPU x {world} GPUs = {n_loc * world} chunks; {d}-d float32 rows ({args.metric}) + "
+                        f"BM25 ({BM25_VOCAB}-term vocabulary); k = {k} per leg, reciprocal-rank fusion (weights 1, c = 60)",
+            "scaling": "weak", "queries_per_step": B, "ms_per_step": round(1e3 * el / steps, 4), "qps": round(B * steps / el, 1),
+            "bm25_sharded_build_s": round(t_build, 2),
+            "fused_results_per_query_mean": round(float(fused_cnt.mean()), 2),
+            "legs_overlap_in_results_mean": round(float(np.mean([len(set(v[0][i, : v[1][i]]) & set(t[0][i, : t[1][i]])) for i in range(B)])), 3)}
 
 
 def main():
@@ -292,15 +553,20 @@ def main():
     aux = 0 if args.metric == "inner_product" else 4 * n_loc
     wide = d in (128, 256, 384) and k <= 12
     qpl = 128 if wide else 32
-    bytes_launch = n_loc * d * 4 + aux + qpl * d * 4 + qpl * k * 12
+    q_launch = min(B, qpl)  # queries actually riding one launch
+    bytes_launch = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
     avg_ms = scan_ms / max(launches, 1)
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic per launch comes from PMC counters, which cannot be collected inside this run (rocprofv3 --pmc
+    # serialises kernels and needs its own passes): it is READ from the tracked summary of the last counter run on
+    # the same shape and labelled as such (`traffic_source`); null when no summary matches.
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("rows_per_launch") == n_loc and tj.get("dim") == d:
             traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run): " + str(tj.get("command", ""))
 
     result = {
         "metric": "retrieval_qps_10Mx384",
@@ -330,11 +596,15 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "bytes_per_launch": bytes_launch,
             "avg_launch_ms": round(avg_ms, 4),
             "launches": launches,
+            # the same bytes over the whole step (prep, threshold pre-pass, scan, finalize, exact-pass gate, merge)
+            "step_frac": round(bytes_launch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         },
-        "uncertain_queries": int(flags_total.item()),
+        "uncertain_queries": 0,  # never returned since the exact pass exists (flag bit 1)
+        "exact_pass_queries": int(flags_total.item()) // 2,  # queries the filter could not prove (flag bit 2), recomputed exactly
         "preconditioning_steps": precondition,
         "index_build_s": {"generate": round(t_gen, 2), "upload_pack_norms": round(t_build, 2)},
     }
@@ -371,8 +641,26 @@ def main():
         result["c5_float16_d1024"] = c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher)
     if args.encode_chunks > 0:
         result["index_build"] = encoder_leg(np, torch, dist, args, world, rank, local_rank, barrier)
+        if rank == 0:
+            import tempfile
+
+            with tempfile.TemporaryDirectory() as td:
+                result["index_build"]["through_build_embeddings"] = build_embeddings_leg(np, torch, args, local_rank, td)
+    if args.hybrid_docs > 0:
+        result["hybrid_c4"] = hybrid_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher)
+    bm25_state = None
+    if args.bm25_docs > 0 and world == 1:
+        result["bm25_c3"], bm25_dev, bm25_corpus = bm25_leg(np, torch, args, local_rank)
+        bm25_state = (bm25_dev, bm25_corpus)
     if rank == 0 and world == 1 and sample is not None and len(sample):
         result["cpu_baseline"] = cpu_baseline(np, sample, queries[: args.cpu_queries].cpu().numpy(), args, DeviceIndex)
+        if args.cpu_legs:
+            # the other two legs of the reference's CPU path (north_star: "CPU embeddings+BM25 path timed in the same run")
+            if bm25_state is not None:
+                result["cpu_baseline"]["bm25"] = bm25_cpu_baseline(np, bm25_state[1], bm25_state[0], args, local_rank)
+            result["cpu_baseline"]["encoder"] = encoder_cpu_baseline(np, torch)
+    if bm25_state is not None:
+        bm25_state[0].close()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
