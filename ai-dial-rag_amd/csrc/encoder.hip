@@ -202,11 +202,7 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
     MIR_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[0], hipEventDisableTiming));
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[1], hipEventDisableTiming));
-    {
-        auto kern = ffn_ln_kernel;
-        MIR_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    FFN_LDS_BYTES));
-    }
+    if (ffn_prepare() != MIR_OK) return fail(MIR_ERR_HIP);
 #undef MIR_TRY
     *out = e;
     return MIR_OK;
@@ -341,7 +337,10 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
             }
             oproj_ln_kernel<<<g4, blk, 0, s>>>(a1, nt, l.wo, l.attn_params, l.attn_params + H, l.attn_params + 2 * H,
                                                a0, a1);  // in place: each wave reads its tile's context before writing it
-            ffn_ln_kernel<<<g4, blk, FFN_LDS_BYTES, s>>>(a1, nt, l.wffn, l.ffn_params, a0);
+            {
+                const int32_t frc = launch_ffn(a1, nt, l.wffn, l.ffn_params, a0, s);
+                if (frc != MIR_OK) return frc;
+            }
         }
         MIR_HIP(hipGetLastError());
         float *d_out = out_on_device ? out + (size_t)s0 * H : reinterpret_cast<float *>(w + o_out);

@@ -47,6 +47,11 @@ constexpr int NFB = H / 32;   // 12 feature blocks
 constexpr int KS_H = H / 16;  // 24 k-steps over the hidden dim
 constexpr int NHT = FF / 32;  // 48 intermediate tiles
 constexpr float LN_EPS = 1e-12f;
+// packed FFN weights: a flat sequence of 24-KiB halves  W1(0) W2(0) W1(1) W2(1) ...  (W1(ht): the 24 k-step fragments
+// of intermediate tile ht; W2(ht): the 24 fragments (output tile nt, s2) for k-steps 2*ht + s2); parameters b1 | b2 | gamma | beta
+constexpr int FFN_HALF_BYTES = 24 * 1024;
+constexpr int FFN_STAGE_BYTES = 2 * FFN_HALF_BYTES;
+constexpr int FFN_PARAM_FLOATS = FF + 3 * H;
 
 // feature (row) index inside a 32-row accumulator tile for register r of lane-half h
 __device__ __forceinline__ int fi(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

@@ -1,0 +1,161 @@
+// The FFN kernel of encoder_ffn.hip, as a header so that diagnostic builds (tools/ffn_stamps.hip) can instantiate it
+// with in-kernel time stamps; the library instantiates ffn_ln_kernel<false>.
+#pragma once
+#include "encoder_common.h"
+
+namespace mir {
+namespace enc {
+
+// LDS fragment prefetch: a wave keeps FFN_RING - 1 ds_read_b128 in flight ahead of the MFMA that consumes them (measured
+// with 4, 6, 8 and 12: no difference - fragment latency is not what bounds this kernel, see encoder_ffn.hip)
+#ifndef FFN_RING
+#define FFN_RING 4
+#endif
+// LDS-DMA of one 1-KiB piece (16 B per lane), as inline asm so that hipcc's own waits do not cover it (see vec_kernels.h)
+__device__ __forceinline__ void ffn_glds16(const void *gsrc, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ uint32_t ffn_lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+constexpr int FFN_HBUF_BYTES = 2 * 4 * 2 * 64 * 16;  // h hand-off: [2 slots][4 tiles][2 fragments][64 lanes] x 16 B
+constexpr int FFN_LDS_BYTES = 2 * FFN_STAGE_BYTES + FFN_HBUF_BYTES + FFN_PARAM_FLOATS * 4;
+
+// STAMPS (diagnostic builds only, tools/ffn_stamps.hip): workgroup 0 records s_memtime at the top of every stage (after
+// the barrier) and at the end of its stage work, per wave: stamps[wave][stage][2].
+template <bool STAMPS>
+__global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict__ act_in, int n_tiles,
+                                                        const unsigned char *__restrict__ wffn,
+                                                        const float *__restrict__ params, uint4 *__restrict__ act_out,
+                                                        unsigned long long *__restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *hb = reinterpret_cast<uint4 *>(smem + 2 * FFN_STAGE_BYTES);
+    float *prm = reinterpret_cast<float *>(smem + 2 * FFN_STAGE_BYTES + FFN_HBUF_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool role_b = wave >= 4;
+    const int tl = wave & 3;  // token tile of the workgroup
+    const int tt_raw = blockIdx.x * 4 + tl;
+    const bool live = tt_raw < n_tiles;
+    const int tt = live ? tt_raw : n_tiles - 1;  // idle waves shadow a real tile: they must join barriers and the staging
+
+    for (int i = tid; i < FFN_PARAM_FLOATS; i += 512) prm[i] = params[i];
+
+    if (!role_b) {
+        // ------------------------------------------------------------------ role A
+        const uint4 *xin = act_in + (size_t)tt * (NFB * 2 * 64) + lane;
+        uint4 x[KS_H];
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) x[ks] = xin[ks * 64];
+        // prologue staging through registers: W1(0) -> slot 1 and W1(1) -> slot 0, pieces 6 tl .. 6 tl + 5 per wave (from stage 1
+        // on the B waves move the weights by LDS-DMA)
+        {
+            const size_t piece0 = (size_t)(tl * 6) * 64 + lane;
+            const uint4 *s0 = reinterpret_cast<const uint4 *>(wffn) + piece0;                       // W1(0) = flat half 0
+            const uint4 *s1 = reinterpret_cast<const uint4 *>(wffn + 2 * FFN_HALF_BYTES) + piece0;  // W1(1) = flat half 2
+            uint4 *d1 = reinterpret_cast<uint4 *>(smem + FFN_STAGE_BYTES) + piece0, *d0 = reinterpret_cast<uint4 *>(smem) + piece0;
+            uint4 t0[6], t1[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { t0[i] = s0[i * 64]; t1[i] = s1[i * 64]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { d1[i * 64] = t0[i]; d0[i * 64] = t1[i]; }
+        }
+        __syncthreads();  // params, W1(0), W1(1) are in LDS
+
+        // first product of tile 0, from stage -1 (slot 1, first half)
+        f32x16 hacc = {0};
+        {
+            const uint4 *st = reinterpret_cast<const uint4 *>(smem + FFN_STAGE_BYTES) + lane;
+            uint4 fr[FFN_RING];
+#pragma unroll
+            for (int i = 0; i < FFN_RING - 1; ++i) fr[i] = st[i * 64];
+#pragma unroll
+            for (int ks = 0; ks < KS_H; ++ks) {
+                if (ks + FFN_RING - 1 < KS_H) fr[(ks + FFN_RING - 1) % FFN_RING] = st[(ks + FFN_RING - 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                hacc = mfma(fr[ks % FFN_RING], x[ks], hacc);
+            }
+        }
+        for (int s = 0; s <= NHT; ++s) {
+            __syncthreads();  // stage s is complete in slot s & 1; everyone is done with slot (s + 1) & 1; h(s - 1) is visible
+            if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2] = __builtin_amdgcn_s_memtime();
+            if (s < NHT) {
+                const uint4 *st = reinterpret_cast<const uint4 *>(smem + (size_t)(s & 1) * FFN_STAGE_BYTES) + lane;  // W1(s+1)
+                const float *b1 = prm + 32 * s;
+                float g[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[r] = hacc[r] + b1[fi(r, h)];
+                f32x16 hn = {0};
+                if (s + 1 < NHT) {
+                    uint4 fr[FFN_RING];
+#pragma unroll
+                    for (int i = 0; i < FFN_RING - 1; ++i) fr[i] = st[i * 64];
+#pragma unroll
+                    for (int ks = 0; ks < KS_H; ++ks) {
+                        if (ks + FFN_RING - 1 < KS_H) fr[(ks + FFN_RING - 1) % FFN_RING] = st[(ks + FFN_RING - 1) * 64];
+                        hn = mfma(fr[ks % FFN_RING], x[ks], hn);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[r] = gelu(g[r]);
+                uint4 *ho = hb + ((size_t)((s & 1) * 4 + tl) * 2) * 64 + lane;
+                ho[0] = make_uint4(pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7]));
+                ho[64] = make_uint4(pack2(g[8], g[9]), pack2(g[10], g[11]), pack2(g[12], g[13]), pack2(g[14], g[15]));
+                hacc = hn;
+            }
+            if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2 + 1] = __builtin_amdgcn_s_memtime();
+        }
+    } else {
+        // ------------------------------------------------------------------ role B
+        f32x16 y[NFB];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) y[fb] = f32x16{0};
+        __syncthreads();
+        for (int s = 0; s <= NHT; ++s) {
+            __syncthreads();
+            if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2] = __builtin_amdgcn_s_memtime();
+            if (s + 1 <= NHT) {  // stage s+1 = [ W1(s+2) | W2(s) ] -> slot (s+1)&1; this wave moves pieces 6 tl .. 6 tl + 5 of each half
+                const int j = s + 1;
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(ffn_lds_addr(smem) + (uint32_t)((j & 1) * FFN_STAGE_BYTES + (tl * 6) * 1024));
+                if (j + 1 < NHT) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (j + 1)) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) ffn_glds16(src + i * 64, dst + i * 1024);
+                }
+                {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (j - 1) + 1) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) ffn_glds16(src + i * 64, dst + FFN_HALF_BYTES + i * 1024);
+                }
+            }
+            if (s >= 1) {
+                const uint4 *st = reinterpret_cast<const uint4 *>(smem + (size_t)(s & 1) * FFN_STAGE_BYTES + FFN_HALF_BYTES) + lane;  // W2(s-1)
+                const uint4 *hi = hb + ((size_t)(((s - 1) & 1) * 4 + tl) * 2) * 64 + lane;
+                const uint4 h0 = hi[0], h1 = hi[64];
+                uint4 fr[FFN_RING];
+#pragma unroll
+                for (int i = 0; i < FFN_RING - 1; ++i) fr[i] = st[i * 64];
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    if (i + FFN_RING - 1 < 24) fr[(i + FFN_RING - 1) % FFN_RING] = st[(i + FFN_RING - 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                    y[i >> 1] = mfma(fr[i % FFN_RING], (i & 1) ? h1 : h0, y[i >> 1]);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s+1 have landed before the barrier publishes them
+            if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2 + 1] = __builtin_amdgcn_s_memtime();
+        }
+        residual_ln_store(y, act_in + (size_t)tt * (NFB * 2 * 64), prm + FF, prm + FF + H, prm + FF + 2 * H,
+                          act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
+    }
+}
+
+
+}  // namespace enc
+}  // namespace mir

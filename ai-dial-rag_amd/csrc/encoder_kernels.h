@@ -195,156 +195,11 @@ __global__ __launch_bounds__(256, 1) void oproj_ln_kernel(const uint4 *__restric
 }
 
 // ---------------------------------------------------------------- E4: FFN1 + GELU + FFN2 + residual + LN
-// Block = 4 waves = 128 tokens sharing the weight stream through LDS.  The packed weights are a
-// flat sequence of 24-KiB halves  W1(0) W2(0) W1(1) W2(1) ...  (W1(ht): the 24 k-step fragments of
-// intermediate tile ht; W2(ht): the 24 fragments (output tile nt, s2) for k-steps 2*ht + s2).
-// A STAGE is 48 KiB starting at an odd half:  stage s = [ W2(s) | W1(s+1) ], so that inside one
-// stage the GELU of tile s (VALU) interleaves with the MFMAs of tile s+1's first product, which do
-// not depend on it; a one-tile-per-stage layout serialises 24 MFMAs -> 16 GELUs -> 24 MFMAs.
-// h^T = gelu(W1^T x^T + b1) never leaves registers: its accumulator is the B fragment of the
-// second product.
-//
-// Weight delivery: measured in-kernel (s_memtime), LDS-DMA of L2-resident weights lands about
-// 11 B/clk per CU however many stages are in flight (48 KiB per ~4.5K cycles: a third of each stage
-// was spent waiting), while plain global loads stream the same weights at 36 B/clk per CU
-// (qkv_kernel).  So each wave loads its 12 pieces of stage s+2 into registers while stage s is
-// computed and writes them to LDS one stage later (two LDS slots, one barrier per stage).
-//
-// GELU: 16 values per lane per stage, ~250 VALU instructions in all, independent of the 24 W1
-// MFMAs they are written next to.  The sched_group_barrier pattern below ASKS hipcc for
-// {1 ds_read, 1 MFMA, 7 VALU}; the ISA it emits still clusters most of the GELU ahead of the MFMAs
-// (in-kernel stamps: first phase 2.1K cycles for 0.77K cycles of MFMA), so the two are largely
-// serialised.  Forcing the order with the stage as inline asm (one GELU slice per MFMA gap) was built and
-// measured: no faster (the dependent VALU chains stretch each gap), see DESIGN.md 4b.
-constexpr int FFN_HALF_BYTES = 24 * 1024;
-constexpr int FFN_STAGE_BYTES = 2 * FFN_HALF_BYTES;
-constexpr int FFN_PARAM_FLOATS = FF + 3 * H;  // b1 | b2 | gamma | beta
-constexpr int FFN_LDS_BYTES = 2 * FFN_STAGE_BYTES + FFN_PARAM_FLOATS * 4;
-
-__global__ __launch_bounds__(256, 1) void ffn_ln_kernel(const uint4 *__restrict__ act_in, int n_tiles,
-                                                        const unsigned char *__restrict__ wffn,
-                                                        const float *__restrict__ params,
-                                                        uint4 *__restrict__ act_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *prm = reinterpret_cast<float *>(smem + 2 * FFN_STAGE_BYTES);
-
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tt_raw = blockIdx.x * 4 + wave;
-    const bool live = tt_raw < n_tiles;
-    const int tt = live ? tt_raw : n_tiles - 1;  // idle waves shadow a real tile: they must join barriers and the staging
-
-    for (int i = tid; i < FFN_PARAM_FLOATS; i += 256) prm[i] = params[i];
-    const uint4 *xin = act_in + (size_t)tt * (NFB * 2 * 64) + lane;
-    uint4 x[KS_H];
-#pragma unroll
-    for (int ks = 0; ks < KS_H; ++ks) x[ks] = xin[ks * 64];
-
-    // stage s in [-1, NHT): half 0 = W2(s) (absent for s = -1), half 1 = W1(s+1) (absent for
-    // s = NHT-1).  This wave moves pieces 6w..6w+5 of each half, one half (6 registers of 16 B per
-    // lane) at a time: loaded half a stage before it is written to LDS.
-    // (six named registers and macros: with an array captured by lambdas hipcc kept it in scratch)
-    uint4 sg0, sg1, sg2, sg3, sg4, sg5;
-#define FFN_GLOAD(S, HALF)                                                                                              \
-    do {                                                                                                                \
-        const uint4 *src_ = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (S) + 1 + (HALF)) * FFN_HALF_BYTES) +   \
-                            lane + (wave * 6) * 64;                                                                     \
-        sg0 = src_[0 * 64]; sg1 = src_[1 * 64]; sg2 = src_[2 * 64];                                                     \
-        sg3 = src_[3 * 64]; sg4 = src_[4 * 64]; sg5 = src_[5 * 64];                                                     \
-    } while (0)
-#define FFN_SWRITE(S, HALF)                                                                                             \
-    do {                                                                                                                \
-        uint4 *dst_ = reinterpret_cast<uint4 *>(smem + (size_t)(((S) + 2) & 1) * FFN_STAGE_BYTES +                      \
-                                                (HALF) * FFN_HALF_BYTES) + lane + (wave * 6) * 64;                      \
-        dst_[0 * 64] = sg0; dst_[1 * 64] = sg1; dst_[2 * 64] = sg2;                                                     \
-        dst_[3 * 64] = sg3; dst_[4 * 64] = sg4; dst_[5 * 64] = sg5;                                                     \
-    } while (0)
-    FFN_GLOAD(-1, 1);
-    FFN_SWRITE(-1, 1);  // W1(0) -> slot 1
-    FFN_GLOAD(0, 0);
-    FFN_SWRITE(0, 0);   // W2(0) -> slot 0
-    FFN_GLOAD(0, 1);
-    f32x16 y[NFB];
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) y[fb] = f32x16{0};
-    __syncthreads();  // params and W1(0) are in LDS
-
-    // first product of tile 0, from stage -1 (slot 1, second half)
-    f32x16 hacc = {0};
-    {
-        const uint4 *st = reinterpret_cast<const uint4 *>(smem + FFN_STAGE_BYTES + FFN_HALF_BYTES) + lane;
-        uint4 fr[4];
-        fr[0] = st[0 * 64];
-        fr[1] = st[1 * 64];
-        fr[2] = st[2 * 64];
-#pragma unroll
-        for (int ks = 0; ks < KS_H; ++ks) {
-            if (ks + 3 < KS_H) fr[(ks + 3) & 3] = st[(ks + 3) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            hacc = mfma(fr[ks & 3], x[ks], hacc);
-        }
-    }
-    FFN_SWRITE(0, 1);   // W1(1) -> slot 0 (nobody reads slot 0 before the loop's first barrier)
-    FFN_GLOAD(1, 0);
-
-    for (int s = 0; s < NHT; ++s) {
-        __syncthreads();  // stage s is complete in slot s&1; everyone is done with slot (s+1)&1 (stage s-1)
-        if (s + 1 < NHT) FFN_SWRITE(s + 1, 0);  // loaded during the previous stage's second phase -> the slot just freed
-        if (s + 2 < NHT) FFN_GLOAD(s + 1, 1);   // lands during the first phase
-        const uint4 *st = reinterpret_cast<const uint4 *>(smem + (size_t)(s & 1) * FFN_STAGE_BYTES) + lane;
-        const float *b1 = prm + 32 * s;
-        float g[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g[r] = hacc[r] + b1[fi(r, h)];
-        f32x16 hn = {0};
-        // fragments are consumed in the order  W1(s+1)[0..23], W2(s)[0..23]  through a 4-slot register
-        // ring filled three ahead (left to hipcc every MFMA sits behind its own ds_read + wait)
-        uint4 fr[4];
-        if (s + 1 < NHT) {
-            fr[0] = st[(24 + 0) * 64];
-            fr[1] = st[(24 + 1) * 64];
-            fr[2] = st[(24 + 2) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int o = 0; o < 24; ++o) {
-                fr[(o + 3) & 3] = st[(o + 3 < 24 ? 24 + o + 3 : o + 3 - 24) * 64];
-                hn = mfma(fr[o & 3], x[o], hn);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[r] = gelu(g[r]);
-#pragma unroll
-            for (int o = 0; o < 24; ++o) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ds_read
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);  // VALU
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            fr[0] = st[0 * 64];
-            fr[1] = st[1 * 64];
-            fr[2] = st[2 * 64];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[r] = gelu(g[r]);
-        }
-        if (s + 2 < NHT) {
-            FFN_SWRITE(s + 1, 1);
-            FFN_GLOAD(s + 2, 0);  // lands during the second phase
-        }
-        const uint4 h0 = make_uint4(pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7]));
-        const uint4 h1 = make_uint4(pack2(g[8], g[9]), pack2(g[10], g[11]), pack2(g[12], g[13]), pack2(g[14], g[15]));
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            if (i + 3 < 24) fr[(24 + i + 3) & 3] = st[(i + 3) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            y[i >> 1] = mfma(fr[(24 + i) & 3], (i & 1) ? h1 : h0, y[i >> 1]);
-        }
-        hacc = hn;
-    }
-#undef FFN_GLOAD
-#undef FFN_SWRITE
-    residual_ln_store(y, act_in + (size_t)tt * (NFB * 2 * 64), prm + FF, prm + FF + H, prm + FF + 2 * H,
-                      act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
-}
+// ffn_ln_kernel lives in encoder_ffn.hip (a translation unit of its own, MFMA accumulators in VGPRs: its two wave
+// roles overlay their registers, which needs one register class).
+int32_t launch_ffn(const uint4 *act_in, int n_tiles, const unsigned char *wffn, const float *params, uint4 *act_out,
+                   hipStream_t stream);
+int32_t ffn_prepare();  // once per process: dynamic-LDS attribute
 
 // ---------------------------------------------------------------- L: latency path for tiny inputs
 // The kernels above are throughput-shaped: a workgroup walks ALL weights of a layer for its 128
