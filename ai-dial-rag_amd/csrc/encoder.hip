@@ -203,6 +203,10 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[0], hipEventDisableTiming));
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[1], hipEventDisableTiming));
     if (ffn_prepare() != MIR_OK) return fail(MIR_ERR_HIP);
+    {
+        auto kern = oproj_ln_kernel;
+        MIR_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, OPROJ_LDS_BYTES));
+    }
 #undef MIR_TRY
     *out = e;
     return MIR_OK;
@@ -335,8 +339,8 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
                 const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);  // a1 = context
                 if (arc != MIR_OK) return arc;
             }
-            oproj_ln_kernel<<<g4, blk, 0, s>>>(a1, nt, l.wo, l.attn_params, l.attn_params + H, l.attn_params + 2 * H,
-                                               a0, a1);  // in place: each wave reads its tile's context before writing it
+            oproj_ln_kernel<<<g4, dim3(512), OPROJ_LDS_BYTES, s>>>(a1, nt, l.wo, l.attn_params, l.attn_params + H, l.attn_params + 2 * H,
+                                                                   a0, a1);  // in place: a tile's two waves read its context before the first barrier and write after the last
             {
                 const int32_t frc = launch_ffn(a1, nt, l.wffn, l.ffn_params, a0, s);
                 if (frc != MIR_OK) return frc;

@@ -107,6 +107,19 @@ __device__ __forceinline__ float gelu(float x) {
     return 0.5f * x * (1.0f + erf_v);
 }
 
+// LDS-DMA of one 1-KiB piece (16 B per lane; the LDS byte address is wave-uniform), as inline asm so that hipcc's own
+// waits do not cover it (see vec_kernels.h: with the builtin every later ds_read is ordered behind ALL pending DMAs)
+__device__ __forceinline__ void enc_glds16(const void *gsrc, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ uint32_t enc_lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
 // Per-tile bookkeeping: which sequence a 32-token tile belongs to.
 struct TileInfo {
     int seq_first_tile;  // first tile of the tile's sequence
@@ -120,31 +133,36 @@ struct TileInfo {
 // registers of a group g = r>>2 are four CONSECUTIVE features, so bias / gamma / beta are read as
 // float4 (a quarter of the loads of the per-register form, which made this epilogue ~3000
 // instructions and longer than the output projection's MFMAs).
-template <bool PIN_CVT = false>
-__device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 *__restrict__ resid_tile,
-                                                  const float *__restrict__ bias, const float *__restrict__ gamma,
-                                                  const float *__restrict__ beta, uint4 *__restrict__ out_tile,
-                                                  int lane, bool store) {
+// The LayerNorm statistics are summed per HALF of the feature blocks (fb 0-5, fb 6-11) and the two halves added, A + B:
+// oproj_ln_kernel keeps one half per wave and exchanges exactly these partial sums, and every kernel that calls this
+// function must round like it (a sequence's embedding does not depend on which kernels served it).
+//
+// residual_ln_part: the work of one wave on feature blocks [FB0, FB0 + NB) of a tile: y += bias + residual (in place),
+// returns the partial sum; then, given the mean, centres y and returns the partial sum of squares; then, given rstd,
+// scales, shifts and stores.  residual_ln_store strings the three steps together for a wave that holds all 12 blocks.
+template <int NB>
+__device__ __forceinline__ float ln_part_sum(f32x16 (&y)[NB], int fb0, const uint4 *__restrict__ resid_tile,
+                                             const float *__restrict__ bias, int lane) {
     const int h = lane >> 5;
-    // Loads first, arithmetic after: written load-next-to-use, hipcc waited for every one of the ~170 loads of
-    // this epilogue separately (s_waitcnt vmcnt(0) each), which with one wave per SIMD is ~170 exposed round trips.
-    uint4 rr[NFB * 2];
+    // Loads first, arithmetic after: written load-next-to-use, hipcc waited for every one of the loads of this
+    // epilogue separately (s_waitcnt vmcnt(0) each), which with one wave per SIMD is that many exposed round trips.
+    uint4 rr[NB * 2];
 #pragma unroll
-    for (int i = 0; i < NFB * 2; ++i) rr[i] = resid_tile[i * 64 + lane];
+    for (int i = 0; i < NB * 2; ++i) rr[i] = resid_tile[(fb0 * 2 + i) * 64 + lane];
     auto load4 = [&](const float *p, int fb, float4 (&dst)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const float4 *>(p + 32 * fb + 8 * g + 4 * h);
     };
     float4 bcur[4], bnext[4];
-    load4(bias, 0, bcur);
+    load4(bias, fb0, bcur);
     float sum = 0.f;
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) {
-        if (fb + 1 < NFB) load4(bias, fb + 1, bnext);
+    for (int f = 0; f < NB; ++f) {
+        if (f + 1 < NB) load4(bias, fb0 + f + 1, bnext);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float rv[8];
-            frag_to_floats(rr[fb * 2 + s2], rv);
+            frag_to_floats(rr[f * 2 + s2], rv);
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 const int g = 2 * s2 + gq;
@@ -152,8 +170,8 @@ __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * g + i;
-                    const float v = y[fb][r] + bb[i] + rv[4 * gq + i];
-                    y[fb][r] = v;
+                    const float v = y[f][r] + bb[i] + rv[4 * gq + i];
+                    y[f][r] = v;
                     sum += v;
                 }
             }
@@ -161,36 +179,49 @@ __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 
 #pragma unroll
         for (int g = 0; g < 4; ++g) bcur[g] = bnext[g];
     }
-    const float mean = half_sum(sum) * (1.0f / H);
+    return sum;
+}
+template <int NB>
+__device__ __forceinline__ float ln_part_sq(f32x16 (&y)[NB], float mean) {
     float sq = 0.f;
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb)
+    for (int f = 0; f < NB; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float dlt = y[fb][r] - mean;
-            y[fb][r] = dlt;
+            const float dlt = y[f][r] - mean;
+            y[f][r] = dlt;
             sq = fmaf(dlt, dlt, sq);
         }
-    float4 gcur[4], ecur[4], gnext[4], enext[4];
-    load4(gamma, 0, gcur);
-    load4(beta, 0, ecur);
-    const float rstd = rsqrtf(half_sum(sq) * (1.0f / H) + LN_EPS);
+    return sq;
+}
+template <int NB, bool PIN_CVT>
+__device__ __forceinline__ void ln_part_store(f32x16 (&y)[NB], int fb0, float rstd, const float *__restrict__ gamma,
+                                              const float *__restrict__ beta, uint4 *__restrict__ out_tile, int lane, bool store) {
+    const int h = lane >> 5;
+    auto load4 = [&](const float *p, int fb, float4 (&dst)[4]) {
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) {
-        if (fb + 1 < NFB) {
-            load4(gamma, fb + 1, gnext);
-            load4(beta, fb + 1, enext);
+        for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const float4 *>(p + 32 * fb + 8 * g + 4 * h);
+    };
+    float4 gcur[4], ecur[4], gnext[4], enext[4];
+    load4(gamma, fb0, gcur);
+    load4(beta, fb0, ecur);
+#pragma unroll
+    for (int f = 0; f < NB; ++f) {
+        if (f + 1 < NB) {
+            load4(gamma, fb0 + f + 1, gnext);
+            load4(beta, fb0 + f + 1, enext);
         }
         float o[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float gg[4] = {gcur[g].x, gcur[g].y, gcur[g].z, gcur[g].w}, ee[4] = {ecur[g].x, ecur[g].y, ecur[g].z, ecur[g].w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[4 * g + i] = fmaf(y[fb][4 * g + i] * rstd, gg[i], ee[i]);
+            for (int i = 0; i < 4; ++i) o[4 * g + i] = fmaf(y[f][4 * g + i] * rstd, gg[i], ee[i]);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) { gcur[g] = gnext[g]; ecur[g] = enext[g]; }
         if (store) {
+            const int fb = fb0 + f;
             out_tile[(fb * 2 + 0) * 64 + lane] =
                 PIN_CVT ? make_uint4(pack2_rn(o[0], o[1]), pack2_rn(o[2], o[3]), pack2_rn(o[4], o[5]), pack2_rn(o[6], o[7]))
                         : make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
@@ -199,6 +230,27 @@ __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 
                         : make_uint4(pack2(o[8], o[9]), pack2(o[10], o[11]), pack2(o[12], o[13]), pack2(o[14], o[15]));
         }
     }
+}
+
+// y[12] (+bias) + residual -> LayerNorm -> ACT store, for a wave that holds the whole tile.  `y` rows are features.
+// Register r of lane-half h is feature (r&3) + 8*(r>>2) + 4*h of its 32-feature block: the four registers of a group
+// g = r>>2 are four CONSECUTIVE features, so bias / gamma / beta are read as float4.
+template <bool PIN_CVT = false>
+__device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 *__restrict__ resid_tile,
+                                                  const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                  const float *__restrict__ beta, uint4 *__restrict__ out_tile,
+                                                  int lane, bool store) {
+    constexpr int HB = NFB / 2;
+    f32x16(&ya)[HB] = *reinterpret_cast<f32x16(*)[HB]>(&y[0]);
+    f32x16(&yb)[HB] = *reinterpret_cast<f32x16(*)[HB]>(&y[HB]);
+    const float sa = ln_part_sum<HB>(ya, 0, resid_tile, bias, lane);
+    const float sb = ln_part_sum<HB>(yb, HB, resid_tile, bias, lane);
+    const float mean = half_sum(sa + sb) * (1.0f / H);
+    const float qa = ln_part_sq<HB>(ya, mean);
+    const float qb = ln_part_sq<HB>(yb, mean);
+    const float rstd = rsqrtf(half_sum(qa + qb) * (1.0f / H) + LN_EPS);
+    ln_part_store<HB, PIN_CVT>(ya, 0, rstd, gamma, beta, out_tile, lane, store);
+    ln_part_store<HB, PIN_CVT>(yb, HB, rstd, gamma, beta, out_tile, lane, store);
 }
 
 

@@ -11,18 +11,6 @@ namespace enc {
 #ifndef FFN_RING
 #define FFN_RING 4
 #endif
-// LDS-DMA of one 1-KiB piece (16 B per lane), as inline asm so that hipcc's own waits do not cover it (see vec_kernels.h)
-__device__ __forceinline__ void ffn_glds16(const void *gsrc, uint32_t lds_byte_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_byte_addr)
-                 : "memory");
-}
-__device__ __forceinline__ uint32_t ffn_lds_addr(const void *p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
-}
-
 constexpr int FFN_HBUF_BYTES = 2 * 4 * 2 * 64 * 16;  // h hand-off: [2 slots][4 tiles][2 fragments][64 lanes] x 16 B
 constexpr int FFN_LDS_BYTES = 2 * FFN_STAGE_BYTES + FFN_HBUF_BYTES + FFN_PARAM_FLOATS * 4;
 
@@ -122,16 +110,16 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
             if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2] = __builtin_amdgcn_s_memtime();
             if (s + 1 <= NHT) {  // stage s+1 = [ W1(s+2) | W2(s) ] -> slot (s+1)&1; this wave moves pieces 6 tl .. 6 tl + 5 of each half
                 const int j = s + 1;
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(ffn_lds_addr(smem) + (uint32_t)((j & 1) * FFN_STAGE_BYTES + (tl * 6) * 1024));
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)((j & 1) * FFN_STAGE_BYTES + (tl * 6) * 1024));
                 if (j + 1 < NHT) {
                     const uint4 *src = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (j + 1)) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) ffn_glds16(src + i * 64, dst + i * 1024);
+                    for (int i = 0; i < 6; ++i) enc_glds16(src + i * 64, dst + i * 1024);
                 }
                 {
                     const uint4 *src = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (j - 1) + 1) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) ffn_glds16(src + i * 64, dst + FFN_HALF_BYTES + i * 1024);
+                    for (int i = 0; i < 6; ++i) enc_glds16(src + i * 64, dst + FFN_HALF_BYTES + i * 1024);
                 }
             }
             if (s >= 1) {

@@ -156,42 +156,76 @@ int32_t launch_attention(const uint4 *qf, const uint4 *kf, const uint4 *vf, cons
                          uint4 *ctx, hipStream_t stream);
 
 // ---------------------------------------------------------------- E3b: output projection + residual + LN
-// One wave per token tile: the context's 24 fragments stay in registers as the B operand, the
-// projection weights stream as A fragments through an 8-deep register ring (as in qkv_kernel),
-// all 12 output tiles accumulate in registers so LayerNorm runs in the epilogue.
-__global__ __launch_bounds__(256, 1) void oproj_ln_kernel(const uint4 *__restrict__ ctx, int n_tiles,
+// Workgroup = 8 waves = 128 tokens (4 token tiles), two waves per SIMD: wave (tile tl, half hf) keeps the tile's context
+// (24 fragments, 96 VGPRs) as the B operand and accumulates the output tiles 6 hf .. 6 hf + 5 (96 registers).  W_o
+// streams ONCE per workgroup through LDS (LDS-DMA, 6 pieces per wave and stage; stage = output tiles {st, st + 6} =
+// 48 KiB, two slots), where round 1's kernel had every wave stream all 288 KiB of it through its own register ring:
+// four copies per CU at the ~29 B/clk a CU draws from L2 were 80 us of a 12-us product.  LayerNorm: the two waves of
+// a tile exchange their partial sums through LDS (ln_part_* in encoder_common.h: the statistics are defined as
+// half A + half B everywhere, so this kernel and the latency path round alike).
+constexpr int OPROJ_STAGE_BYTES = 2 * KS_H * 1024;                       // two output tiles x 24 k-steps
+constexpr int OPROJ_LDS_BYTES = 2 * OPROJ_STAGE_BYTES + 2 * 8 * 64 * 4;  // + [2 rounds][8 waves][64 lanes] partial sums
+
+__global__ __launch_bounds__(512, 2) void oproj_ln_kernel(const uint4 *__restrict__ ctx, int n_tiles,
                                                           const uint4 *__restrict__ wo, const float *__restrict__ bo,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           const uint4 *__restrict__ act_in, uint4 *__restrict__ act_out) {
-    const int lane = threadIdx.x & 63;
-    const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tt >= n_tiles) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem + 2 * OPROJ_STAGE_BYTES);  // [2][8][64]
+    constexpr int HB = NFB / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tl = wave & 3, hf = wave >> 2;
+    const int tt_raw = blockIdx.x * 4 + tl;
+    const bool live = tt_raw < n_tiles;
+    const int tt = live ? tt_raw : n_tiles - 1;  // idle waves shadow a real tile: they join the barriers and the DMA
+
+    // stage st -> slot st & 1: [ W_o tile st (24 KiB) | W_o tile st + 6 ]; this wave moves pieces 3 wave .. 3 wave + 2 of each
+    auto issue = [&](int st) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)((st & 1) * OPROJ_STAGE_BYTES + (wave * 3) * 1024));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint4 *src = wo + (size_t)(st + HB * half) * (KS_H * 64) + (size_t)(wave * 3) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) enc_glds16(src + i * 64, dst + half * (KS_H * 1024) + i * 1024);
+        }
+    };
+    issue(0);
     const uint4 *cin = ctx + (size_t)tt * (NFB * 2 * 64) + lane;
     uint4 c[KS_H];
 #pragma unroll
     for (int ks = 0; ks < KS_H; ++ks) c[ks] = cin[ks * 64];
-    constexpr int R = 24;  // a whole output tile ahead (768 cycles of MFMAs); must divide KS_H
-    const uint4 *wp = wo + lane;  // [nt][ks][64]
-    uint4 ring[R];
+    f32x16 y[HB];
 #pragma unroll
-    for (int i = 0; i < R; ++i) ring[i] = wp[i * 64];
-    f32x16 y[NFB];
-#pragma unroll
-    for (int nt = 0; nt < NFB; ++nt) {
-        const uint4 *np = wo + (size_t)(nt + 1 < NFB ? nt + 1 : nt) * (KS_H * 64) + lane;
+    for (int st = 0; st < HB; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage st (and, at st = 0, its context) have landed
+        __syncthreads();                                   // stage st is complete; everyone is done with the other slot
+        if (st + 1 < HB) issue(st + 1);
+        const uint4 *w = reinterpret_cast<const uint4 *>(smem + (size_t)(st & 1) * OPROJ_STAGE_BYTES + (size_t)hf * (KS_H * 1024)) + lane;
+        uint4 fr[4];
+        fr[0] = w[0 * 64];
+        fr[1] = w[1 * 64];
+        fr[2] = w[2 * 64];
         f32x16 acc = {0};
 #pragma unroll
         for (int ks = 0; ks < KS_H; ++ks) {
-            const int slot = ks % R;
-            acc = mfma(ring[slot], c[ks], acc);
-            ring[slot] = (ks + R < KS_H) ? wp[(ks + R) * 64] : np[(ks + R - KS_H) * 64];
+            if (ks + 3 < KS_H) fr[(ks + 3) & 3] = w[(ks + 3) * 64];
             __builtin_amdgcn_sched_barrier(0);
+            acc = mfma(fr[ks & 3], c[ks], acc);
         }
-        wp = np;
-        y[nt] = acc;
+        y[st] = acc;
     }
-    residual_ln_store(y, act_in + (size_t)tt * (NFB * 2 * 64), bo, gamma, beta,
-                      act_out + (size_t)tt * (NFB * 2 * 64), lane, true);
+    // LayerNorm over the tile's 384 features: this wave holds blocks [6 hf, 6 hf + 6)
+    const uint4 *resid = act_in + (size_t)tt * (NFB * 2 * 64);
+    const float ps = ln_part_sum<HB>(y, HB * hf, resid, bo, lane);
+    xs[(0 * 8 + wave) * 64 + lane] = ps;
+    __syncthreads();
+    const float mean = half_sum(xs[(0 * 8 + tl) * 64 + lane] + xs[(0 * 8 + 4 + tl) * 64 + lane]) * (1.0f / H);  // half A + half B
+    const float pq = ln_part_sq<HB>(y, mean);
+    xs[(1 * 8 + wave) * 64 + lane] = pq;
+    __syncthreads();
+    const float rstd = rsqrtf(half_sum(xs[(1 * 8 + tl) * 64 + lane] + xs[(1 * 8 + 4 + tl) * 64 + lane]) * (1.0f / H) + LN_EPS);
+    ln_part_store<HB, false>(y, HB * hf, rstd, gamma, beta, act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
 }
 
 // ---------------------------------------------------------------- E4: FFN1 + GELU + FFN2 + residual + LN
