@@ -204,6 +204,10 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[1], hipEventDisableTiming));
     if (ffn_prepare() != MIR_OK) return fail(MIR_ERR_HIP);
     {
+        auto kern = qkv_kernel;
+        MIR_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS_BYTES));
+    }
+    {
         auto kern = oproj_ln_kernel;
         MIR_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, OPROJ_LDS_BYTES));
     }
@@ -334,7 +338,7 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         }
         for (int li = 0; li < nl && !small; ++li) {
             const Layer &l = e->L[li];
-            qkv_kernel<<<dim3((nt + 4 * QKV_G - 1) / (4 * QKV_G)), blk, 0, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
+            qkv_kernel<<<dim3((nt + 4 * QKV_G - 1) / (4 * QKV_G)), blk, QKV_LDS_BYTES, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
             {
                 const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);  // a1 = context
                 if (arc != MIR_OK) return arc;

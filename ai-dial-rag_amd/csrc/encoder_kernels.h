@@ -62,32 +62,37 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 }
 
 // ---------------------------------------------------------------- E2: QKV projection
-// One wave per QKV_G = 3 token tiles (96 tokens; 4 waves per block, no barriers).  wqkv: 36 tiles
-// x 24 k-steps of 1-KiB fragments: tiles 0-11 = Q heads, 12-23 = K heads, 24-35 = V heads.
-// Every wave streams ALL 864 KiB of weights through a 24-deep register ring (L2 hits); with one
-// token tile per wave that stream, not the matrix pipe, set the pace (measured 36 B/clk per CU
-// against the 128 B/clk four waves at full MFMA rate would need: 28 % of MFMA peak).  A fragment
-// now feeds three MFMAs (three token tiles' activations stay in registers: 288 VGPRs), which puts
-// the demand at 43 B/clk per CU.
-// Q, K come out as W^T x^T (rows = head features, lanes = tokens); V as x W
-// (rows = tokens, lanes = head features) so that each is directly the operand
-// the attention kernel needs.  Output fragment buffers: [tile][head][s2][64].
+// One wave per QKV_G = 3 token tiles (96 tokens), 4 waves per block = 384 tokens.  wqkv: 36 tiles x 24 k-steps of
+// 1-KiB fragments: tiles 0-11 = Q heads, 12-23 = K heads, 24-35 = V heads.  The weights enter LDS ONCE per workgroup:
+// a ring of QKV_NS stages (one stage = one weight tile = 24 KiB), filled by LDS-DMA (6 pieces per wave and stage) with
+// counted waits, one barrier per stage; a fragment read from LDS feeds three MFMAs (three token tiles' activations stay
+// in registers: 288 VGPRs).  Round 1's form had every wave stream all 864 KiB through its own register ring - four
+// copies per CU, at the ~29 B/clk a CU draws from L2 that stream (57 us per pass) was longer than the MFMAs (40 us).
+// Q, K come out as W^T x^T (rows = head features, lanes = tokens); V as x W (rows = tokens, lanes = head features) so
+// that each is directly the operand the attention kernel needs.  Output fragment buffers: [tile][head][s2][64].
 constexpr int QKV_G = 3;
+constexpr int QKV_NS = 4;                                     // ring stages
+constexpr int QKV_STAGE_BYTES = KS_H * 1024;                  // one weight tile
+constexpr int QKV_LDS_BYTES = QKV_NS * QKV_STAGE_BYTES + 3 * H * 4;  // + the biases
 
 __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ act, int n_tiles,
                                                      const uint4 *__restrict__ wqkv, const float *__restrict__ bqkv,
                                                      uint4 *__restrict__ qf, uint4 *__restrict__ kf,
                                                      uint4 *__restrict__ vf) {
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * QKV_G;
-    if (t0 >= n_tiles) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *bias = reinterpret_cast<float *>(smem + QKV_NS * QKV_STAGE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = (blockIdx.x * 4 + wave) * QKV_G;
     int tt[QKV_G];
     bool live[QKV_G];
 #pragma unroll
     for (int g = 0; g < QKV_G; ++g) {
         live[g] = t0 + g < n_tiles;
-        tt[g] = live[g] ? t0 + g : n_tiles - 1;  // a missing tile shadows a real one; nothing is stored for it
-    }
+        tt[g] = live[g] ? t0 + g : n_tiles - 1;  // a missing tile shadows a real one; nothing is stored for it (idle waves still
+    }                                             // join the barriers and move their share of the weights)
+    for (int i = tid; i < 3 * H; i += 256) bias[i] = bqkv[i];
+    __syncthreads();  // (the stage barriers below are raw s_barrier: they do not wait for LDS writes)
     uint4 x[QKV_G][KS_H];
 #pragma unroll
     for (int g = 0; g < QKV_G; ++g) {
@@ -95,33 +100,50 @@ __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ a
 #pragma unroll
         for (int ks = 0; ks < KS_H; ++ks) x[g][ks] = xin[ks * 64];
     }
-
-    constexpr int R = 24;  // a whole tile of k-steps (2.3K cycles of MFMAs) ahead: an L2 hit under load takes ~1K; must divide KS_H
-    const uint4 *wp = wqkv + lane;
-    uint4 ring[R];
+    // ordinary loads are complete before the first DMA: the counted waits below count DMAs and stores only
 #pragma unroll
-    for (int i = 0; i < R; ++i) ring[i] = wp[i * 64];
-    // Two loops with a compile-time operand order: with `is_v ? mfma(x, w) : mfma(w, x)` inside one
-    // loop hipcc emitted a branch per MFMA.
+    for (int g = 0; g < QKV_G; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) asm volatile("" : "+v"(x[g][ks].x), "+v"(x[g][ks].y), "+v"(x[g][ks].z), "+v"(x[g][ks].w));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    auto issue = [&](int tile) {  // weight tile `tile` -> slot tile % QKV_NS; this wave moves pieces 6 wave .. 6 wave + 5
+        const uint4 *src = wqkv + (size_t)tile * (KS_H * 64) + (size_t)(wave * 6) * 64 + lane;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)((tile % QKV_NS) * QKV_STAGE_BYTES + (wave * 6) * 1024));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) enc_glds16(src + i * 64, dst + i * 1024);
+    };
+    for (int t = 0; t < QKV_NS - 1; ++t) issue(t);
+
+    // Two loops with a compile-time operand order: with `is_v ? mfma(x, w) : mfma(w, x)` inside one loop hipcc emitted a
+    // branch per MFMA.
     auto run_tiles = [&](int tile_lo, int tile_hi, auto IS_V_) {
         constexpr bool is_v = decltype(IS_V_)::value;
         for (int tile = tile_lo; tile < tile_hi; ++tile) {
-            const uint4 *np = wqkv + (size_t)(tile + 1 < 36 ? tile + 1 : tile) * (KS_H * 64) + lane;
+            // Younger than this stage's 6 DMA pieces, in issue order: stores(tile-3), DMA(tile+1), stores(tile-2), DMA(tile+2),
+            // stores(tile-1) = 30 operations once the pipeline is full; the first and last stages simply drain.
+            if (tile >= 3 && tile + QKV_NS - 1 <= 36) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // stage `tile` is in LDS for everyone; everyone is done with stage tile - 1
+            if (tile + QKV_NS - 1 < 36) issue(tile + QKV_NS - 1);
+            const uint4 *w = reinterpret_cast<const uint4 *>(smem + (size_t)(tile % QKV_NS) * QKV_STAGE_BYTES) + lane;
             f32x16 acc[QKV_G];
 #pragma unroll
             for (int g = 0; g < QKV_G; ++g) acc[g] = f32x16{0};
+            uint4 fr[4];
+            fr[0] = w[0 * 64];
+            fr[1] = w[1 * 64];
+            fr[2] = w[2 * 64];
 #pragma unroll
             for (int ks = 0; ks < KS_H; ++ks) {
-                const int slot = ks % R;
+                if (ks + 3 < KS_H) fr[(ks + 3) & 3] = w[(ks + 3) * 64];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < QKV_G; ++g)
-                    acc[g] = is_v ? mfma(x[g][ks], ring[slot], acc[g]) : mfma(ring[slot], x[g][ks], acc[g]);
-                ring[slot] = (ks + R < KS_H) ? wp[(ks + R) * 64] : np[(ks + R - KS_H) * 64];
-                __builtin_amdgcn_sched_barrier(0);
+                    acc[g] = is_v ? mfma(x[g][ks], fr[ks & 3], acc[g]) : mfma(fr[ks & 3], x[g][ks], acc[g]);
             }
-            wp = np;
             const int head = tile % 12;
-            const float *b = bqkv + tile * 32;
+            const float *b = bias + tile * 32;
             uint4 *dbase = (tile < 12 ? qf : tile < 24 ? kf : vf);
 #pragma unroll
             for (int g = 0; g < QKV_G; ++g) {
@@ -133,11 +155,10 @@ __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ a
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[g][r] += b[fi(r, h)];
                 }
-                if (live[g]) {
-                    uint4 *dst = dbase + ((size_t)(tt[g] * NH + head) * 2) * 64 + lane;
-                    dst[0] = acc_to_frag(acc[g], 0);
-                    dst[64] = acc_to_frag(acc[g], 1);
-                }
+                // always two stores per token tile (the counted waits assume it): a missing tile rewrites its shadow's values
+                uint4 *dst = dbase + ((size_t)(tt[g] * NH + head) * 2) * 64 + lane;
+                dst[0] = acc_to_frag(acc[g], 0);
+                dst[64] = acc_to_frag(acc[g], 1);
             }
         }
     };
