@@ -470,7 +470,8 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     // thresholds of the wide scans + the exact pass's control words: zeroed by the first blocks of the prep kernel
     unsigned long long *gz = reinterpret_cast<unsigned long long *>(sb.gthr);
     const int gwords = sb.ctl_words;
-    MIR_REQUIRE(gwords <= 64 * (ntiles32 * ix->ksteps + b), "control words larger than the prep grid");
+    // (blocks past the fragment and per-query blocks only zero their 64 words and return)
+    const int prep_blocks = std::max(ntiles32 * ix->ksteps + b, (gwords + 63) / 64);
     ExactArgs ea;
     ea.docs = ix->d_orig; ea.docs16 = ix->d_f16; ea.doc_sq = ix->d_docsq; ea.n_rows = (uint32_t)ix->n; ea.d = d;
     ea.metric = metric; ea.q = dq; ea.q_sq = sb.q_sq; ea.q_norm = sb.q_norm; ea.nflag = sb.nflag; ea.flagged = sb.flagged;
@@ -481,7 +482,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     if (pl.exact_only) {
         // k beyond the filter's candidate lists: no scan; every query is the reference's own computation.
         // ceil(min(k, n) / 64) rounds, each one pass over the rows per query.
-        prep_queries_kernel<<<dim3(b), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, 0, nullptr, sb.q_sq, sb.q_norm, gz, gwords);
+        prep_queries_kernel<<<dim3(std::max(b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, 0, nullptr, sb.q_sq, sb.q_norm, gz, gwords);
         flag_all_kernel<<<dim3((b + 255) / 256), dim3(256), 0, stream>>>(b, sb.nflag, sb.flagged);
         MIR_HIP(hipGetLastError());
         const int64_t found = std::min<int64_t>(k, ix->n);
@@ -494,10 +495,10 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         return MIR_OK;
     }
     if (ix->native16)
-        prep_queries_f16_kernel<<<dim3(ntiles32 * ix->ksteps + b), dim3(64), 0, stream>>>(
+        prep_queries_f16_kernel<<<dim3(prep_blocks), dim3(64), 0, stream>>>(
             dq, b, d, ix->ksteps, ntiles32, sb.qsplit, sb.q_sq, sb.q_norm, sb.qscale, gz, gwords);
     else
-        prep_queries_kernel<<<dim3(ntiles32 * ix->ksteps + b), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, ntiles32,
+        prep_queries_kernel<<<dim3(prep_blocks), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, ntiles32,
                                                                                     sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords);
     MIR_HIP(hipGetLastError());
     for (int g = 0; g < ngroups; ++g) {

@@ -311,14 +311,14 @@ def test_float16_native_scan_shapes(amd, metric):
             np.testing.assert_allclose(dist[i], wdist, rtol=1e-12, atol=2e-7 * max(1.0, float(np.abs(wdist).max())))
     if metric == "sqeuclidean_dist":
         assert list(rows[5, :3]) == [31, 32, n - 1]
-    # k up to the float16 scan's list capacity; above it the call is refused, never wrong
-    _, _, rows28, _, cnt28, _ = dev.search(qs[:2], 28, metric)
-    for i in range(2):
-        wrows, _ = oi.find_flat(qs[i], docs32, metric, 28)
-        alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs32) if metric == "cosine_sim" else None
-        assert_same_ids(metric, rows28[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} k=28 q={i}")
-    with pytest.raises(NotImplementedError):
-        dev.search(qs[:1], 29, metric)
+    # k up to the float16 scan's list capacity (28) runs the filter scan; above it the exact pass answers alone
+    for k, want_flag in ((28, 0), (29, amd.nat.FLAG_EXACT_PASS)):
+        _, _, rows_k, _, cnt_k, flags_k = dev.search(qs[:2], k, metric)
+        assert (cnt_k == k).all() and (flags_k[1] == want_flag)
+        for i in range(2):
+            wrows, _ = oi.find_flat(qs[i], docs32, metric, k)
+            alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs32) if metric == "cosine_sim" else None
+            assert_same_ids(metric, rows_k[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} k={k} q={i}")
 
 
 @pytest.mark.parametrize("metric", METRICS)
