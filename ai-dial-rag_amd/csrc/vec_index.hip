@@ -56,6 +56,9 @@ static int pad_ksteps(int d) {
     static const int kInst[] = {1, 2, 4, 8, 16, 24};
     for (int v : kInst)
         if (ks <= v) return v;
+    if (ks <= 32) return 32;  // 384 < d <= 1024: the 64-query K-split scan over the bf16 hi/lo image (whole 16-k-step stages)
+    if (ks <= 48) return 48;
+    if (ks <= 64) return 64;
     return (ks + 7) / 8 * 8;  // generic kernel: multiple of the ring depth
 }
 
@@ -350,6 +353,9 @@ static void release_ws(mir_index *ix, Workspace *w, hipStream_t used, bool pendi
     ix->pool.push_back(w);
 }
 
+// float32 index with 384 < d <= 1024: scanned 64 queries per pass by the K-split kernel of vec_kernels_f16.h (SPLIT form)
+static bool wide64_split(const mir_index *ix) { return !ix->native16 && (ix->ksteps == 32 || ix->ksteps == 48 || ix->ksteps == 64); }
+
 // LDS the 128-query scan needs for a list length
 static size_t b128_lds_bytes(int klist) {
     // DMA ring (at most 96 KiB: b128_ring_stages) (reused for the per-workgroup output at the end) + per-lane lists and pending
@@ -438,12 +444,34 @@ static int32_t launch_scan_f16(const mir_index *ix, const uint4 *qfrag_g, const 
                                                     nq, klist, part_g, gthr_g);                              \
         break;                                                                                               \
     }
+#define MIR_SCAN_CASE_SPLIT(KS)                                                                              \
+    case KS: {                                                                                               \
+        auto kern = sample ? scan_topk_f16_kernel<KS, KIND, true, true> : scan_topk_f16_kernel<KS, KIND, false, true>; \
+        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qfrag_g, qscale_g, n_rows, n_tiles,    \
+                                                    nq, klist, part_g, gthr_g);                              \
+        break;                                                                                               \
+    }
+    if (!ix->native16) {  // float32 index, 384 < d <= 1024: the same kernel over the bf16 hi/lo image
+        switch (ix->ksteps) {
+            MIR_SCAN_CASE_SPLIT(32)
+            MIR_SCAN_CASE_SPLIT(48)
+            MIR_SCAN_CASE_SPLIT(64)
+            default:
+                set_error("internal: wide split scan has no instance for %d k-steps", ix->ksteps);
+                return MIR_ERR_UNSUPPORTED;
+        }
+        MIR_HIP(hipGetLastError());
+        return MIR_OK;
+    }
     switch (ix->ksteps) {
         MIR_SCAN_CASE(64)  // 96 / 128 k-steps would need 192 / 256 VGPRs of query fragments per wave: they spill
         default:
             set_error("internal: float16 scan has no instance for %d k-steps", ix->ksteps);
             return MIR_ERR_UNSUPPORTED;
     }
+#undef MIR_SCAN_CASE_SPLIT
 #undef MIR_SCAN_CASE
     MIR_HIP(hipGetLastError());
     return MIR_OK;
@@ -527,7 +555,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             uint64_t *gt = sb.gthr + (size_t)g * 128;
             const float *qsc = sb.qscale + (size_t)g * qpw;
             auto run = [&](int wgs, uint32_t tiles, uint64_t *out, bool sample) {
-                if (ix->native16) {
+                if (ix->native16 || wide64_split(ix)) {
                     if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_f16<SCAN_IP>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
                     if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_f16<SCAN_COS>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
                     return launch_scan_f16<SCAN_L2>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
@@ -592,6 +620,7 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
     pl->klist = std::min(k + kListMargin, kMaxList);
     // The reference takes any `limit` (embeddings_index.py:58,81).  Beyond what the filter's per-lane candidate
     // lists hold (LDS), an index that could actually return that many rows is searched by the exact pass alone.
+    const bool wide64 = ix->native16 || wide64_split(ix);
     const bool lists_fit = k + kListMargin <= kMaxList && (!ix->native16 || f16_lds_bytes(pl->klist) <= 160 * 1024);
     if (!lists_fit && (ix->native16 || ix->n > (int64_t)kMaxList)) {  // (float32, n <= 64: every row fits the lists)
         pl->exact_only = true;
@@ -600,8 +629,8 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
         pl->nwg = 1;
         return MIR_OK;
     }
-    if (ix->native16) {  // one kernel, 64 queries per pass; its LDS holds lists up to k = 28
-        pl->qpw = kF16Queries;
+    if (wide64 && f16_lds_bytes(pl->klist) <= 160 * 1024) {  // 64 queries per pass; its LDS holds lists up to k = 28 (a float32
+        pl->qpw = kF16Queries;                                  // index with a larger k falls through to the 32-query kernels)
         pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
         const int64_t want16 = (int64_t)ix->n_tiles;
         pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want16));

@@ -122,7 +122,13 @@ __host__ __device__ constexpr size_t f16_lds_bytes(int klist) {
 // LDS, the fourth (the query tile's reducer, j = 2 qt: on different SIMDs for the two query tiles)
 // adds them, un-scales, applies the norm column and runs the candidate filter of
 // scan_topk_b128_kernel one tile behind.
-template <int KSTEPS, int KIND, bool SAMPLE>
+//
+// SPLIT = true is the same kernel over the float32 index's bf16 hi/lo image (vec_kernels.h) for 384 < d <= 1024 -
+// float32 page embeddings of the multimodal / description retrievers (embeddings_index.py:139-153 stores them as
+// float32): a k-step is a (hi, lo) pair of 1-KiB blocks, three bf16 MFMAs per k-step as in scan_topk_b128_kernel, a
+// stage is 16 k-steps (the same 32 KiB), the query is not scaled.  Before, such an index ran scan_topk_generic_kernel
+// (32 queries per pass, fragments re-read from L2 per k-step, nothing in flight across tiles).
+template <int KSTEPS, int KIND, bool SAMPLE, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void scan_topk_f16_kernel(const uint4 *__restrict__ docs,
                                                                const float *__restrict__ aux,
                                                                const uint4 *__restrict__ qfrag,
@@ -130,15 +136,17 @@ __global__ __launch_bounds__(512, 2) void scan_topk_f16_kernel(const uint4 *__re
                                                                uint32_t n_tiles, int nq, int klist,
                                                                uint64_t *__restrict__ part,
                                                                const uint64_t *__restrict__ gthr) {
-    constexpr int SK = kF16StageKsteps;
-    static_assert(KSTEPS % SK == 0 && KSTEPS / SK >= 2, "f16 scan: d must be a multiple of 512, at least 1024");
+    constexpr int BPK = SPLIT ? 2 : 1;        // 1-KiB blocks per k-step
+    constexpr int SK = kF16StageKsteps / BPK; // k-steps per stage (32 KiB either way)
+    static_assert(KSTEPS % SK == 0 && KSTEPS / SK >= 2, "wide scan: whole stages, at least two per tile");
     constexpr int SPT = KSTEPS / SK;          // stages per tile (>= 2: the exchange buffer is single)
     constexpr int WK = SK / 4;                // k-steps per wave per stage
     constexpr int QK = SPT * WK;              // k-steps per wave per tile
+    static_assert(QK <= 16, "query fragments beyond 128 VGPRs per wave spill");
     constexpr int NS = kF16RingStages;
-    constexpr int STAGE_U4 = SK * 64;         // 1 KiB per k-step
-    constexpr int PPW = SK / 8;               // DMA pieces per wave per stage
-    constexpr int TILE_U4 = KSTEPS * 64;
+    constexpr int STAGE_U4 = SK * BPK * 64;   // 1 KiB per block
+    constexpr int PPW = SK * BPK / 8;         // DMA pieces per wave per stage
+    constexpr int TILE_U4 = KSTEPS * BPK * 64;
     constexpr int LS = 128;                   // list column stride
     typedef uint32_t __attribute__((ext_vector_type(16))) u32x16;
 
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void scan_topk_f16_kernel(const uint4 *__re
     uint64_t minkey = 0;
     int minpos = 0, pending = 0;
     const uint64_t seed_thr = (!is_red || SAMPLE) ? 0 : gthr[qt * 32 + qj];
-    const float qinv = (is_red && lane_live) ? qscale_inv[32 * qt + qj] : 0.f;
+    const float qinv = SPLIT ? 1.0f : (is_red && lane_live) ? qscale_inv[32 * qt + qj] : 0.f;
 
     // this wave's quarter of its query tile's fragments: slot s <-> k-step (s / WK) * SK + j * WK + s % WK
     f16x8 qh[QK], ql[QK];
@@ -279,17 +287,38 @@ __global__ __launch_bounds__(512, 2) void scan_topk_f16_kernel(const uint4 *__re
                 }
             }
             if (active) {
-                const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + (j * WK) * 64 + lane;
-                uint4 fr[3];
-                fr[0] = st[0 * 64];
-                fr[1] = st[1 * 64];
+                const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + (j * WK * BPK) * 64 + lane;
+                if constexpr (!SPLIT) {
+                    uint4 fr[3];
+                    fr[0] = st[0 * 64];
+                    fr[1] = st[1 * 64];
 #pragma unroll
-                for (int i = 0; i < WK; ++i) {
-                    if (i + 2 < WK) fr[(i + 2) % 3] = st[(i + 2) * 64];
-                    __builtin_amdgcn_sched_barrier(0);
-                    const f16x8 a = __builtin_bit_cast(f16x8, fr[i % 3]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[part_i * WK + i], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[part_i * WK + i], acc, 0, 0, 0);
+                    for (int i = 0; i < WK; ++i) {
+                        if (i + 2 < WK) fr[(i + 2) % 3] = st[(i + 2) * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                        const f16x8 a = __builtin_bit_cast(f16x8, fr[i % 3]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[part_i * WK + i], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[part_i * WK + i], acc, 0, 0, 0);
+                    }
+                } else {
+                    uint4 fh[3], fl[3];
+                    fh[0] = st[0 * 64];
+                    fl[0] = st[1 * 64];
+                    fh[1] = st[2 * 64];
+                    fl[1] = st[3 * 64];
+#pragma unroll
+                    for (int i = 0; i < WK; ++i) {
+                        if (i + 2 < WK) {
+                            fh[(i + 2) % 3] = st[(2 * (i + 2) + 0) * 64];
+                            fl[(i + 2) % 3] = st[(2 * (i + 2) + 1) * 64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, fh[i % 3]), al = __builtin_bit_cast(bf16x8, fl[i % 3]);
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, qh[part_i * WK + i]), bl = __builtin_bit_cast(bf16x8, ql[part_i * WK + i]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                    }
                 }
                 if (part_i == SPT - 1 && is_red) epilogue(w4);
             }

@@ -599,3 +599,41 @@ def test_full_size_c5_float16_properties(amd):
                                                   amd.nat.ptr(od), amd.nat.ptr(orow), amd.nat.ptr(oc)))
     np.testing.assert_array_equal(orow, rows)
     np.testing.assert_array_equal(od, dist)
+
+
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("d", [1024, 768, 520, 400])
+def test_float32_wide_dims_k_split_scan(amd, metric, d):
+    """float32 rows with 384 < d <= 1024 (multimodal / description page embeddings are stored as float32,
+    embeddings_index.py:139-153 upstream): the 64-query K-split scan over the bf16 hi/lo image (d padded to 512 / 768 /
+    1024 columns), with the threshold pre-pass (>= 32K rows), a ragged last tile, duplicates, batches of 1 / 64 / 100."""
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(1000 + d)
+    n = 40_003
+    docs = (rng.standard_normal((n, d)) * rng.uniform(0.3, 2.0, (n, 1))).astype(np.float32)
+    if metric in ("cosine_sim", "inner_product"):
+        docs = unit(docs)
+    docs[31] = docs[32] = docs[n - 1]
+    qs = rng.standard_normal((100, d))
+    qs[5] = docs[n - 1].astype(np.float64)
+    dev = amd.ei.DeviceIndex.from_host(docs)
+    for b in (1, 64, 100):
+        _, _, rows, dist, cnt, flags = dev.search(qs[:b], 10, metric)
+        assert (cnt == 10).all()
+        for i in list(range(min(b, 8))) + ([63] if b >= 64 else []) + ([99] if b == 100 else []):
+            with np.errstate(invalid="ignore"):
+                wrows, wdist = oi.find_flat(qs[i], docs, metric, 10)
+                alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs) if metric == "cosine_sim" else None
+            assert_same_ids(metric, rows[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} d={d} b={b} q={i}")
+            np.testing.assert_allclose(dist[i], wdist, rtol=1e-9, atol=2e-7 * d, equal_nan=True)
+    if metric in ("sqeuclidean_dist", "inner_product"):
+        _, _, rows, _, _, _ = dev.search(qs[5:6], 10, metric)
+        assert list(rows[0, :3]) == [31, 32, n - 1]
+    # k beyond the 64-query kernel's lists (28): the 32-query kernels take over, same answers
+    _, _, rows40, _, cnt40, _ = dev.search(qs[:3], 40, metric)
+    for i in range(3):
+        with np.errstate(invalid="ignore"):
+            wrows, _ = oi.find_flat(qs[i], docs, metric, 40)
+            alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs) if metric == "cosine_sim" else None
+        assert_same_ids(metric, rows40[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} d={d} k=40 q={i}")
