@@ -134,6 +134,10 @@ class ShardedBM25:
         b = int(q_ptr.numel()) - 1 if q_ptr is not None else len(queries)
         off_idx, off_cnt, size = _blob_layout(b, k)
         blob, gathered, o_score, o_idx, o_cnt, ws = self._buffers(b, k)
+        if self.on_gpu and self.world == 1:  # one shard: its top-k is the result
+            self.model.search_device(queries.data_ptr(), q_ptr.data_ptr(), b, k, o_idx.data_ptr(), o_score.data_ptr(), o_cnt.data_ptr(),
+                                     ws.data_ptr(), t.cuda.current_stream(self.device).cuda_stream)
+            return o_score, o_idx, o_cnt
         if self.on_gpu:
             stream = t.cuda.current_stream(self.device).cuda_stream
             base = blob.data_ptr()
