@@ -93,6 +93,9 @@ def _load():
         "mir_encoder_encode": ([vp, vp, vp, i32, i32, vp], i32),
         "mir_encoder_encode_to_device": ([vp, vp, vp, i32, i32, vp, vp], i32),
         "mir_encoder_debug_hidden": ([vp, vp, vp, i32, i32, vp, vp, i64], i32),
+        "mir_wordpiece_create": ([vp, i64, vp, vp, vp, vp, i32, vp], i32),
+        "mir_wordpiece_destroy": ([vp], i32),
+        "mir_wordpiece_encode": ([vp, vp, vp, i32, i32, i32, vp, vp, vp], i32),
         "mir_rrf_fuse": ([vp, vp, vp, i32, i32, vp, vp, vp], i32),
         "mir_rrf_fuse_batch": ([vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp], i32),
     }

@@ -89,13 +89,33 @@ class BgeEncoder:
 
     @classmethod
     def from_pretrained_dir(cls, path: str, device: int = 0) -> "BgeEncoder":
-        """Load `model.safetensors` + tokenizer files from a local Hugging Face directory."""
+        """Load `model.safetensors` + tokenizer files from a local Hugging Face directory.  The tokenizer is the
+        native WordPiece one over the directory's vocab.txt (embeddings/wordpiece.py: BertTokenizer's rules, all host
+        cores); texts it hands back (code points beyond the BMP) go to the directory's own Hugging Face tokenizer,
+        which is only loaded if that ever happens."""
+        import json
+
         from safetensors.numpy import load_file
-        from transformers import AutoTokenizer
+
+        from .wordpiece import WordPieceTokenizer
 
         sd = load_file(os.path.join(path, "model.safetensors"))
         prefix = "bert." if any(k.startswith("bert.") for k in sd) else ""
-        return cls.from_state_dict(sd, AutoTokenizer.from_pretrained(path), device, prefix)
+        lower = True
+        cfg = os.path.join(path, "tokenizer_config.json")
+        if os.path.exists(cfg):
+            lower = bool(json.load(open(cfg)).get("do_lower_case", True))
+        hf = []
+
+        def fallback(texts, **kw):
+            if not hf:
+                from transformers import AutoTokenizer
+
+                hf.append(AutoTokenizer.from_pretrained(path))
+            return hf[0](texts, **kw)
+
+        tok = WordPieceTokenizer.from_vocab_file(os.path.join(path, "vocab.txt"), do_lower_case=lower, fallback=fallback)
+        return cls.from_state_dict(sd, tok, device, prefix)
 
     # ---- token-id level (what crosses the C ABI) ----
     def encode_ids(self, sequences: Sequence[Sequence[int]], normalize: bool = True) -> np.ndarray:

@@ -360,9 +360,8 @@ def build_embeddings_leg(np, torch, args, local_rank, tmpdir):
     import asyncio
     import json as js
 
-    from transformers import AutoTokenizer
-
     from aidial_rag_amd.embeddings import embeddings as emb
+    from aidial_rag_amd.embeddings.wordpiece import WordPieceTokenizer
 
     os.makedirs(tmpdir, exist_ok=True)
     rng = np.random.default_rng(7)
@@ -373,7 +372,7 @@ def build_embeddings_leg(np, torch, args, local_rank, tmpdir):
     open(os.path.join(tmpdir, "vocab.txt"), "w").write("\n".join(vocab) + "\n")
     js.dump({"tokenizer_class": "BertTokenizer", "do_lower_case": True, "model_max_length": 512},
             open(os.path.join(tmpdir, "tokenizer_config.json"), "w"))
-    tok = AutoTokenizer.from_pretrained(tmpdir)
+    tok = WordPieceTokenizer.from_vocab_file(os.path.join(tmpdir, "vocab.txt"))  # what BgeEncoder.from_pretrained_dir installs
     enc = emb.BgeEncoder.from_state_dict(random_bge_small_state_dict(np), tokenizer=tok, device=local_rank)
     emb.set_bge_embedding_impl(enc)
     try:
@@ -392,7 +391,7 @@ def build_embeddings_leg(np, torch, args, local_rank, tmpdir):
                 "shared_encoder_passes": enc._doc_commit().passes - p0,
                 "mean_tokens_per_chunk": round(float(np.mean([len(x) for x in ids])), 1),
                 "host_tokenise_us_per_chunk_1thread": round(t_tok * 1e6, 1),
-                "note": "texts in, List[np.ndarray] out; includes WordPiece tokenisation (transformers BertTokenizer) and result hand-over",
+                "note": "texts in, List[np.ndarray] out; includes WordPiece tokenisation (native, mir_wordpiece_encode) and result hand-over",
                 "ok": bool(len(out) == n)}
     finally:
         emb.set_bge_embedding_impl(None)

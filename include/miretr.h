@@ -268,6 +268,24 @@ int32_t mir_rrf_fuse_batch(const int64_t *keys, const int64_t *key_base, const i
                            int32_t *out_count);
 
 /* ------------------------------------------------------------------------
+ * WordPiece tokenisation (host code): the BertTokenizer step in front of the encoder
+ * (aidial_rag/embeddings/embeddings.py:79-96 reaches it through sentence-transformers).  The caller supplies the
+ * vocabulary (the lines of vocab.txt) and per-code-point tables over the Basic Multilingual Plane (class of raw and
+ * of normalised code points: 0 other, 1 whitespace, 2 removed, 3 punctuation, 4 CJK, 5 hand the text back; the
+ * normalised form = NFD, combining marks dropped, lower-cased, up to 3 code points): the library carries no Unicode
+ * data.  mir_wordpiece_encode: n UTF-8 texts back to back (text i = [text_ptr[i], text_ptr[i+1])) -> ids with
+ * [CLS] / [SEP], truncated to max_len in all, sequence i at out_ids[i * max_len .. + out_len[i]); fallback[i] = 1
+ * when text i holds a code point beyond the BMP or invalid UTF-8 (nothing written: the caller tokenises it with
+ * the reference tokenizer).  threads <= 0: one per core, at most 32.
+ * ---------------------------------------------------------------------- */
+typedef struct mir_wordpiece mir_wordpiece;
+int32_t mir_wordpiece_create(const char *vocab, int64_t vocab_bytes, const uint8_t *cls, const uint8_t *ncls,
+                             const uint32_t *map, const uint8_t *maplen, int32_t max_chars_per_word, mir_wordpiece **out);
+int32_t mir_wordpiece_destroy(mir_wordpiece *t);
+int32_t mir_wordpiece_encode(const mir_wordpiece *t, const char *texts, const int64_t *text_ptr, int32_t n, int32_t max_len,
+                             int32_t threads, int32_t *out_ids, int32_t *out_len, uint8_t *fallback);
+
+/* ------------------------------------------------------------------------
  * Text encoder: replaces the sentence-transformers forward behind
  * bge_embedding_impl / AsyncEmbeddings (aidial_rag/embeddings/embeddings.py:
  * 52-108): bge-small-en = BERT with hidden 384, 12 heads, FFN 1536, CLS

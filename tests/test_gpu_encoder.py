@@ -157,8 +157,11 @@ def test_build_embeddings_through_the_product_surface(setup, tmp_path, monkeypat
     monkeypatch.setenv("BGE_EMBEDDINGS_DEVICE", "auto")
     emb.set_bge_embedding_impl(None)
     try:
-        impl = emb.bge_embedding_impl()  # from_pretrained_dir + AutoTokenizer
+        impl = emb.bge_embedding_impl()  # from_pretrained_dir: safetensors weights + the native WordPiece tokenizer
         assert impl.layers == 12 and impl.tokenizer is not None
+        from transformers import AutoTokenizer
+
+        hf = AutoTokenizer.from_pretrained(str(tmp_path / "bge"))
         rng = np.random.default_rng(5)
         plain = [w for w in words[104:] if not w.startswith("##") and len(w) > 1]
         texts = [" ".join(rng.choice(plain, rng.integers(3, 120))) + (".\nnext line" if i % 3 == 0 else "") for i in range(700)]
@@ -166,6 +169,7 @@ def test_build_embeddings_through_the_product_surface(setup, tmp_path, monkeypat
         got = asyncio.run(emb.build_embeddings(texts, stage))
         assert len(got) == 700 and "6/6" in stage.getvalue()
         ids = impl.tokenizer([t.replace("\n", " ") for t in texts], add_special_tokens=True, truncation=True, max_length=512)["input_ids"]
+        assert ids == hf([t.replace("\n", " ") for t in texts], add_special_tokens=True, truncation=True, max_length=512)["input_ids"]
         assert impl._doc_commit().passes < 6  # outer batches shared passes
         pick = list(range(0, 700, 23))
         want = oe.embed(model, [ids[i] for i in pick])
