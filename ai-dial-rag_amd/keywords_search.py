@@ -3,15 +3,26 @@
 ``keywords_preprocess(text)`` = NLTK ``word_tokenize`` -> drop tokens found in the English stopword list
 (compared BEFORE lower-casing, so "The" survives) -> Snowball-English stem of the lower-cased token.
 
-The stemmer is native: ``stem_tokens`` hands a whole batch of tokens to ``mir_stem_english`` (C++,
-csrc/stem_english.cpp), which follows NLTK's EnglishStemmer including its quirks and is pinned against it
-token by token (tests/golden/snowball_english.json).  In the reference it is pure Python and, once the
-encoder runs on a GPU, the slowest step of the index build (bm25_retriever.py:30-39,112).
+What is native / restated here, and what it is pinned against:
 
-Tokenisation and the stopword list still come from NLTK and its ``punkt`` / ``stopwords`` data, which are
-not part of this build's image (Punkt is a trained model; there is nothing here to check a restatement
-against): ``keywords_preprocess`` imports them on first use and raises ImportError when they are missing.
-Callers that hold token lists already (the stored ``tokenized_text`` of a DocumentRecord) never need it.
+* the stemmer: ``stem_tokens`` hands a batch of tokens to ``mir_stem_english`` (C++, csrc/stem_english.cpp), which
+  follows NLTK's EnglishStemmer including its quirks - pinned token by token (tests/golden/snowball_english.json.gz).
+  In the reference it is pure Python and, once the encoder runs on a GPU, the slowest step of the index build
+  (bm25_retriever.py:30-39,112);
+* the word tokenizer: ``treebank_tokenize`` restates NLTK's ``NLTKWordTokenizer`` (the per-sentence half of
+  ``word_tokenize``: an ordered list of regular-expression substitutions, then a whitespace split) - pinned on 24 744
+  sentences written by nltk 3.6.5 (tests/golden/treebank_tokenize.json.gz; the reference pins 3.9.1);
+* the sentence splitter in FRONT of it is Punkt, a TRAINED model whose parameters (nltk_data `punkt`) are not in
+  this image: ``split_sentences`` is a rule-based APPROXIMATION (sentence-final punctuation followed by whitespace and
+  a capital / digit / opening quote, a short list of abbreviations excepted) and UNPINNED.  It only matters for the one
+  thing sentence boundaries change: a period at the end of a non-final sentence becomes a token of its own.  A query
+  is normally one sentence, where ``word_tokenize`` IS the Treebank tokenizer;
+* the stopword list: NLTK's English list as shipped with nltk_data through 2023 (179 words), restated from memory and
+  UNPINNED (the data file is absent; newer nltk_data releases extend the list).
+
+When NLTK and its data ARE installed, ``keywords_preprocess`` uses them (exact by construction); otherwise the
+restatements above.  Callers that hold token lists already (the stored ``tokenized_text`` of a DocumentRecord)
+never need any of this.
 """
 
 import ctypes as C
@@ -38,22 +49,113 @@ def stem_tokens(tokens: Sequence[str]) -> List[str]:
     return out.raw[: n.value].decode("utf-8", "surrogatepass").split(_SEP)
 
 
+# ---- NLTKWordTokenizer (nltk/tokenize/destructive.py, nltk 3.6.5), restated: ordered (pattern, replacement) rules ----
+import re
+
+_STARTING_QUOTES = [
+    (re.compile("([\u00ab\u201c\u2018\u201e]|[`]+)"), r" \1 "),
+    (re.compile(r'^"'), r"``"),
+    (re.compile(r"(``)"), r" \1 "),
+    (re.compile(r"([ \(\[{<])(\"|'{2})"), r"\1 `` "),
+    (re.compile(r"(?i)(')(?!re|ve|ll|m|t|s|d|n)(\w)\b"), r"\1 \2"),
+]
+_PUNCTUATION = [
+    (re.compile("([^\\.])(\\.)([\\]\\)}>\"'\u00bb\u201d\u2019 ]*)\\s*$"), r"\1 \2 \3 "),
+    (re.compile(r"([:,])([^\d])"), r" \1 \2"),
+    (re.compile(r"([:,])$"), r" \1 "),
+    (re.compile(r"\.{2,}"), r" \g<0> "),
+    (re.compile(r"[;@#$%&]"), r" \g<0> "),
+    (re.compile(r"([^\.])(\.)([\]\)}>\"']*)\s*$"), r"\1 \2\3 "),
+    (re.compile(r"[?!]"), r" \g<0> "),
+    (re.compile(r"([^'])' "), r"\1 ' "),
+    (re.compile(r"[*]"), r" \g<0> "),
+]
+_PARENS_BRACKETS = (re.compile(r"[\]\[\(\)\{\}\<\>]"), r" \g<0> ")
+_DOUBLE_DASHES = (re.compile(r"--"), r" -- ")
+_ENDING_QUOTES = [
+    (re.compile("([\u00bb\u201d\u2019])"), r" \1 "),
+    (re.compile(r'"'), " '' "),
+    (re.compile(r"(\S)('')"), r"\1 \2 "),
+    (re.compile(r"([^' ])('[sS]|'[mM]|'[dD]|') "), r"\1 \2 "),
+    (re.compile(r"([^' ])('ll|'LL|'re|'RE|'ve|'VE|n't|N'T) "), r"\1 \2 "),
+]
+_CONTRACTIONS = [re.compile(p) for p in (
+    r"(?i)\b(can)(?#X)(not)\b", r"(?i)\b(d)(?#X)('ye)\b", r"(?i)\b(gim)(?#X)(me)\b", r"(?i)\b(gon)(?#X)(na)\b",
+    r"(?i)\b(got)(?#X)(ta)\b", r"(?i)\b(lem)(?#X)(me)\b", r"(?i)\b(more)(?#X)('n)\b", r"(?i)\b(wan)(?#X)(na)\s",
+    r"(?i) ('t)(?#X)(is)\b", r"(?i) ('t)(?#X)(was)\b")]
+
+
+def treebank_tokenize(sentence: str) -> List[str]:
+    """``NLTKWordTokenizer().tokenize(sentence)``: the substitutions in NLTK's order, then a whitespace split."""
+    text = sentence
+    for rx, sub in _STARTING_QUOTES:
+        text = rx.sub(sub, text)
+    for rx, sub in _PUNCTUATION:
+        text = rx.sub(sub, text)
+    text = _PARENS_BRACKETS[0].sub(_PARENS_BRACKETS[1], text)
+    text = _DOUBLE_DASHES[0].sub(_DOUBLE_DASHES[1], text)
+    text = " " + text + " "
+    for rx, sub in _ENDING_QUOTES:
+        text = rx.sub(sub, text)
+    for rx in _CONTRACTIONS:
+        text = rx.sub(r" \1 \2 ", text)
+    return text.split()
+
+
+# ---- sentence splitting: an APPROXIMATION of Punkt (see the module docstring) ----
+_ABBREVIATIONS = frozenset("""mr mrs ms dr prof sr jr st vs etc inc ltd co corp no fig figs eq vol pp ed eds e.g i.e cf al approx dept est
+jan feb mar apr jun jul aug sep sept oct nov dec mon tue wed thu fri sat sun u.s u.k a.m p.m ph.d gen col lt sgt capt rev hon""".split())
+_SENT_END = re.compile(r"""([.?!]+)(["'\u201d\u2019)\]]*)(\s+)(?=["'\u201c\u2018(\[]*[A-Z0-9])""")
+
+
+def split_sentences(text: str) -> List[str]:
+    out, start = [], 0
+    for m in _SENT_END.finditer(text):
+        if m.group(1) == ".":
+            before = text[start : m.start()].rsplit(None, 1)
+            last = (before[-1] if before else "").lower().strip("\"'([")
+            if last in _ABBREVIATIONS or (len(last) == 1 and last.isalpha()):  # "Dr. Smith", initials: "J. Smith"
+                continue
+        end = m.end(2)
+        out.append(text[start:end])
+        start = m.end()
+    tail = text[start:]
+    if tail.strip():
+        out.append(tail)
+    return [s for s in out if s.strip()]
+
+
+def _word_tokenize_restated(text: str) -> List[str]:
+    return [tok for sent in split_sentences(text) for tok in treebank_tokenize(sent)]
+
+
+ENGLISH_STOPWORDS = frozenset("""i me my myself we our ours ourselves you you're you've you'll you'd your yours yourself yourselves he him his
+himself she she's her hers herself it it's its itself they them their theirs themselves what which who whom this that that'll these those am
+is are was were be been being have has had having do does did doing a an the and but if or because as until while of at by for with about
+against between into through during before after above below to from up down in out on off over under again further then once here there when
+where why how all any both each few more most other some such no nor not only own same so than too very s t can will just don don't should
+should've now d ll m o re ve y ain aren aren't couldn couldn't didn didn't doesn doesn't hadn hadn't hasn hasn't haven haven't isn isn't ma
+mightn mightn't mustn mustn't needn needn't shan shan't shouldn shouldn't wasn wasn't weren weren't won won't wouldn wouldn't""".split())
+
+
 @lru_cache(maxsize=1)
-def _nltk_front_end():
+def _front_end():
+    """(stopwords, word_tokenize): NLTK's own when it is installed WITH its data, else the restatements above."""
     try:
         from nltk.corpus import stopwords
         from nltk.tokenize import word_tokenize
 
         stop = frozenset(stopwords.words(LANG))
         word_tokenize("probe the tokenizer data")
-    except (ImportError, LookupError) as e:  # pragma: no cover - depends on the host image
-        raise ImportError(
-            "keywords_preprocess needs nltk with the 'punkt' and 'stopwords' data "
-            "(as the reference does); pass pre-tokenised text or a `preprocess` callable instead"
-        ) from e
-    return stop, word_tokenize
+        return stop, word_tokenize
+    except (ImportError, LookupError):
+        return ENGLISH_STOPWORDS, _word_tokenize_restated
+
+
+def word_tokenize(text: str) -> List[str]:
+    return _front_end()[1](text)
 
 
 def keywords_preprocess(text: str) -> List[str]:
-    stop, word_tokenize = _nltk_front_end()
-    return stem_tokens([t for t in word_tokenize(text) if t not in stop])
+    stop, tokenize = _front_end()
+    return stem_tokens([t for t in tokenize(text) if t not in stop])
