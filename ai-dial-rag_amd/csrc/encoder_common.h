@@ -47,6 +47,9 @@ constexpr int NFB = H / 32;   // 12 feature blocks
 constexpr int KS_H = H / 16;  // 24 k-steps over the hidden dim
 constexpr int NHT = FF / 32;  // 48 intermediate tiles
 constexpr float LN_EPS = 1e-12f;
+// softmax scale 1/sqrt(32) and the log2(e) of exp -> exp2, folded into Q by the QKV kernels (one multiply per Q element
+// there instead of one per score in the VALU-bound attention loop)
+constexpr float kQScaleLog2e = 0.17677669529663688f * 1.4426950408889634f;
 // packed FFN weights: a flat sequence of 24-KiB halves  W1(0) W2(0) W1(1) W2(1) ...  (W1(ht): the 24 k-step fragments
 // of intermediate tile ht; W2(ht): the 24 fragments (output tile nt, s2) for k-steps 2*ht + s2); parameters b1 | b2 | gamma | beta
 constexpr int FFN_HALF_BYTES = 24 * 1024;

@@ -152,8 +152,9 @@ __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ a
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[g][r] += bv;
                 } else {
+                    const float qs = tile < 12 ? kQScaleLog2e : 1.0f;  // Q carries the softmax scale (see attention_kernel)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[g][r] += b[fi(r, h)];
+                    for (int r = 0; r < 16; ++r) acc[g][r] = (acc[g][r] + b[fi(r, h)]) * qs;
                 }
                 // always two stores per token tile (the counted waits assume it): a missing tile rewrites its shadow's values
                 uint4 *dst = dbase + ((size_t)(tt[g] * NH + head) * 2) * 64 + lane;
@@ -297,8 +298,9 @@ __global__ __launch_bounds__(64) MIR_ONE_WAVE void qkv_small_kernel(const uint4 
     } else {           // Q, K: W^T x^T (rows = head features)
 #pragma unroll
         for (int ks = 0; ks < KS_H; ++ks) acc = mfma(w[ks], x[ks], acc);
+        const float qs = tile < 12 ? kQScaleLog2e : 1.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += b[fi(r, h)];
+        for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + b[fi(r, h)]) * qs;
     }
     uint4 *dst = (tile < 12 ? qf : tile < 24 ? kf : vf) + ((size_t)(tt * NH + tile % 12) * 2) * 64 + lane;
     dst[0] = acc_to_frag(acc, 0);
