@@ -143,6 +143,8 @@ class BgeEncoder:
     def _tokenize(self, texts: Sequence[str]) -> List[List[int]]:
         if self.tokenizer is None:
             raise RuntimeError("this BgeEncoder was built without a tokenizer; use encode_ids or pass one")
+        if hasattr(self.tokenizer, "encode_arrays"):  # the native tokenizer: int32 arrays, no Python lists in between
+            return self.tokenizer.encode_arrays(list(texts), MAX_TOKENS)
         enc = self.tokenizer(list(texts), add_special_tokens=True, truncation=True, max_length=MAX_TOKENS)
         return enc["input_ids"]
 
