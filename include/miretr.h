@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define MIR_ABI_VERSION 1
+#define MIR_ABI_VERSION 2 /* 2: results always exact (exact pass), any k; mir_bm25_tune / _corpus_stats / _idf_from_stats /
+                             _set_global_stats, mir_rrf_fuse_batch, mir_wordpiece_* added */
 
 /* status codes */
 #define MIR_OK 0

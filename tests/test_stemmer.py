@@ -55,20 +55,23 @@ def test_batch_edges():
 def test_keywords_preprocess_pipeline(monkeypatch):
     """Stopwords are matched BEFORE lower-casing (keywords_search.py:16-17): "The" survives, "the" does not;
     punctuation tokens are kept."""
-    monkeypatch.setattr(ks, "_nltk_front_end", lambda: (frozenset({"the", "is", "of"}), str.split))
+    monkeypatch.setattr(ks, "_front_end", lambda: (frozenset({"the", "is", "of"}), str.split))
     assert ks.keywords_preprocess("The colours of the Alps , running") == ["the", "colour", "alp", ",", "run"]
 
 
-def test_without_nltk_data_the_front_end_refuses():
+def test_without_nltk_data_the_front_end_is_the_restatement():
+    """No NLTK data in this image: keywords_preprocess runs on the restated tokenizer / stopword list
+    (tests/test_keywords_search.py pins those); with the data installed it would use NLTK's own."""
     try:
         import nltk  # noqa: F401
         from nltk.corpus import stopwords
 
         stopwords.words("english")
     except (ImportError, LookupError):
-        ks._nltk_front_end.cache_clear()
-        with pytest.raises(ImportError, match="punkt"):
-            ks.keywords_preprocess("some text")
+        ks._front_end.cache_clear()
+        stop, tokenize = ks._front_end()
+        assert stop is ks.ENGLISH_STOPWORDS and tokenize is ks._word_tokenize_restated
+        assert ks.keywords_preprocess("some text, surely") == ["text", ",", "sure"]
 
 
 def test_compact_term_ids_first_appearance_order():
