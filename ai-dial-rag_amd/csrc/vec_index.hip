@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -12,6 +13,7 @@
 #include "common.h"
 #include "vec_kernels.h"
 #include "vec_kernels_f16.h"
+#include "vec_kernels_q16.h"
 
 namespace mir {
 
@@ -89,6 +91,7 @@ struct mir_index {
     float *d_orig = nullptr;     // float32 rows (re-scoring); null on a float16-native index
     _Float16 *d_f16 = nullptr;   // float16-native index: the rows as given (re-scoring)
     bool native16 = false;       // float16 storage scanned as 2-byte fragments (vec_kernels_f16.h)
+    bool layout16 = false;       // float32, d padded to 128 / 256 / 384: the 16x16x32 image of vec_kernels_q16.h
     uint4 *d_split = nullptr;    // bf16 hi/lo fragments, or the float16 fragments of a native16 index
     float *d_docsq = nullptr;    // padded to n_tiles*32
     float *d_invnorm = nullptr;  // padded to n_tiles*32
@@ -167,6 +170,7 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
     const int64_t n = ix->n;
     const int d = ix->d;
     ix->ksteps = ix->native16 ? (d + 511) / 512 * 32 : pad_ksteps(d);  // native16: whole 32-k-step stages
+    ix->layout16 = !ix->native16 && (ix->ksteps == 8 || ix->ksteps == 16 || ix->ksteps == 24);  // d padded to 128 / 256 / 384
     ix->n_tiles = (uint32_t)((n + kTileRows - 1) / kTileRows);
     const size_t split_bytes = (size_t)ix->n_tiles * ix->ksteps * (ix->native16 ? 1024 : 2048);
     const size_t aux_bytes = (size_t)ix->n_tiles * kTileRows * sizeof(float);
@@ -187,6 +191,12 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
                                                                             ix->d_split);
             MIR_HIP(hipGetLastError());
             launch_row_norms(ix->d_f16, n, d, ix, stream);
+        } else if (ix->layout16) {
+            const int64_t lanes16 = total_lanes;  // tiles x (ks32 * 2) blocks x 64 lanes; one thread writes a hi and a lo block
+            pack_split16_f32_kernel<<<dim3((unsigned)((lanes16 + 255) / 256)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ksteps / 2,
+                                                                                                   lanes16, ix->d_split);
+            MIR_HIP(hipGetLastError());
+            launch_row_norms(ix->d_orig, n, d, ix, stream);
         } else {
             pack_split_f32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ksteps,
                                                                                   total_lanes, ix->d_split);
@@ -259,6 +269,8 @@ struct SearchPlan {
     int ngroups = 0, nwg = 1, klist = 2, qpw = 32;
     int exact_grid = 1;       // workgroups of exact_topk_kernel
     bool exact_only = false;
+    int nwg_first = 0;        // layout16 progressive scan: workgroups (= candidate lists) and tiles of the first launch;
+    uint32_t tiles_first = 0; // nwg counts the lists of BOTH launches (0 = one launch)
 };
 
 static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int ksteps, const SearchPlan &pl, bool host_api) {
@@ -356,13 +368,6 @@ static void release_ws(mir_index *ix, Workspace *w, hipStream_t used, bool pendi
 // float32 index with 384 < d <= 1024: scanned 64 queries per pass by the K-split kernel of vec_kernels_f16.h (SPLIT form)
 static bool wide64_split(const mir_index *ix) { return !ix->native16 && (ix->ksteps == 32 || ix->ksteps == 48 || ix->ksteps == 64); }
 
-// LDS the 128-query scan needs for a list length
-static size_t b128_lds_bytes(int klist) {
-    // DMA ring (at most 96 KiB: b128_ring_stages) (reused for the per-workgroup output at the end) + per-lane lists and pending
-    // buffers + the hi->lo partial-accumulator exchange (4 query tiles x 16 x 64 floats)
-    return (size_t)96 * 1024 + (size_t)(klist + kB128Pending) * 256 * 8 + 4 * 16 * 64 * 4;
-}
-
 template <int KIND>
 static int32_t launch_scan(const mir_index *ix, const uint4 *qsplit_g, int nq, int klist, int nwg,
                            uint64_t *part_g, hipStream_t stream) {
@@ -381,10 +386,7 @@ static int32_t launch_scan(const mir_index *ix, const uint4 *qsplit_g, int nq, i
     switch (ix->ksteps) {
         MIR_SCAN_CASE(1)
         MIR_SCAN_CASE(2)
-        MIR_SCAN_CASE(4)
-        MIR_SCAN_CASE(8)
-        MIR_SCAN_CASE(16)
-        MIR_SCAN_CASE(24)
+        MIR_SCAN_CASE(4)  // (8 / 16 / 24 k-steps = d padded to 128 / 256 / 384 are layout16 indexes: launch_scan_q16)
         default: {
             auto kern = scan_topk_generic_kernel<KIND>;
             MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -399,31 +401,37 @@ static int32_t launch_scan(const mir_index *ix, const uint4 *qsplit_g, int nq, i
     return MIR_OK;
 }
 
+// float32 layout16 scan: 128 queries per launch, 16 per wave (vec_kernels_q16.h)
 template <int KIND>
-static int32_t launch_scan_b128(const mir_index *ix, const uint4 *qsplit_g, int nq, int klist, int nwg,
-                                uint32_t n_tiles, uint64_t *part_g, uint64_t *gthr_g, bool sample,
-                                hipStream_t stream) {
+static int32_t launch_scan_q16(const mir_index *ix, const uint4 *qsplit_g, const double *q_norm_g, int nq, int klist, int nwg,
+                               uint32_t tile0, uint32_t n_tiles, uint64_t *part_g, uint64_t *gthr_g, bool sample, hipStream_t stream) {
     const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
-    const size_t lds = b128_lds_bytes(klist);
+    const int ks32 = ix->ksteps / 2;
+    const size_t lds = q16_lds_bytes(ks32, klist);
     const uint32_t n_rows = (uint32_t)ix->n;
-#define MIR_SCAN_CASE(KS)                                                                                    \
-    case KS: {                                                                                               \
-        auto kern = sample ? scan_topk_b128_kernel<KS, KIND, true> : scan_topk_b128_kernel<KS, KIND, false>; \
-        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, n_rows, n_tiles, nq,         \
-                                                    klist, part_g, gthr_g);                                  \
-        break;                                                                                               \
-    }
-    switch (ix->ksteps) {
-        MIR_SCAN_CASE(8)
-        MIR_SCAN_CASE(16)
-        MIR_SCAN_CASE(24)
+    const int ns = q16_ring_stages(klist);
+#define MIR_Q16_LAUNCH(KS, NSV)                                                                                        \
+    do {                                                                                                               \
+        auto kern = sample ? scan_topk_q16_kernel<KS, KIND, true, NSV> : scan_topk_q16_kernel<KS, KIND, false, NSV>;   \
+        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, q_norm_g, ix->d_maxnorm, n_rows, tile0, n_tiles, nq, \
+                                                    klist, part_g, gthr_g);                                            \
+    } while (0)
+#define MIR_Q16_CASE(KS)                                                                                               \
+    case KS:                                                                                                           \
+        if (ns == 5) MIR_Q16_LAUNCH(KS, 5);                                                                            \
+        else MIR_Q16_LAUNCH(KS, 4);                                                                                    \
+        break;
+    switch (ks32) {
+        MIR_Q16_CASE(4)
+        MIR_Q16_CASE(8)
+        MIR_Q16_CASE(12)
         default:
-            set_error("internal: b128 scan has no instance for %d k-steps", ix->ksteps);
+            set_error("internal: q16 scan has no instance for %d k-steps of 32", ks32);
             return MIR_ERR_UNSUPPORTED;
     }
-#undef MIR_SCAN_CASE
+#undef MIR_Q16_CASE
+#undef MIR_Q16_LAUNCH
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }
@@ -522,7 +530,11 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         }
         return MIR_OK;
     }
-    if (ix->native16)
+    if (ix->layout16 && qpw == kQ16Queries) {
+        const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (kQ16Queries / 16);
+        prep_queries16_kernel<<<dim3(std::max(ntiles16 * ks32 + b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(
+            dq, b, d, ks32, ntiles16, sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords);
+    } else if (ix->native16)
         prep_queries_f16_kernel<<<dim3(prep_blocks), dim3(64), 0, stream>>>(
             dq, b, d, ix->ksteps, ntiles32, sb.qsplit, sb.q_sq, sb.q_norm, sb.qscale, gz, gwords);
     else
@@ -555,14 +567,30 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             uint64_t *gt = sb.gthr + (size_t)g * 128;
             const float *qsc = sb.qscale + (size_t)g * qpw;
             auto run = [&](int wgs, uint32_t tiles, uint64_t *out, bool sample) {
+                if (ix->layout16) {
+                    const double *qn = sb.q_norm + (size_t)g * qpw;
+                    auto one = [&](int w, uint32_t t0, uint32_t nt, uint64_t *o, bool smp) {
+                        if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_q16<SCAN_IP>(ix, qs, qn, nq, klist, w, t0, nt, o, gt, smp, stream);
+                        if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_q16<SCAN_COS>(ix, qs, qn, nq, klist, w, t0, nt, o, gt, smp, stream);
+                        return launch_scan_q16<SCAN_L2>(ix, qs, qn, nq, klist, w, t0, nt, o, gt, smp, stream);
+                    };
+                    if (sample || pl.nwg_first == 0) return one(wgs, 0, tiles, out, sample);
+                    // Progressive scan: the first 1/16 of the tiles with the sample's thresholds, then the klist-th best of
+                    // what that found as the threshold of the rest (list_threshold_kernel): the rest runs its correction
+                    // products for ~1 % of its blocks instead of ~25 %.  Lists of both launches go to finalize.
+                    int32_t r1 = one(pl.nwg_first, 0, pl.tiles_first, out, false);
+                    if (r1 != MIR_OK) return r1;
+                    list_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(out, pl.nwg_first, qpw, klist, nq,
+                                                                             reinterpret_cast<unsigned long long *>(gt));
+                    return one(wgs - pl.nwg_first, pl.tiles_first, tiles - pl.tiles_first, out + (size_t)pl.nwg_first * qpw * klist, false);
+                }
                 if (ix->native16 || wide64_split(ix)) {
                     if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_f16<SCAN_IP>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
                     if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_f16<SCAN_COS>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
                     return launch_scan_f16<SCAN_L2>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
                 }
-                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_b128<SCAN_IP>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
-                if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_b128<SCAN_COS>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
-                return launch_scan_b128<SCAN_L2>(ix, qs, nq, klist, wgs, tiles, out, gt, sample, stream);
+                set_error("internal: no wide scan for this index");
+                return (int32_t)MIR_ERR_UNSUPPORTED;
             };
             // Scan a sample of the shard first and seed every query's threshold with a lower bound of its
             // klist-th best value (sample_threshold_kernel), so the full pass starts with tight thresholds
@@ -636,12 +664,25 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
         pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want16));
         return MIR_OK;
     }
-    // The 128-query kernel whenever it fits (d padded to a multiple of 128 on the register-resident
-    // kernels, lists + DMA ring within 160 KiB of LDS) - also for 1..32 queries: with idle query tiles
-    // it is simply the better streamer (LDS-DMA ring, nt policy: 2.31 ms per 10M x 384 pass against
-    // 2.64 ms for the 32-query register-ring kernel, which remains for the other shapes and k > 12).
-    const bool wide = (ix->ksteps == 8 || ix->ksteps == 16 || ix->ksteps == 24) && b128_lds_bytes(pl->klist) <= 160 * 1024;
-    pl->qpw = wide ? 128 : 32;
+    if (ix->layout16 && pl->klist > kQ16MaxList) {  // k > 52 on a layout16 index: the exact pass alone (any n)
+        pl->exact_only = true;
+        pl->ngroups = 0;
+        pl->qpw = 32;
+        pl->nwg = 1;
+        return MIR_OK;
+    }
+    if (ix->layout16) {  // the image only the 16-queries-per-wave kernel reads: it takes every k its buffers hold (k <= 52)
+        pl->qpw = kQ16Queries;
+        pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
+        pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), (int64_t)ix->n_tiles));
+        if ((int64_t)ix->n_tiles >= 64 * (int64_t)pl->nwg) {  // >= 64 tiles per workgroup: scan 1/16 first, re-seed, scan the rest
+            pl->tiles_first = ix->n_tiles / 16;
+            pl->nwg_first = pl->nwg;
+            pl->nwg = 2 * pl->nwg;  // lists for finalize
+        }
+        return MIR_OK;
+    }
+    pl->qpw = 32;  // the register-ring kernels: d <= 64, d > 1024, or a float32 wide index with k > 28
     pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
     // one workgroup per CU, or one per tile on shards smaller than that: a workgroup's fixed costs
     // (ring start-up, filling empty lists) grow with the tiles it walks, and on a 1k-5k-row index one

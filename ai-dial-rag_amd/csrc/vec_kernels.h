@@ -484,23 +484,15 @@ __global__ __launch_bounds__(256, 1) void scan_topk_kernel(const uint4 *__restri
     for (int i = tid; i < 32 * klist; i += 256) out[i] = stage[i];
 }
 
-// ---------------------------------------------------------------- scan, 128 queries per pass
-// The doc stream costs the same HBM bytes whether 32 or 128 queries ride on it.
-// Here a workgroup's 4 waves hold one 32-query tile EACH (fragments in registers
-// as above) and consume the SAME doc tiles: the stream enters LDS once per
-// workgroup by LDS-DMA (global_load_lds_dwordx4; the split layout is already
-// lane-linear, so a 1-KiB piece is one wave-instruction and ds_read_b128 at
-// lane*16 is conflict-free) and every wave reads it from there.  Ring of NS
-// stages of SK k-steps (16 KiB); per stage ONE raw s_barrier and a COUNTED
-// vmcnt (never 0 in steady state) so (NS-1) stages = 64 KiB per CU stay in
-// flight across barriers.  No VGPR-destination global load exists in the loop
-// (hipcc would drain vmcnt(0) for it): the per-row norm column comes through
-// the scalar cache, it is wave-uniform.
-// 128-query scan geometry: a stage is half a tile's k-steps (one barrier per stage; lo waves
-// compute stage A, hi waves stage B), except that d <= 128 keeps one 8-k-step stage per tile.
-__host__ __device__ constexpr int b128_stage_ksteps(int ksteps) { return ksteps >= 16 ? ksteps / 2 : 8; }
-__host__ __device__ constexpr int b128_ring_stages(int ksteps) { return 96 / (b128_stage_ksteps(ksteps) * 2); }  // <= 96 KiB of ring
-constexpr int kB128Pending = 4;  // per-lane buffer of appended, not yet merged candidates
+// ---------------------------------------------------------------- shared pieces of the wide (64- and 128-query) scans
+// The doc stream costs the same HBM bytes whether 32 or 128 queries ride on it, so the wide scans (vec_kernels_q16.h:
+// 128 queries over the float32 image of d <= 384; vec_kernels_f16.h: 64 queries over float16 / wide float32 rows)
+// bring it into LDS ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4; the images are lane-linear, so a 1-KiB
+// piece is one wave-instruction and ds_read_b128 at lane*16 is conflict-free) and every wave reads it from there: a
+// ring of stages, per stage ONE raw s_barrier and a COUNTED vmcnt (never 0 in steady state) so that several stages stay
+// in flight across barriers.  No VGPR-destination global load exists in their loops (hipcc would drain vmcnt(0) for
+// it): the per-row norm column comes through the scalar cache, it is wave-uniform.
+constexpr int kB128Pending = 4;  // per-lane buffer of appended, not yet merged candidates (vec_kernels_f16.h)
 
 // LDS-DMA of one 1-KiB piece (16 B per lane) as inline asm: with the builtin, hipcc
 // orders every later ds_read behind ALL pending DMAs (`s_waitcnt vmcnt(0)` after the
@@ -519,7 +511,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
 
-// Candidate handling for the 128-query scan.  Its 4 waves run in lockstep (one
+// Candidate handling of the 64-query K-split scan (vec_kernels_f16.h).  Its waves run in lockstep (one
 // barrier per stage), so anything lane-divergent with a dependent LDS chain sits
 // on the workgroup's critical path at almost every tile (measured: insertions
 // cost 2.5 ms of a 5.6 ms launch).  Therefore:
@@ -564,339 +556,6 @@ __device__ __forceinline__ void drain_candidates(uint32_t mask, const float (&v)
             pending = 0;
         }
     }
-}
-
-// K-split form: 8 waves per workgroup, TWO per SIMD.  Query tile qt (0..3) is served by a
-// "lo" wave (k-steps [0, KS/2)) and a "hi" wave (k-steps [KS/2, KS)); each keeps only its
-// half of the query fragments in registers (96 VGPRs at d = 384), so two waves fit a SIMD
-// and one's VALU / LDS / barrier time hides under the other's MFMAs:
-//     stage 0: lo MFMA            | hi: idle (just wrote its partial)
-//     stage 1: lo MFMA (1st half) | hi MFMA (2nd half)
-//     stage 2: lo: filter + append of tile t-1   | hi MFMA
-// The hi wave hands its partial 32x32 accumulator to its lo partner through LDS once per
-// tile (16 floats per lane); the lo wave owns the candidate lists.
-//
-// SAMPLE = true is the threshold pre-pass over the first tiles of a large shard: no candidate
-// lists at all - every lane (half a query's rows of this workgroup) keeps the MAXIMUM ranking
-// value it saw and writes it to part as float [wg][128][2].  The klist-th largest of a query's
-// 2*nwg maxima belongs to klist distinct rows, so it bounds the index's klist-th best from below
-// (sample_threshold_kernel); with lists, the pass spent ~100 us inserting into empty lists.
-template <int KSTEPS, int KIND, bool SAMPLE>
-__global__ __launch_bounds__(512, 2) void scan_topk_b128_kernel(const uint4 *__restrict__ docs,
-                                                                const float *__restrict__ aux,
-                                                                const uint4 *__restrict__ qsplit, uint32_t n_rows,
-                                                                uint32_t n_tiles, int nq, int klist,
-                                                                uint64_t *__restrict__ part, uint64_t *__restrict__ gthr) {
-    constexpr int SK = b128_stage_ksteps(KSTEPS);   // k-steps per stage
-    static_assert(KSTEPS % SK == 0 && KSTEPS % 8 == 0, "b128 scan needs d padded to a multiple of 128");
-    constexpr int SPT = KSTEPS / SK;         // stages per tile (1 or 2)
-    constexpr int KH = KSTEPS / 2;           // lo waves: k-steps [0, KH); hi waves: [KH, KSTEPS)
-    constexpr int NS = b128_ring_stages(KSTEPS);
-    constexpr int STAGE_U4 = SK * 2 * 64;    // uint4 per stage (2 KiB per k-step)
-    constexpr int PPW = SK * 2 / 8;          // DMA pieces per wave per stage
-    constexpr int TILE_U4 = KSTEPS * 128;
-    typedef uint32_t __attribute__((ext_vector_type(16))) u32x16;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4 *ring = reinterpret_cast<uint4 *>(smem);                                   // [NS][STAGE_U4]
-    uint64_t *list = reinterpret_cast<uint64_t *>(smem + NS * STAGE_U4 * 16);        // [klist + pending][256]
-    float *pbuf = reinterpret_cast<float *>(list + (size_t)(klist + kB128Pending) * 256);  // [4][16][64]
-    uint64_t *stage_out = reinterpret_cast<uint64_t *>(smem);                        // [128][klist], reuses the ring afterwards
-
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, qj = lane & 31;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qt = wave8 & 3;                // query tile
-    const bool is_hi = wave8 >= 4;
-    const int ltid = qt * 64 + lane;         // list column (lo waves only)
-    const bool active = nq > 32 * qt;
-    const bool lane_live = qj + 32 * qt < nq;
-    const uint32_t G = gridDim.x;
-
-    if (!is_hi && !SAMPLE) {
-        for (int p = 0; p < klist + kB128Pending; ++p) list[p * 256 + ltid] = 0;
-    }
-    float best = -__builtin_inff();  // SAMPLE: this lane's maximum
-    uint64_t minkey = 0;
-    int minpos = 0, pending = 0;
-    // Lower bound on this query's klist-th best key, from the sample pre-pass (0 = none).  Read-only
-    // here on purpose: refreshing it in-kernel needs atomics, and no-return atomics complete out of
-    // order with loads in the vmcnt queue, which breaks the counted waits on the DMA ring.
-    const uint64_t seed_thr = (is_hi || SAMPLE) ? 0 : gthr[qt * 32 + qj];
-
-    // this wave's half of its 32 queries' B fragments
-    bf16x8 qh[KH], ql[KH];
-    {
-        const uint4 *qs = qsplit + ((size_t)qt * KSTEPS + (is_hi ? KH : 0)) * 128;
-#pragma unroll
-        for (int s = 0; s < KH; ++s) {
-            qh[s] = __builtin_bit_cast(bf16x8, qs[(s * 2 + 0) * 64 + lane]);
-            ql[s] = __builtin_bit_cast(bf16x8, qs[(s * 2 + 1) * 64 + lane]);
-        }
-    }
-    const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + G - 1) / G : 0;
-    const uint32_t NG = my_tiles * SPT;      // stages this workgroup streams
-
-    auto issue = [&](uint32_t g) {           // stage g -> slot g % NS; 2 consecutive 1-KiB pieces per wave
-        const uint32_t tile = blockIdx.x + (g / SPT) * G;
-        const uint4 *src = docs + (size_t)tile * TILE_U4 + (size_t)(g % SPT) * STAGE_U4 + (wave8 * PPW) * 64 + lane;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(
-            lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave8 * PPW) * 64) * 16);
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
-    };
-    // Touch every Q fragment so hipcc waits for those (ordinary) loads BEFORE the loop: left
-    // alone it keeps `s_waitcnt vmcnt(1..0)` at their first use inside the loop, and vmcnt(0)
-    // there also waits for every DMA in flight.
-#pragma unroll
-    for (int s = 0; s < KH; ++s) asm volatile("" : "+v"(qh[s]), "+v"(ql[s]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (uint32_t g = 0; g < (uint32_t)(NS - 1) && g < NG; ++g) issue(g);
-
-    // lo waves: previous tile's own partial, its norm values and row base ("no rows" at first)
-    f32x16 pacc = {0};
-    float4 pax[4] = {};
-    uint32_t prow0 = n_rows;
-    float4 *pb = reinterpret_cast<float4 *>(pbuf) + (size_t)qt * 4 * 64 + lane;   // partner exchange slot: [4 chunks][64 lanes] float4 (lane-linear b128: conflict-free)
-
-    // filter + append for the previous tile.  `comb` holds ranking values already (inner product:
-    // the dot; sqeuclid: 2*dot - |d|^2, the hi wave folded the norm in); cosine still scales by pax.
-    auto lo_epilogue = [&](const float4 (&w4)[4]) {
-        // complete scores of the previous tile: own partial + the partner's (which, for sqeuclid,
-        // arrives as 2*dot_hi - |d|^2)
-        f32x16 comb;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (KIND == SCAN_L2) {
-                comb[4 * c + 0] = fmaf(2.0f, pacc[4 * c + 0], w4[c].x); comb[4 * c + 1] = fmaf(2.0f, pacc[4 * c + 1], w4[c].y);
-                comb[4 * c + 2] = fmaf(2.0f, pacc[4 * c + 2], w4[c].z); comb[4 * c + 3] = fmaf(2.0f, pacc[4 * c + 3], w4[c].w);
-            } else {
-                comb[4 * c + 0] = pacc[4 * c + 0] + w4[c].x; comb[4 * c + 1] = pacc[4 * c + 1] + w4[c].y;
-                comb[4 * c + 2] = pacc[4 * c + 2] + w4[c].z; comb[4 * c + 3] = pacc[4 * c + 3] + w4[c].w;
-            }
-        }
-        if (SAMPLE) {
-            float x[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                x[r] = comb[r];
-                if (KIND == SCAN_COS) {
-                    const int gq = r >> 2, i = r & 3;
-                    x[r] *= (i == 0) ? pax[gq].x : (i == 1) ? pax[gq].y : (i == 2) ? pax[gq].z : pax[gq].w;
-                }
-            }
-            const float a0 = fmaxf(fmaxf(x[0], x[1]), x[2]), a1 = fmaxf(fmaxf(x[3], x[4]), x[5]);
-            const float a2 = fmaxf(fmaxf(x[6], x[7]), x[8]), a3 = fmaxf(fmaxf(x[9], x[10]), x[11]);
-            const float a4 = fmaxf(fmaxf(x[12], x[13]), x[14]);
-            const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(a4, x[15]));
-            if (prow0 != n_rows) best = fmaxf(best, mx);  // sample tiles are whole tiles
-            return;
-        }
-        float pv[16];
-        uint32_t pmask = 0;
-        // the two half-lanes of a query share the tighter threshold: a row below EITHER list's
-        // worst entry cannot be in the query's top klist
-        const uint64_t other = ((uint64_t)__shfl_xor((uint32_t)(minkey >> 32), 32, 64) << 32) |
-                               (uint64_t)__shfl_xor((uint32_t)minkey, 32, 64);
-        uint64_t thr = other > minkey ? other : minkey;
-        thr = seed_thr > thr ? seed_thr : thr;
-        // Branch-free filter: with short-circuit conditions hipcc emits two scalar branches and an
-        // exec save/restore PER SCORE (measured ~2.9K cycles per tile for these 16 scores alone).
-        // `!(x < vmin)` is `x >= vmin` for numbers and lets NaN through (it is ranked last later);
-        // an open list (no threshold yet) takes everything: vmin = -inf.
-        const float vmin = thr == 0 ? -__builtin_inff() : key_value(thr);
-        const bool full_tile = __builtin_amdgcn_readfirstlane(prow0 != n_rows ? (prow0 & ~31u) + 32 <= n_rows : 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float x = comb[r];
-            if (KIND == SCAN_COS) {
-                const int gq = r >> 2, i = r & 3;
-                x *= (i == 0) ? pax[gq].x : (i == 1) ? pax[gq].y : (i == 2) ? pax[gq].z : pax[gq].w;
-            }
-            pv[r] = x;
-        }
-        // Most tiles hold nothing for any lane once the thresholds are seeded: one maximum per lane
-        // (v_max3 tree) and one wave vote instead of 16 compare-and-set-bit.  max ignores a NaN next
-        // to a number - such a row could only matter while the list is open, and then vmin = -inf
-        // and `!(m < vmin)` holds for any m, NaN included.
-        const float m01 = fmaxf(fmaxf(pv[0], pv[1]), pv[2]), m02 = fmaxf(fmaxf(pv[3], pv[4]), pv[5]);
-        const float m03 = fmaxf(fmaxf(pv[6], pv[7]), pv[8]), m04 = fmaxf(fmaxf(pv[9], pv[10]), pv[11]);
-        const float m05 = fmaxf(fmaxf(pv[12], pv[13]), pv[14]);
-        const float mx = fmaxf(fmaxf(fmaxf(m01, m02), fmaxf(m03, m04)), fmaxf(m05, pv[15]));
-        if (!__any(!(mx < vmin) && prow0 != n_rows)) return;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pmask |= (uint32_t)(!(pv[r] < vmin)) << r;
-        if (!full_tile) {  // wave-uniform; only the index's last, partial tile
-            uint32_t ok = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ok |= (uint32_t)(prow0 + 8 * (r >> 2) + (r & 3) < n_rows) << r;
-            pmask &= ok;
-        }
-        pmask = prow0 == n_rows ? 0u : pmask;  // no previous tile / dead lane
-        drain_candidates(pmask, pv, prow0, list, klist, ltid, minkey, minpos, pending);
-    };
-
-    // The tile's 32 norm values are wave-uniform: one scalar fetch (lgkmcnt); a vector load would
-    // queue behind the DMA ring and hipcc's wait for it would drain the ring.  Load and wait in ONE
-    // statement (SGPRs left "in flight" across other code get copied / spilled before the data
-    // lands).
-    auto load_aux = [&](uint32_t t, float4 (&ax)[4]) {
-        u32x16 sa, sb;
-        const float *ap = aux + (size_t)__builtin_amdgcn_readfirstlane(t) * kTileRows;
-        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(sa), "=&s"(sb)
-                     : "s"(ap)
-                     : "memory");
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            // rows 8*gq + 4*h + i  ->  dwords 8*gq + {0..3} (h = 0) or 8*gq + {4..7} (h = 1)
-            float lo[4], hi[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = 8 * gq + i;
-                lo[i] = __uint_as_float(idx < 16 ? sa[idx] : sb[idx - 16]);
-                hi[i] = __uint_as_float(idx + 4 < 16 ? sa[idx + 4] : sb[idx + 4 - 16]);
-            }
-            ax[gq] = h ? make_float4(hi[0], hi[1], hi[2], hi[3]) : make_float4(lo[0], lo[1], lo[2], lo[3]);
-        }
-    };
-    // sqeuclid: the hi wave folds the norms into its partial.  With two stages per tile it has no
-    // k-steps in the first one, so it fetches them there, off its critical path (MFMAs -> partial ->
-    // barrier); cosine: the lo wave needs them as a factor, after its epilogue.
-    constexpr bool kAuxEarly = KIND == SCAN_L2 && SPT == 2;
-
-    uint32_t g = 0;
-    for (uint32_t ts = 0; ts < my_tiles; ++ts) {
-        const uint32_t t = blockIdx.x + ts * G;
-        f32x16 acc = {0};
-        float4 ax[4] = {};
-        float4 w4[4] = {};  // lo: the partner's partial of tile t-1 (combined with pacc in the epilogue)
-#pragma unroll
-        for (int part_i = 0; part_i < SPT; ++part_i, ++g) {
-            const uint32_t younger = (NG - 1 - g) < (uint32_t)(NS - 2) ? (NG - 1 - g) : (uint32_t)(NS - 2);
-            if (younger == NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only in the last NS-2 stages of the launch
-            __builtin_amdgcn_s_barrier();    // stage g is in LDS; stage g-1 is consumed; partials of tile t-1 are written
-            // Refill the ring FIRST: the loop runs at the DMA pipe's cadence (about 12 B/clk per CU),
-            // and issuing after the first fragment reads instead measured 3 % slower.
-            if (g + NS - 1 < NG) issue(g + NS - 1);
-            if (kAuxEarly && part_i == 0 && is_hi && active) load_aux(t, ax);
-            if (part_i == 0 && !is_hi && active) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) w4[c] = pb[c * 64];
-            }
-            // this wave's k-steps inside the stage, with a distance-2 LDS prefetch (three fragment
-            // pairs in registers): in stages where only one wave of the SIMD has MFMAs, a
-            // read-then-use per k-step would leave the matrix pipe idle for the LDS latency.
-            const int k0 = part_i * SK;
-            if (active) {
-                const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
-                auto run = [&](auto A_, auto B_, auto QOFF_) {
-                    constexpr int A = decltype(A_)::value, B = decltype(B_)::value, QOFF = decltype(QOFF_)::value;
-                    if constexpr (A < B) {
-                        uint4 fh[3], fl[3];
-                        fh[0] = st[(2 * A + 0) * 64];
-                        fl[0] = st[(2 * A + 1) * 64];
-                        if constexpr (A + 1 < B) {
-                            fh[1] = st[(2 * (A + 1) + 0) * 64];
-                            fl[1] = st[(2 * (A + 1) + 1) * 64];
-                        }
-#pragma unroll
-                        for (int i = A; i < B; ++i) {
-                            if (i + 2 < B) {
-                                fh[(i + 2 - A) % 3] = st[(2 * (i + 2) + 0) * 64];
-                                fl[(i + 2 - A) % 3] = st[(2 * (i + 2) + 1) * 64];
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            const int kq = k0 + i - QOFF;
-                            const bf16x8 ah = __builtin_bit_cast(bf16x8, fh[(i - A) % 3]);
-                            const bf16x8 al = __builtin_bit_cast(bf16x8, fl[(i - A) % 3]);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[kq], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[kq], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[kq], acc, 0, 0, 0);
-                        }
-                    }
-                };
-                // stage-local k-step ranges: lo [0, min(8, KH - k0)), hi [max(0, KH - k0), 8)
-                if (!is_hi) {
-                    if (part_i * SK < KH) {
-                        if ((part_i + 1) * SK <= KH) run(std::integral_constant<int, 0>{}, std::integral_constant<int, SK>{}, std::integral_constant<int, 0>{});
-                        else run(std::integral_constant<int, 0>{}, std::integral_constant<int, SK / 2>{}, std::integral_constant<int, 0>{});
-                    }
-                } else {
-                    if ((part_i + 1) * SK > KH) {
-                        if (part_i * SK >= KH) run(std::integral_constant<int, 0>{}, std::integral_constant<int, SK>{}, std::integral_constant<int, KH>{});
-                        else run(std::integral_constant<int, SK / 2>{}, std::integral_constant<int, SK>{}, std::integral_constant<int, KH>{});
-                    }
-                }
-                // lo waves are free in the last stage (or right after their k-steps): previous tile's candidates
-                if (part_i == SPT - 1 && !is_hi) lo_epilogue(w4);
-            }
-        }
-        // The tile's 32 norm values are wave-uniform: one scalar fetch (lgkmcnt); a vector load would
-        // queue behind the DMA ring and hipcc's wait for it would drain the ring.  Load and wait in ONE
-        // statement (SGPRs left "in flight" across other code get copied / spilled before the data
-        // lands).  sqeuclid: the hi wave, which has slack, fetches and folds them into its partial;
-        // cosine: the lo wave needs them as a factor.
-        if (KIND != SCAN_IP && active && !kAuxEarly && (KIND == SCAN_L2 ? is_hi : !is_hi)) load_aux(t, ax);
-        if (is_hi) {
-            if (active) {   // read by the partner after the next barrier
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float4 w = make_float4(acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
-                    if (KIND == SCAN_L2) {
-                        w.x = fmaf(2.0f, w.x, -ax[c].x); w.y = fmaf(2.0f, w.y, -ax[c].y);
-                        w.z = fmaf(2.0f, w.z, -ax[c].z); w.w = fmaf(2.0f, w.w, -ax[c].w);
-                    }
-                    pb[c * 64] = w;
-                }
-            }
-        } else {
-            if (KIND == SCAN_COS) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) pax[gq] = ax[gq];
-            }
-            pacc = acc;
-            prow0 = lane_live ? t * kTileRows + 4 * h : n_rows;
-        }
-    }
-    // the last tile: its partials are complete after one more barrier
-    __syncthreads();
-    if (!is_hi && active) {
-        float4 w4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) w4[c] = pb[c * 64];
-        lo_epilogue(w4);
-        for (int i = 0; i < pending; ++i) {
-            const uint64_t key = list[(klist + i) * 256 + ltid];
-            if (key > minkey) list_insert(list, klist, ltid, key, minkey, minpos);
-        }
-    }
-    if (SAMPLE) {
-        if (!is_hi) reinterpret_cast<float *>(part)[((size_t)blockIdx.x * 128 + 32 * qt + qj) * 2 + h] = best;
-        return;
-    }
-
-    // ---- merge the two half-lists of each query, write [128][klist] per workgroup ----
-    __syncthreads();
-    for (int i = tid; i < 128 * klist; i += 512) stage_out[i] = 0;
-    __syncthreads();
-    if (!is_hi) {
-        const int qloc = 32 * qt + qj;
-        for (int p = 0; p < klist; ++p) {
-            const uint64_t key = list[p * 256 + ltid];
-            if (key == 0) continue;
-            int rank = 0;
-            const int t2 = ltid ^ 32;  // the other half of the same query
-            for (int p2 = 0; p2 < klist; ++p2) {
-                rank += (list[p2 * 256 + ltid] > key) ? 1 : 0;
-                rank += (list[p2 * 256 + t2] > key) ? 1 : 0;
-            }
-            if (rank < klist) stage_out[qloc * klist + rank] = key;
-        }
-    }
-    __syncthreads();
-    uint64_t *out = part + (size_t)blockIdx.x * 128 * klist;
-    for (int i = tid; i < 128 * klist; i += 512) out[i] = stage_out[i];
 }
 
 // Generic dimension: query fragments are re-read from L2 each k-step instead of

@@ -115,17 +115,17 @@ __host__ __device__ constexpr size_t f16_lds_bytes(int klist) {
 
 // 8 waves per workgroup, two per SIMD: query tile qt = wave >> 2 (32 queries each), k-slice
 // j = wave & 3.  A stage is 32 consecutive k-steps of a doc tile (LDS-DMA ring as in
-// scan_topk_b128_kernel: counted vmcnt, one raw s_barrier per stage); inside a stage wave (qt, j)
+// the wide scans' ring: counted vmcnt, one raw s_barrier per stage); inside a stage wave (qt, j)
 // multiplies k-steps 8j..8j+7 against ITS 8 query fragments of that stage (its quarter of the query
 // tile's fragments stays in registers: 128 VGPRs at d = 1024), so every SIMD has work in every
 // stage.  A tile's four partial 32x32 accumulators meet once per tile: three waves write theirs to
 // LDS, the fourth (the query tile's reducer, j = 2 qt: on different SIMDs for the two query tiles)
 // adds them, un-scales, applies the norm column and runs the candidate filter of
-// scan_topk_b128_kernel one tile behind.
+// lane-list filter one tile behind.
 //
 // SPLIT = true is the same kernel over the float32 index's bf16 hi/lo image (vec_kernels.h) for 384 < d <= 1024 -
 // float32 page embeddings of the multimodal / description retrievers (embeddings_index.py:139-153 stores them as
-// float32): a k-step is a (hi, lo) pair of 1-KiB blocks, three bf16 MFMAs per k-step as in scan_topk_b128_kernel, a
+// float32): a k-step is a (hi, lo) pair of 1-KiB blocks, three bf16 MFMAs per k-step (hi*hi, hi*lo, lo*hi), a
 // stage is 16 k-steps (the same 32 KiB), the query is not scaled.  Before, such an index ran scan_topk_generic_kernel
 // (32 queries per pass, fragments re-read from L2 per k-step, nothing in flight across tiles).
 template <int KSTEPS, int KIND, bool SAMPLE, bool SPLIT = false>
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void scan_topk_f16_kernel(const uint4 *__re
 #pragma unroll
         for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
     };
-    // ordinary loads are complete before the first DMA (see scan_topk_b128_kernel)
+    // ordinary loads are complete before the first DMA (the counted waits below count DMAs only)
 #pragma unroll
     for (int s = 0; s < QK; ++s) asm volatile("" : "+v"(qh[s]), "+v"(ql[s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -546,11 +546,11 @@ def main():
     # ---- roofline of the dominant kernel (scan), per launch ----
     # algorithmic bytes per launch: shard rows * d * 4 (the bf16 hi+lo image is
     # the same 4 B/element) + 4 B/row norm column (sqeuclid/cosine) + the query tile + its results.
-    # One launch of scan_topk_b128_kernel serves up to 128 queries (it is used for every batch size at
-    # d = 384, k <= 12; the 32-query register-ring kernel only for other shapes).
+    # One pass of scan_topk_q16_kernel over the shard serves up to 128 queries (every batch size at d <= 384, k <= 56;
+    # the 32-query register-ring kernel only for other shapes).
     n_loc = hi - lo
     aux = 0 if args.metric == "inner_product" else 4 * n_loc
-    wide = d in (128, 256, 384) and k <= 12
+    wide = d in (128, 256, 384) and k <= 56
     qpl = 128 if wide else 32
     q_launch = min(B, qpl)  # queries actually riding one launch
     bytes_launch = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
@@ -588,7 +588,9 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "scan_topk_b128_kernel" if wide else "scan_topk_kernel",
+            # the full shard is streamed by TWO launches of the kernel (first 1/16 of the tiles, then the rest with the
+            # thresholds the first found, list_threshold_kernel in between); the HIP events bracket all three
+            "kernel": "scan_topk_q16_kernel (2 launches per shard + list_threshold_kernel)" if wide else "scan_topk_kernel",
             "queries_per_launch": qpl,
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
