@@ -40,9 +40,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=384)
-    ap.add_argument("--batch", type=int, default=96,
-                    help="queries per step (B).  The scan is clock/power-limited: 128 per pass gives the most QPS (~37k) at "
-                         "57-60 %% of the HBM roofline, 96 gives ~31k at 63-65 %%, 64 ~25k at 77 %%; the sweep reports the others")
+    ap.add_argument("--batch", type=int, default=128,
+                    help="queries per step (B).  One pass of the shard serves up to 128 queries at (nearly) the same cost, "
+                         "so 128 gives the most QPS (~52k at ~82 %% of the HBM roofline; 96: ~40k at 83 %%; 64: ~27k); the "
+                         "sweep reports the others")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="sqeuclidean_dist")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample (0 = skip)")
@@ -546,11 +547,11 @@ def main():
     # ---- roofline of the dominant kernel (scan), per launch ----
     # algorithmic bytes per launch: shard rows * d * 4 (the bf16 hi+lo image is
     # the same 4 B/element) + 4 B/row norm column (sqeuclid/cosine) + the query tile + its results.
-    # One pass of scan_topk_q16_kernel over the shard serves up to 128 queries (every batch size at d <= 384, k <= 56;
+    # One pass of scan_topk_q16_kernel over the shard serves up to 128 queries (every batch size at d <= 384, k <= 52;
     # the 32-query register-ring kernel only for other shapes).
     n_loc = hi - lo
     aux = 0 if args.metric == "inner_product" else 4 * n_loc
-    wide = d in (128, 256, 384) and k <= 56
+    wide = d <= 384 and d > 64 and k <= 52
     qpl = 128 if wide else 32
     q_launch = min(B, qpl)  # queries actually riding one launch
     bytes_launch = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
@@ -589,7 +590,8 @@ def main():
         "roofline": {
             "bound": "hbm",
             # the full shard is streamed by TWO launches of the kernel (first 1/16 of the tiles, then the rest with the
-            # thresholds the first found, list_threshold_kernel in between); the HIP events bracket all three
+            # thresholds the first found, list_threshold_kernel in between); the HIP events bracket all three.  The
+            # 32K-row sample launch before them (13 us) is outside the bracket and inside `step_frac`.
             "kernel": "scan_topk_q16_kernel (2 launches per shard + list_threshold_kernel)" if wide else "scan_topk_kernel",
             "queries_per_launch": qpl,
             "achieved": round(achieved, 1),
@@ -617,7 +619,7 @@ def main():
             if Bs == B:
                 continue
             index.profile(True)
-            for i in range(3):
+            for i in range(5):
                 searcher.search(queries[i * Bs : (i + 1) * Bs], k, args.metric)
             barrier()
             index.profile_read(reset=True)
