@@ -37,7 +37,7 @@ struct Layer {
     uint4 *wo = nullptr;          // [12][24][64]
     float *attn_params = nullptr; // bo | gamma | beta  [3*384]
     unsigned char *wffn = nullptr;// [48][48 KiB]
-    float *ffn_params = nullptr;  // b1 | b2 | gamma | beta
+    float *ffn_params = nullptr;  // b1 | b2 | gamma | beta | GELU table (encoder_common.h)
 };
 
 }  // namespace
@@ -191,7 +191,8 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
         }
         MIR_TRY(upload(e, (void **)&l.wffn, buf.data(), buf.size() * 2));
         {
-            std::vector<float> p(FFN_PARAM_FLOATS);
+            std::vector<float> p(FFN_PARAM_FLOATS + GELU_LUT_FLOATS);  // b1 | b2 | gamma | beta | GELU table
+            gelu_table(p.data() + FFN_PARAM_FLOATS);
             std::memcpy(p.data(), t[11], sizeof(float) * FF);
             std::memcpy(p.data() + FF, t[13], sizeof(float) * H);
             std::memcpy(p.data() + FF + H, t[14], sizeof(float) * H);

@@ -31,6 +31,7 @@
 // (shared by encoder.hip and encoder_attention.hip: types, fragment helpers, the LayerNorm epilogue)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <type_traits>
 
 namespace mir {
@@ -96,18 +97,48 @@ __device__ __forceinline__ void frag_to_floats(uint4 f, float (&out)[8]) {
 __device__ __forceinline__ float half_sum(float x) { return x + __shfl_xor(x, 32, 64); }
 __device__ __forceinline__ float half_max(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
 
-// exact-erf GELU (HF "gelu"), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
-__device__ __forceinline__ float gelu(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float e = 1.0f - p * __expf(-z * z);
-    const float erf_v = x < 0.f ? -e : e;
-    return 0.5f * x * (1.0f + erf_v);
+// GELU by table (x * Phi(x), Phi = the standard normal CDF of HF "gelu"): Phi is linear per step of 1/128 on [-5.5, 5.5],
+// entry n <-> x_n = -5.5 + n / 128 holds (a_n, b_n) with Phi(x) ~ a_n + b_n x on [x_n - 1/256, x_n + 1/256] (the minimax
+// line of the step, built in float64 on the host: gelu_table()); |Phi error| <= 1e-6, so |GELU error| <= 1e-6 |x| - two
+// orders below the float16 rounding of the result.  Four full-rate VALU + one 8-byte table read per value instead of
+// ~16 VALU + v_rcp + v_exp for the erf formula: the FFN kernel's FFN1 waves are VALU-issue-bound.
+constexpr int GELU_LUT_N = 1409;
+constexpr int GELU_LUT_FLOATS = 2 * 1410;  // padded to a multiple of 4 floats
+constexpr float GELU_LUT_LIM = 5.5f;
+// host: the GELU_LUT_FLOATS floats of the table (a_0, b_0, a_1, b_1, ...)
+inline void gelu_table(float *out) {
+    auto phi = [](double x) { return 0.5 * erfc(-x * 0.70710678118654752440); };
+    const double d = 1.0 / 256.0;
+    for (int n = 0; n < GELU_LUT_FLOATS / 2; ++n) {
+        const double xn = -5.5 + (double)(n < GELU_LUT_N ? n : GELU_LUT_N - 1) / 128.0;
+        const double lo = phi(xn - d), hi = phi(xn + d), mid = phi(xn);
+        const double b = (hi - lo) / (2.0 * d);
+        const double a = 0.5 * (mid + 0.5 * (lo + hi)) - b * xn;  // chord moved half-way to the curve: equal error at the middle and the ends
+        out[2 * n] = (float)a;
+        out[2 * n + 1] = (float)b;
+    }
+}
+// byte address of x's table entry (base = where the table starts: an LDS byte address or 0 for an offset), and the
+// clamped x.  float(2^23 + n) holds n = rne(128 clamp(x) + 704) in its low 24 bits, which v_mad_u32_u24 reads.
+__device__ __forceinline__ uint32_t gelu_lut_addr(float x, float &xc, uint32_t base) {
+    xc = __builtin_amdgcn_fmed3f(x, -GELU_LUT_LIM, GELU_LUT_LIM);  // NaN -> -5.5 (min3), the product with x restores it
+    const float t = fmaf(xc, 128.0f, 8388608.0f + 704.0f);
+    uint32_t addr;
+    asm("v_mad_u32_u24 %0, %1, 8, %2" : "=v"(addr) : "v"(__float_as_uint(t)), "s"(base));
+    return addr;
+}
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+__device__ __forceinline__ f32x2 lds_read_f2(uint32_t byte_addr) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) f32x2 *>(byte_addr);
+}
+// float16 pair (lo = gelu(x0), hi = gelu(x1)) from the table entries of x0, x1; the conversion is part of the last
+// multiply (v_fma_mix*: one rounding), stated as the instruction so that every kernel rounds alike
+__device__ __forceinline__ uint32_t gelu_pack2(float x0, float xc0, f32x2 e0, float x1, float xc1, f32x2 e1) {
+    const float p0 = fmaf(e0.y, xc0, e0.x), p1 = fmaf(e1.y, xc1, e1.x);
+    uint32_t d;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(x0), "v"(p0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(x1), "v"(p1));
+    return d;
 }
 
 // LDS-DMA of one 1-KiB piece (16 B per lane; the LDS byte address is wave-uniform), as inline asm so that hipcc's own
@@ -145,7 +176,7 @@ struct TileInfo {
 // scales, shifts and stores.  residual_ln_store strings the three steps together for a wave that holds all 12 blocks.
 template <int NB>
 __device__ __forceinline__ float ln_part_sum(f32x16 (&y)[NB], int fb0, const uint4 *__restrict__ resid_tile,
-                                             const float *__restrict__ bias, int lane) {
+                                             const float *__restrict__ bias, int lane, float sum = 0.f) {
     const int h = lane >> 5;
     // Loads first, arithmetic after: written load-next-to-use, hipcc waited for every one of the loads of this
     // epilogue separately (s_waitcnt vmcnt(0) each), which with one wave per SIMD is that many exposed round trips.
@@ -158,7 +189,6 @@ __device__ __forceinline__ float ln_part_sum(f32x16 (&y)[NB], int fb0, const uin
     };
     float4 bcur[4], bnext[4];
     load4(bias, fb0, bcur);
-    float sum = 0.f;
 #pragma unroll
     for (int f = 0; f < NB; ++f) {
         if (f + 1 < NB) load4(bias, fb0 + f + 1, bnext);
@@ -238,7 +268,9 @@ __device__ __forceinline__ void ln_part_store(f32x16 (&y)[NB], int fb0, float rs
 // y[12] (+bias) + residual -> LayerNorm -> ACT store, for a wave that holds the whole tile.  `y` rows are features.
 // Register r of lane-half h is feature (r&3) + 8*(r>>2) + 4*h of its 32-feature block: the four registers of a group
 // g = r>>2 are four CONSECUTIVE features, so bias / gamma / beta are read as float4.
-template <bool PIN_CVT = false>
+// QUARTERS: load the residual three blocks at a time instead of six (a wave that also holds other state: the FFN kernel);
+// the sums run over the blocks in the same order either way, so the result is the same bit for bit.
+template <bool PIN_CVT = false, bool QUARTERS = false>
 __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 *__restrict__ resid_tile,
                                                   const float *__restrict__ bias, const float *__restrict__ gamma,
                                                   const float *__restrict__ beta, uint4 *__restrict__ out_tile,
@@ -246,8 +278,21 @@ __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 
     constexpr int HB = NFB / 2;
     f32x16(&ya)[HB] = *reinterpret_cast<f32x16(*)[HB]>(&y[0]);
     f32x16(&yb)[HB] = *reinterpret_cast<f32x16(*)[HB]>(&y[HB]);
-    const float sa = ln_part_sum<HB>(ya, 0, resid_tile, bias, lane);
-    const float sb = ln_part_sum<HB>(yb, HB, resid_tile, bias, lane);
+    float sa, sb;
+    if (QUARTERS) {
+        constexpr int QB = HB / 2;
+        f32x16(&y0)[QB] = *reinterpret_cast<f32x16(*)[QB]>(&y[0]);
+        f32x16(&y1)[QB] = *reinterpret_cast<f32x16(*)[QB]>(&y[QB]);
+        f32x16(&y2)[QB] = *reinterpret_cast<f32x16(*)[QB]>(&y[2 * QB]);
+        f32x16(&y3)[QB] = *reinterpret_cast<f32x16(*)[QB]>(&y[3 * QB]);
+        sa = ln_part_sum<QB>(y0, 0, resid_tile, bias, lane);
+        sa = ln_part_sum<QB>(y1, QB, resid_tile, bias, lane, sa);
+        sb = ln_part_sum<QB>(y2, 2 * QB, resid_tile, bias, lane);
+        sb = ln_part_sum<QB>(y3, 3 * QB, resid_tile, bias, lane, sb);
+    } else {
+        sa = ln_part_sum<HB>(ya, 0, resid_tile, bias, lane);
+        sb = ln_part_sum<HB>(yb, HB, resid_tile, bias, lane);
+    }
     const float mean = half_sum(sa + sb) * (1.0f / H);
     const float qa = ln_part_sq<HB>(ya, mean);
     const float qb = ln_part_sq<HB>(yb, mean);

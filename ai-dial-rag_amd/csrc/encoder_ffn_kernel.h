@@ -11,8 +11,16 @@ namespace enc {
 #ifndef FFN_RING
 #define FFN_RING 4
 #endif
+// Of the six 1-KiB pieces of a W1 half that belong to token tile tl, the A wave of the tile moves the first
+// FFN_A_PIECES and its B wave the rest (plus its six pieces of the W2 half): an LDS-DMA piece costs the issuing wave
+// 75-100 cycles, so the split balances the two roles' stage times (tools/ffn_stamps.hip).
+#ifndef FFN_A_PIECES
+#define FFN_A_PIECES 2
+#endif
 constexpr int FFN_HBUF_BYTES = 2 * 4 * 2 * 64 * 16;  // h hand-off: [2 slots][4 tiles][2 fragments][64 lanes] x 16 B
-constexpr int FFN_LDS_BYTES = 2 * FFN_STAGE_BYTES + FFN_HBUF_BYTES + FFN_PARAM_FLOATS * 4;
+constexpr int FFN_LUT_BYTES = 12 * 1024;            // the GELU table first: its offsets then fit a ds_read's 16-bit immediate
+constexpr int FFN_LDS_BYTES = FFN_LUT_BYTES + 2 * FFN_STAGE_BYTES + FFN_HBUF_BYTES + FFN_PARAM_FLOATS * 4;
+static_assert(GELU_LUT_FLOATS * 4 <= FFN_LUT_BYTES, "GELU table");
 
 // STAMPS (diagnostic builds only, tools/ffn_stamps.hip): workgroup 0 records s_memtime at the top of every stage (after
 // the barrier) and at the end of its stage work, per wave: stamps[wave][stage][2].
@@ -21,7 +29,9 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
                                                         const unsigned char *__restrict__ wffn,
                                                         const float *__restrict__ params, uint4 *__restrict__ act_out,
                                                         unsigned long long *__restrict__ stamps) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    const uint32_t lut_base = __builtin_amdgcn_readfirstlane(enc_lds_addr(lds_all));
+    unsigned char *smem = lds_all + FFN_LUT_BYTES;  // the two weight stages
     uint4 *hb = reinterpret_cast<uint4 *>(smem + 2 * FFN_STAGE_BYTES);
     float *prm = reinterpret_cast<float *>(smem + 2 * FFN_STAGE_BYTES + FFN_HBUF_BYTES);
 
@@ -34,9 +44,13 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
     const int tt = live ? tt_raw : n_tiles - 1;  // idle waves shadow a real tile: they must join barriers and the staging
 
     for (int i = tid; i < FFN_PARAM_FLOATS; i += 512) prm[i] = params[i];
+    for (int i = tid; i < GELU_LUT_FLOATS; i += 512) reinterpret_cast<float *>(lds_all)[i] = params[FFN_PARAM_FLOATS + i];
 
     if (!role_b) {
         // ------------------------------------------------------------------ role A
+#ifdef FFN_A_PRIO
+        __builtin_amdgcn_s_setprio(FFN_A_PRIO);
+#endif
         const uint4 *xin = act_in + (size_t)tt * (NFB * 2 * 64) + lane;
         uint4 x[KS_H];
 #pragma unroll
@@ -56,8 +70,10 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
         }
         __syncthreads();  // params, W1(0), W1(1) are in LDS
 
-        // first product of tile 0, from stage -1 (slot 1, first half)
-        f32x16 hacc = {0};
+        // first product of tile 0, from stage -1 (slot 1, first half); the accumulator starts from the bias
+        f32x16 hacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[r] = prm[fi(r, h)];
         {
             const uint4 *st = reinterpret_cast<const uint4 *>(smem + FFN_STAGE_BYTES) + lane;
             uint4 fr[FFN_RING];
@@ -70,37 +86,76 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
                 hacc = mfma(fr[ks % FFN_RING], x[ks], hacc);
             }
         }
-        for (int s = 0; s <= NHT; ++s) {
+        // One stage of role A, in the order the instructions are to issue (a sched_barrier after every k-step keeps it): hipcc
+        // left alone sinks the fragment reads next to their MFMAs (two reads in flight, each pair's LDS latency exposed:
+        // 92 cycles per MFMA measured) and bunches the GELU at the end of the stage.  Per k-step: the fragment read
+        // FFN_RING - 1 steps ahead, the MFMA of the NEXT tile's product, and a slice of the GELU of THIS tile - steps 0..15
+        // look up one value each, even steps 6..20 finish a pair, steps 14 and 22 hand the two fragments over.
+        auto stage_a = [&](int s, f32x16 &cur, f32x16 &nxt, auto with_next) {
+            constexpr bool NEXT = decltype(with_next)::value;
+            const uint4 *st = reinterpret_cast<const uint4 *>(smem + (size_t)(s & 1) * FFN_STAGE_BYTES) + lane;  // W1(s+1)
+            uint4 *ho = hb + ((size_t)((s & 1) * 4 + tl) * 2) * 64 + lane;
+            uint4 fr[FFN_RING];
+            if (NEXT) {
+                const float *b1 = prm + 32 * (s + 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nxt[r] = b1[fi(r, h)];  // the accumulator starts from the bias
+#pragma unroll
+                for (int i = 0; i < FFN_RING - 1; ++i) fr[i] = st[i * 64];
+            }
+            uint32_t addr[16], hw[8];
+            float xc[16];
+            f32x2 e[16];
+            // this wave's six 1-KiB pieces of W1(s + 2) -> first half of slot (s + 1) & 1, one every other k-step (the B waves
+            // move W2(s) into the second half)
+            const bool dma = s + 2 < NHT;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)(((s + 1) & 1) * FFN_STAGE_BYTES + (tl * 6) * 1024));
+            const uint4 *src = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (s + 2)) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < KS_H; ++ks) {
+#ifndef FFN_ABL_NO_DMA
+                if (dma && (ks & 1) && (ks >> 1) < FFN_A_PIECES) enc_glds16(src + (ks >> 1) * 64, dst + (ks >> 1) * 1024);
+#endif
+                if (NEXT) {
+                    if (ks + FFN_RING - 1 < KS_H) fr[(ks + FFN_RING - 1) % FFN_RING] = st[(ks + FFN_RING - 1) * 64];
+                    nxt = mfma(fr[ks % FFN_RING], x[ks], nxt);
+                }
+                if (ks < 16) {
+                    addr[ks] = gelu_lut_addr(cur[ks], xc[ks], lut_base);
+                    e[ks] = lds_read_f2(addr[ks]);
+                }
+                if (ks >= 6 && ks <= 20 && (ks & 1) == 0) {
+                    const int p = (ks - 6) >> 1;
+                    hw[p] = gelu_pack2(cur[2 * p], xc[2 * p], e[2 * p], cur[2 * p + 1], xc[2 * p + 1], e[2 * p + 1]);
+                }
+                if (ks == 14) ho[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                if (ks == 22) ho[64] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed before the barrier publishes them
+        };
+        f32x16 hnx;
+        for (int s = 0; s < NHT; s += 2) {  // two stages per trip: hacc / hnx swap roles instead of being copied (NHT is even)
             __syncthreads();  // stage s is complete in slot s & 1; everyone is done with slot (s + 1) & 1; h(s - 1) is visible
             if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2] = __builtin_amdgcn_s_memtime();
-            if (s < NHT) {
-                const uint4 *st = reinterpret_cast<const uint4 *>(smem + (size_t)(s & 1) * FFN_STAGE_BYTES) + lane;  // W1(s+1)
-                const float *b1 = prm + 32 * s;
-                float g[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) g[r] = hacc[r] + b1[fi(r, h)];
-                f32x16 hn = {0};
-                if (s + 1 < NHT) {
-                    uint4 fr[FFN_RING];
-#pragma unroll
-                    for (int i = 0; i < FFN_RING - 1; ++i) fr[i] = st[i * 64];
-#pragma unroll
-                    for (int ks = 0; ks < KS_H; ++ks) {
-                        if (ks + FFN_RING - 1 < KS_H) fr[(ks + FFN_RING - 1) % FFN_RING] = st[(ks + FFN_RING - 1) * 64];
-                        hn = mfma(fr[ks % FFN_RING], x[ks], hn);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) g[r] = gelu(g[r]);
-                uint4 *ho = hb + ((size_t)((s & 1) * 4 + tl) * 2) * 64 + lane;
-                ho[0] = make_uint4(pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7]));
-                ho[64] = make_uint4(pack2(g[8], g[9]), pack2(g[10], g[11]), pack2(g[12], g[13]), pack2(g[14], g[15]));
-                hacc = hn;
-            }
+            stage_a(s, hacc, hnx, std::true_type{});
             if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2 + 1] = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s + 1) * 2] = __builtin_amdgcn_s_memtime();
+            if (s + 2 < NHT) stage_a(s + 1, hnx, hacc, std::true_type{});
+            else stage_a(s + 1, hnx, hacc, std::false_type{});
+            if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s + 1) * 2 + 1] = __builtin_amdgcn_s_memtime();
+        }
+        __syncthreads();  // stage NHT: role B's last product
+        if (STAMPS && blockIdx.x == 0 && lane == 0) {
+            stamps[(wave * (NHT + 1) + NHT) * 2] = __builtin_amdgcn_s_memtime();
+            stamps[(wave * (NHT + 1) + NHT) * 2 + 1] = __builtin_amdgcn_s_memtime();
         }
     } else {
         // ------------------------------------------------------------------ role B
+#ifdef FFN_B_PRIO
+        __builtin_amdgcn_s_setprio(FFN_B_PRIO);
+#endif
         f32x16 y[NFB];
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) y[fb] = f32x16{0};
@@ -108,13 +163,14 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
         for (int s = 0; s <= NHT; ++s) {
             __syncthreads();
             if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2] = __builtin_amdgcn_s_memtime();
+#ifndef FFN_ABL_NO_DMA  // (diagnostic builds: tools/ffn_stamps.hip)
             if (s + 1 <= NHT) {  // stage s+1 = [ W1(s+2) | W2(s) ] -> slot (s+1)&1; this wave moves pieces 6 tl .. 6 tl + 5 of each half
                 const int j = s + 1;
                 const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)((j & 1) * FFN_STAGE_BYTES + (tl * 6) * 1024));
-                if (j + 1 < NHT) {
+                if (j + 1 < NHT) {  // W1(s + 2): the pieces the A wave of this tile leaves
                     const uint4 *src = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (j + 1)) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) enc_glds16(src + i * 64, dst + i * 1024);
+                    for (int i = FFN_A_PIECES; i < 6; ++i) enc_glds16(src + i * 64, dst + i * 1024);
                 }
                 {
                     const uint4 *src = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (j - 1) + 1) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
@@ -122,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
                     for (int i = 0; i < 6; ++i) enc_glds16(src + i * 64, dst + FFN_HALF_BYTES + i * 1024);
                 }
             }
+#endif
             if (s >= 1) {
                 const uint4 *st = reinterpret_cast<const uint4 *>(smem + (size_t)(s & 1) * FFN_STAGE_BYTES + FFN_HALF_BYTES) + lane;  // W2(s-1)
                 const uint4 *hi = hb + ((size_t)(((s - 1) & 1) * 4 + tl) * 2) * 64 + lane;
@@ -139,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s+1 have landed before the barrier publishes them
             if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2 + 1] = __builtin_amdgcn_s_memtime();
         }
-        residual_ln_store(y, act_in + (size_t)tt * (NFB * 2 * 64), prm + FF, prm + FF + H, prm + FF + 2 * H,
+        residual_ln_store<true, true>(y, act_in + (size_t)tt * (NFB * 2 * 64), prm + FF, prm + FF + H, prm + FF + 2 * H,
                           act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
     }
 }

@@ -370,19 +370,28 @@ __global__ __launch_bounds__(64) MIR_ONE_WAVE void ffn1_small_kernel(const uint4
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) bq[gq] = *reinterpret_cast<const float4 *>(b1 + 32 * ht + 8 * gq + 4 * h);
     __builtin_amdgcn_sched_barrier(0);
-    f32x16 acc = {0};
-#pragma unroll
-    for (int ks = 0; ks < KS_H; ++ks) acc = mfma(w[ks], x[ks], acc);
-    float g[16];
+    // as in ffn_ln_kernel: the accumulator starts from the bias, GELU by the table behind the parameters (read from L2 here)
+    f32x16 acc;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-        const float bb[4] = {bq[gq].x, bq[gq].y, bq[gq].z, bq[gq].w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[4 * gq + i] = gelu(acc[4 * gq + i] + bb[i]);
+        acc[4 * gq + 0] = bq[gq].x; acc[4 * gq + 1] = bq[gq].y; acc[4 * gq + 2] = bq[gq].z; acc[4 * gq + 3] = bq[gq].w;
     }
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) acc = mfma(w[ks], x[ks], acc);
+    const unsigned char *lut = reinterpret_cast<const unsigned char *>(b1 + FFN_PARAM_FLOATS);
+    uint32_t off[16], hw[8];
+    float xc[16];
+    f32x2 e[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        off[r] = gelu_lut_addr(acc[r], xc[r], 0u);
+        e[r] = *reinterpret_cast<const f32x2 *>(lut + off[r]);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) hw[p] = gelu_pack2(acc[2 * p], xc[2 * p], e[2 * p], acc[2 * p + 1], xc[2 * p + 1], e[2 * p + 1]);
     uint4 *ho = hbuf + ((size_t)tt * (2 * NHT) + 2 * ht) * 64 + lane;
-    ho[0] = make_uint4(pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7]));
-    ho[64] = make_uint4(pack2(g[8], g[9]), pack2(g[10], g[11]), pack2(g[12], g[13]), pack2(g[14], g[15]));
+    ho[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+    ho[64] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
 }
 
 __global__ __launch_bounds__(64) MIR_ONE_WAVE void ffn2_small_kernel(const uint4 *__restrict__ hbuf,

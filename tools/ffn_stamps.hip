@@ -17,7 +17,8 @@ int main(int argc, char **argv) {
     std::vector<_Float16> hact(act_bytes / 2), hw(w_bytes / 2);
     for (auto &v : hact) v = (_Float16)((rand() % 2001 - 1000) / 1000.0f);
     for (auto &v : hw) v = (_Float16)((rand() % 2001 - 1000) / 20000.0f);
-    std::vector<float> hp(FFN_PARAM_FLOATS, 0.01f);
+    std::vector<float> hp(FFN_PARAM_FLOATS + GELU_LUT_FLOATS, 0.01f);
+    gelu_table(hp.data() + FFN_PARAM_FLOATS);
     for (int i = FF + H; i < FF + 2 * H; ++i) hp[i] = 1.0f;
     void *act, *out, *w, *p; unsigned long long *st;
     CK(hipMalloc(&act, act_bytes)); CK(hipMalloc(&out, act_bytes)); CK(hipMalloc(&w, w_bytes)); CK(hipMalloc(&p, hp.size() * 4));
