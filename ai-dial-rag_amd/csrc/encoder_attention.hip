@@ -17,64 +17,92 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict_
                                                         const TileInfo *__restrict__ ti, int n_tiles,
                                                         uint4 *__restrict__ ctx) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= n_tiles * NH) return;
+    // Workgroups go to the 8 XCDs round-robin (blockIdx & 7), each with its own L2.  Every query tile of a sequence reads
+    // the sequence's K/V of its head, so the tiles of one (head, sequence) must meet in ONE L2: XCD x takes the x-th
+    // eighth of the (head, tile) list instead of every eighth entry.  (Counters, tools/run_enc_pmc.sh: with the plain
+    // mapping 73 % of the kernel's L2 requests missed and it pulled 0.53 GB per 2888-tile pass through the fabric -
+    // ~5 TB/s: the kernel's whole time - where Q + K + V are 0.21 GB.)
+    const int n_wg = gridDim.x, per_xcd = (n_wg + 7) >> 3;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int w = wg * 4 + (threadIdx.x >> 6);
+    if ((blockIdx.x >> 3) >= per_xcd || w >= n_tiles * NH) return;
     const int head = w / n_tiles, tt = w - head * n_tiles;   // neighbours share a sequence's K/V of one head
     const TileInfo info = ti[tt];
     // Q arrives pre-multiplied by log2(e) / sqrt(32) (qkv kernels): the scores are exp2 arguments as they leave the MFMA
     const uint4 *qp = qf + ((size_t)(tt * NH + head) * 2) * 64 + lane;
     const uint4 q0 = qp[0], q1 = qp[64];
-    typedef float __attribute__((ext_vector_type(2))) f32x2;
-    f32x16 o = {0};
-    float m = -__builtin_inff(), l = 0.f;
-    for (int kt = 0; kt < info.seq_tiles; ++kt) {
-        const size_t kb = ((size_t)((info.seq_first_tile + kt) * NH + head) * 2) * 64 + lane;
-        const uint4 k0 = kf[kb], k1 = kf[kb + 64];
-        const uint4 v0 = vf[kb], v1 = vf[kb + 64];
-        f32x16 s = {0};
-        s = mfma(k0, q0, s);
-        s = mfma(k1, q1, s);
-        if (kt == info.seq_tiles - 1) {  // only the sequence's last key tile can hold padding
+    const int n_kt = __builtin_amdgcn_readfirstlane(info.seq_tiles);  // a tile's bookkeeping is wave-uniform: scalar loop control
+    const int seq_len = __builtin_amdgcn_readfirstlane(info.seq_len);
+    const size_t kv0 = ((size_t)(__builtin_amdgcn_readfirstlane(info.seq_first_tile) * NH + head) * 2) * 64 + lane;
+
+    // Online softmax with a LAZY reference: a query's scores are taken relative to a reference value ref (exp2 arguments
+    // s - ref), which moves only when some score exceeds it by more than kSlack (or on the first key tile, to that tile's
+    // maximum).  The usual running maximum moves for SOME of a wave's 32 queries on nearly every tile, and every move costs
+    // the wave the rescale of its accumulators; here the steady state of a tile is the score MFMAs, a max tree, one
+    // vote, 16 v_exp, 8 packed converts and the output MFMAs:
+    //   * -ref sits in a 16-register tile that is the C operand of the score MFMA: no per-score subtraction;
+    //   * the row sums come from the matrix pipe (ones x P^T into a second accumulator): no adds, no cross-half shuffle;
+    //   * P stays <= 2^kSlack: float16 holds it with the same relative precision as values <= 1.
+    // (~110 -> ~50 VALU instructions per key tile, tools/run_enc_pmc.sh.)
+    constexpr float kSlack = 6.0f;
+    f32x16 o = {0}, lsum = {0}, nref = {0};  // lsum: every register holds the lane's query's running sum
+    const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
+
+    // one key tile: S^T = K Q^T - ref, P = exp2, O^T += V^T P^T, lsum += 1 P^T
+    auto step = [&](int kt, const uint4 &kc0, const uint4 &kc1, const uint4 &vc0, const uint4 &vc1) {
+        f32x16 s = mfma(kc0, q0, nref);
+        s = mfma(kc1, q1, s);
+        if (kt == n_kt - 1) {  // only the sequence's last key tile can hold padding
             const int key0 = 32 * kt;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = (key0 + fi(r, h) < info.seq_len) ? s[r] : -__builtin_inff();
+            for (int r = 0; r < 16; ++r) s[r] = (key0 + fi(r, h) < seq_len) ? s[r] : -__builtin_inff();
         }
         const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]), a2 = fmaxf(fmaxf(s[6], s[7]), s[8]);
         const float a3 = fmaxf(fmaxf(s[9], s[10]), s[11]), a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
-        const float mx = half_max(fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(a4, s[15])));
-        const float m_new = fmaxf(m, mx);
-        // v_exp_f32 directly: exp2f() wraps it in a compare / select / ldexp to keep results below
-        // 2^-126 exact, ~4 extra instructions per value in a VALU-bound loop; a softmax term that small
-        // is zero next to the row's maximum term 1.0 either way.  Subtraction and sum two values per instruction
-        // (v_pk_add_f32): the loop is VALU-bound 4:1 against its MFMAs.
-        const f32x2 nm = {-m_new, -m_new};
-        f32x2 ps2 = {0.f, 0.f};
+        const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(a4, s[15]));  // this lane's half of the keys
+        if (kt == 0 || __any(mx > kSlack)) {  // wave-uniform; rare after the first tile
+            const float mq = half_max(mx);
+            const float delta = kt == 0 ? mq : fmaxf(mq, 0.f);  // the reference only rises after the first tile
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            f32x2 d = f32x2{s[r], s[r + 1]} + nm;
-            d.x = __builtin_amdgcn_exp2f(d.x);
-            d.y = __builtin_amdgcn_exp2f(d.y);
-            s[r] = d.x;
-            s[r + 1] = d.y;
-            ps2 += d;
+            for (int r = 0; r < 16; ++r) {
+                s[r] -= delta;
+                nref[r] -= delta;
+                o[r] *= alpha;
+                lsum[r] *= alpha;
+            }
         }
-        const float ps = half_sum(ps2.x + ps2.y);
-        if (__any(m_new > m)) {  // some query's running maximum moved: rescale (wave-uniform branch)
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);  // exp2(-inf) = 0 on the first tile
-            l = fmaf(l, alpha, ps);
+        // v_exp_f32 directly: exp2f() wraps it in a compare / select / ldexp to keep results below 2^-126 exact, ~4 extra
+        // instructions per value; a softmax term that small is zero next to the row's largest term either way
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] *= alpha;
-        } else {
-            l += ps;
-        }
-        m = m_new;
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
         // P to float16 with the packed convert (two values per instruction; the scalar casts cost three)
         const uint4 p0 = make_uint4(pack2_rn(s[0], s[1]), pack2_rn(s[2], s[3]), pack2_rn(s[4], s[5]), pack2_rn(s[6], s[7]));
         const uint4 p1 = make_uint4(pack2_rn(s[8], s[9]), pack2_rn(s[10], s[11]), pack2_rn(s[12], s[13]), pack2_rn(s[14], s[15]));
-        o = mfma(v0, p0, o);
-        o = mfma(v1, p1, o);
+        o = mfma(vc0, p0, o);
+        lsum = mfma(ones, p0, lsum);
+        o = mfma(vc1, p1, o);
+        lsum = mfma(ones, p1, lsum);
+    };
+    // Two key tiles per trip, each in its own registers: a tile's K/V are requested one step ahead.  vmcnt counts in
+    // order, so the wait for the older buffer leaves the younger one's loads in flight.  (The requests are unconditional -
+    // past the end they re-read the last tile: behind a branch that may or may not have issued loads, hipcc waits for
+    // vmcnt(0).)
+    auto load = [&](int kt, uint4 &k0, uint4 &k1, uint4 &v0, uint4 &v1) {
+        const size_t kb = kv0 + (size_t)kt * (NH * 2 * 64);
+        k0 = kf[kb]; k1 = kf[kb + 64]; v0 = vf[kb]; v1 = vf[kb + 64];
+    };
+    uint4 ka0, ka1, va0, va1, kb0, kb1, vb0, vb1;
+    load(0, ka0, ka1, va0, va1);
+    for (int kt = 0; kt < n_kt; kt += 2) {
+        load(min(kt + 1, n_kt - 1), kb0, kb1, vb0, vb1);
+        step(kt, ka0, ka1, va0, va1);
+        if (kt + 1 < n_kt) {
+            load(min(kt + 2, n_kt - 1), ka0, ka1, va0, va1);
+            step(kt + 1, kb0, kb1, vb0, vb1);
+        }
     }
-    const float inv = 1.0f / l;
+    const float inv = 1.0f / lsum[0];
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] *= inv;
     uint4 *out = ctx + (size_t)tt * (NFB * 2 * 64) + (size_t)(head * 2) * 64 + lane;
@@ -85,7 +113,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict_
 
 int32_t launch_attention(const uint4 *qf, const uint4 *kf, const uint4 *vf, const TileInfo *ti, int n_tiles,
                          uint4 *ctx, hipStream_t stream) {
-    attention_kernel<<<dim3((n_tiles * NH + 3) / 4), dim3(256), 0, stream>>>(qf, kf, vf, ti, n_tiles, ctx);
+    const int n_wg = (n_tiles * NH + 3) / 4;
+    attention_kernel<<<dim3((n_wg + 7) / 8 * 8), dim3(256), 0, stream>>>(qf, kf, vf, ti, n_tiles, ctx);  // a multiple of 8: see the XCD mapping
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }

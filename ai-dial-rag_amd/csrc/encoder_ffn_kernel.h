@@ -163,22 +163,20 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
         for (int s = 0; s <= NHT; ++s) {
             __syncthreads();
             if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2] = __builtin_amdgcn_s_memtime();
+            // stage s+1 = [ W1(s+2) | W2(s) ] -> slot (s+1)&1.  This wave moves pieces 6 tl + FFN_A_PIECES .. 6 tl + 5 of the W1 half
+            // (the A wave of the tile moves the first FFN_A_PIECES) and pieces 6 tl .. 6 tl + 5 of the W2 half, ONE PER MFMA of
+            // its product: issued in a burst at the top of the stage they held this wave for ~100 cycles each before its first MFMA.
+            const int j = s + 1;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)((j & 1) * FFN_STAGE_BYTES + (tl * 6) * 1024));
+            const uint4 *src1 = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (j + 1)) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
+            const uint4 *src2 = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (j - 1) + 1) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
+            const bool dma2 = s + 1 <= NHT, dma1 = dma2 && j + 1 < NHT;
+            auto piece = [&](int i) {  // i = 0 .. 11 - FFN_A_PIECES
 #ifndef FFN_ABL_NO_DMA  // (diagnostic builds: tools/ffn_stamps.hip)
-            if (s + 1 <= NHT) {  // stage s+1 = [ W1(s+2) | W2(s) ] -> slot (s+1)&1; this wave moves pieces 6 tl .. 6 tl + 5 of each half
-                const int j = s + 1;
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)((j & 1) * FFN_STAGE_BYTES + (tl * 6) * 1024));
-                if (j + 1 < NHT) {  // W1(s + 2): the pieces the A wave of this tile leaves
-                    const uint4 *src = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (j + 1)) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
-#pragma unroll
-                    for (int i = FFN_A_PIECES; i < 6; ++i) enc_glds16(src + i * 64, dst + i * 1024);
-                }
-                {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * (j - 1) + 1) * FFN_HALF_BYTES) + (size_t)(tl * 6) * 64 + lane;
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) enc_glds16(src + i * 64, dst + FFN_HALF_BYTES + i * 1024);
-                }
-            }
+                if (i < 6) { if (dma2) enc_glds16(src2 + i * 64, dst + FFN_HALF_BYTES + i * 1024); }
+                else if (i < 12 - FFN_A_PIECES) { if (dma1) enc_glds16(src1 + (i - 6 + FFN_A_PIECES) * 64, dst + (i - 6 + FFN_A_PIECES) * 1024); }
 #endif
+            };
             if (s >= 1) {
                 const uint4 *st = reinterpret_cast<const uint4 *>(smem + (size_t)(s & 1) * FFN_STAGE_BYTES + FFN_HALF_BYTES) + lane;  // W2(s-1)
                 const uint4 *hi = hb + ((size_t)(((s - 1) & 1) * 4 + tl) * 2) * 64 + lane;
@@ -189,9 +187,13 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
 #pragma unroll
                 for (int i = 0; i < 24; ++i) {
                     if (i + FFN_RING - 1 < 24) fr[(i + FFN_RING - 1) % FFN_RING] = st[(i + FFN_RING - 1) * 64];
+                    if (i < 12) piece(i);
                     __builtin_amdgcn_sched_barrier(0);
                     y[i >> 1] = mfma(fr[i % FFN_RING], (i & 1) ? h1 : h0, y[i >> 1]);
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) piece(i);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s+1 have landed before the barrier publishes them
             if (STAMPS && blockIdx.x == 0 && lane == 0) stamps[(wave * (NHT + 1) + s) * 2 + 1] = __builtin_amdgcn_s_memtime();
