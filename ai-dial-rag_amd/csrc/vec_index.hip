@@ -675,7 +675,11 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
         pl->qpw = kQ16Queries;
         pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
         pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), (int64_t)ix->n_tiles));
-        if ((int64_t)ix->n_tiles >= 64 * (int64_t)pl->nwg) {  // >= 64 tiles per workgroup: scan 1/16 first, re-seed, scan the rest
+        static const int64_t min_tiles_per_wg = []() {  // tuning knob (tools/): MIR_PROGRESSIVE_MIN_TILES
+            const char *e = getenv("MIR_PROGRESSIVE_MIN_TILES");
+            return (int64_t)(e && atoi(e) > 0 ? atoi(e) : 64);
+        }();
+        if ((int64_t)ix->n_tiles >= min_tiles_per_wg * (int64_t)pl->nwg) {  // many tiles per workgroup: scan 1/16 first, re-seed, scan the rest
             pl->tiles_first = ix->n_tiles / 16;
             pl->nwg_first = pl->nwg;
             pl->nwg = 2 * pl->nwg;  // lists for finalize
