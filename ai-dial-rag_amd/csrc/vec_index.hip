@@ -14,6 +14,7 @@
 #include "vec_kernels.h"
 #include "vec_kernels_f16.h"
 #include "vec_kernels_q16.h"
+#include "vec_kernels_h16.h"
 
 namespace mir {
 
@@ -187,8 +188,8 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
         const int64_t blocks = (total_lanes + 255) / 256;
         MIR_REQUIRE(blocks < (int64_t)0x7fffffff, "index too large for one pack launch");
         if (ix->native16) {
-            pack_f16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(ix->d_f16, n, d, ix->ksteps, total_lanes,
-                                                                            ix->d_split);
+            pack_f16_16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(ix->d_f16, n, d, ix->ksteps / 2, total_lanes,
+                                                                               ix->d_split);  // a tile: ksteps blocks of 1 KiB
             MIR_HIP(hipGetLastError());
             launch_row_norms(ix->d_f16, n, d, ix, stream);
         } else if (ix->layout16) {
@@ -436,22 +437,39 @@ static int32_t launch_scan_q16(const mir_index *ix, const uint4 *qsplit_g, const
     return MIR_OK;
 }
 
-// float16-native scan: 64 queries per launch
+// float16-native scan: 128 queries per launch, 16 per wave, one float16 product per fragment (vec_kernels_h16.h)
+template <int KIND>
+static int32_t launch_scan_h16(const mir_index *ix, const uint4 *qfrag_g, const float *qscale_g, int nq, int klist, int nwg,
+                               uint32_t tile0, uint32_t n_tiles, uint64_t *part_g, uint64_t *gthr_g, bool sample, hipStream_t stream) {
+    const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
+    const size_t lds = h16_lds_bytes(klist);
+    const uint32_t n_rows = (uint32_t)ix->n;
+    const int ns = h16_ring_stages(klist);
+#define MIR_H16_LAUNCH(KS, NSV)                                                                                        \
+    do {                                                                                                               \
+        auto kern = sample ? scan_topk_h16_kernel<KS, KIND, true, NSV> : scan_topk_h16_kernel<KS, KIND, false, NSV>;   \
+        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qfrag_g, qscale_g, n_rows, tile0, n_tiles, nq, klist, part_g, \
+                                                    gthr_g);                                                           \
+    } while (0)
+    if (ix->ksteps != 64) {  // 512 < d <= 1024: 32 k-steps of 32 columns (128 VGPRs of query fragments per wave)
+        set_error("internal: float16 scan has no instance for %d k-steps", ix->ksteps);
+        return MIR_ERR_UNSUPPORTED;
+    }
+    if (ns == 4) MIR_H16_LAUNCH(32, 4);
+    else MIR_H16_LAUNCH(32, 3);
+#undef MIR_H16_LAUNCH
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
+// float32 rows with 384 < d <= 1024: the 64-query K-split scan over the bf16 hi/lo image
 template <int KIND>
 static int32_t launch_scan_f16(const mir_index *ix, const uint4 *qfrag_g, const float *qscale_g, int nq, int klist, int nwg,
                                uint32_t n_tiles, uint64_t *part_g, uint64_t *gthr_g, bool sample, hipStream_t stream) {
     const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
     const size_t lds = f16_lds_bytes(klist);
     const uint32_t n_rows = (uint32_t)ix->n;
-#define MIR_SCAN_CASE(KS)                                                                                    \
-    case KS: {                                                                                               \
-        auto kern = sample ? scan_topk_f16_kernel<KS, KIND, true> : scan_topk_f16_kernel<KS, KIND, false>;   \
-        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qfrag_g, qscale_g, n_rows, n_tiles,    \
-                                                    nq, klist, part_g, gthr_g);                              \
-        break;                                                                                               \
-    }
 #define MIR_SCAN_CASE_SPLIT(KS)                                                                              \
     case KS: {                                                                                               \
         auto kern = sample ? scan_topk_f16_kernel<KS, KIND, true, true> : scan_topk_f16_kernel<KS, KIND, false, true>; \
@@ -461,26 +479,15 @@ static int32_t launch_scan_f16(const mir_index *ix, const uint4 *qfrag_g, const 
                                                     nq, klist, part_g, gthr_g);                              \
         break;                                                                                               \
     }
-    if (!ix->native16) {  // float32 index, 384 < d <= 1024: the same kernel over the bf16 hi/lo image
-        switch (ix->ksteps) {
-            MIR_SCAN_CASE_SPLIT(32)
-            MIR_SCAN_CASE_SPLIT(48)
-            MIR_SCAN_CASE_SPLIT(64)
-            default:
-                set_error("internal: wide split scan has no instance for %d k-steps", ix->ksteps);
-                return MIR_ERR_UNSUPPORTED;
-        }
-        MIR_HIP(hipGetLastError());
-        return MIR_OK;
-    }
     switch (ix->ksteps) {
-        MIR_SCAN_CASE(64)  // 96 / 128 k-steps would need 192 / 256 VGPRs of query fragments per wave: they spill
+        MIR_SCAN_CASE_SPLIT(32)
+        MIR_SCAN_CASE_SPLIT(48)
+        MIR_SCAN_CASE_SPLIT(64)
         default:
-            set_error("internal: float16 scan has no instance for %d k-steps", ix->ksteps);
+            set_error("internal: wide split scan has no instance for %d k-steps", ix->ksteps);
             return MIR_ERR_UNSUPPORTED;
     }
 #undef MIR_SCAN_CASE_SPLIT
-#undef MIR_SCAN_CASE
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }
@@ -534,10 +541,11 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (kQ16Queries / 16);
         prep_queries16_kernel<<<dim3(std::max(ntiles16 * ks32 + b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(
             dq, b, d, ks32, ntiles16, sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords);
-    } else if (ix->native16)
-        prep_queries_f16_kernel<<<dim3(prep_blocks), dim3(64), 0, stream>>>(
-            dq, b, d, ix->ksteps, ntiles32, sb.qsplit, sb.q_sq, sb.q_norm, sb.qscale, gz, gwords);
-    else
+    } else if (ix->native16) {
+        const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (kQ16Queries / 16);
+        query_stats_h16_kernel<<<dim3(std::max(b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(dq, b, d, sb.q_sq, sb.q_norm, sb.qscale, gz, gwords);
+        prep_queries_h16_kernel<<<dim3(ntiles16 * ks32), dim3(64), 0, stream>>>(dq, b, d, ks32, sb.qscale, sb.qsplit);
+    } else
         prep_queries_kernel<<<dim3(prep_blocks), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, ntiles32,
                                                                                     sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords);
     MIR_HIP(hipGetLastError());
@@ -567,9 +575,15 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             uint64_t *gt = sb.gthr + (size_t)g * 128;
             const float *qsc = sb.qscale + (size_t)g * qpw;
             auto run = [&](int wgs, uint32_t tiles, uint64_t *out, bool sample) {
-                if (ix->layout16) {
+                if (ix->layout16 || ix->native16) {
                     const double *qn = sb.q_norm + (size_t)g * qpw;
+                    const uint4 *qs16 = sb.qsplit + (size_t)g * (kQ16Queries / 16) * (ix->ksteps / 2) * 64;  // native16: hi fragments only
                     auto one = [&](int w, uint32_t t0, uint32_t nt, uint64_t *o, bool smp) {
+                        if (ix->native16) {
+                            if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_h16<SCAN_IP>(ix, qs16, qsc, nq, klist, w, t0, nt, o, gt, smp, stream);
+                            if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_h16<SCAN_COS>(ix, qs16, qsc, nq, klist, w, t0, nt, o, gt, smp, stream);
+                            return launch_scan_h16<SCAN_L2>(ix, qs16, qsc, nq, klist, w, t0, nt, o, gt, smp, stream);
+                        }
                         if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_q16<SCAN_IP>(ix, qs, qn, nq, klist, w, t0, nt, o, gt, smp, stream);
                         if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_q16<SCAN_COS>(ix, qs, qn, nq, klist, w, t0, nt, o, gt, smp, stream);
                         return launch_scan_q16<SCAN_L2>(ix, qs, qn, nq, klist, w, t0, nt, o, gt, smp, stream);
@@ -584,7 +598,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                                                                              reinterpret_cast<unsigned long long *>(gt));
                     return one(wgs - pl.nwg_first, pl.tiles_first, tiles - pl.tiles_first, out + (size_t)pl.nwg_first * qpw * klist, false);
                 }
-                if (ix->native16 || wide64_split(ix)) {
+                if (wide64_split(ix)) {
                     if (metric == MIR_METRIC_INNER_PRODUCT) return launch_scan_f16<SCAN_IP>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
                     if (metric == MIR_METRIC_COSINE_SIM) return launch_scan_f16<SCAN_COS>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
                     return launch_scan_f16<SCAN_L2>(ix, qs, qsc, nq, klist, wgs, tiles, out, gt, sample, stream);
@@ -629,6 +643,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     FinalizeArgs fa;
     fa.part = sb.part; fa.nwg = nwg; fa.qpw = qpw; fa.klist = klist; fa.k = k; fa.b = b; fa.d = d; fa.metric = metric;
     fa.docs = ix->d_orig; fa.docs16 = ix->d_f16; fa.doc_sq = ix->d_docsq; fa.max_norm = ix->d_maxnorm;
+    fa.scan_rel_err = ix->native16 ? kH16RelErr : kScanRelErr;  // the bound of the scan whose values the lists hold
     fa.q = dq; fa.q_sq = sb.q_sq; fa.q_norm = sb.q_norm;
     fa.chunk_ids = ix->d_chunk; fa.doc_ids = ix->d_doc; fa.row_offset = ix->row_offset;
     fa.out_doc = o_doc; fa.out_chunk = o_chunk; fa.out_row = o_row; fa.out_dist = o_dist;
@@ -648,9 +663,9 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
     pl->klist = std::min(k + kListMargin, kMaxList);
     // The reference takes any `limit` (embeddings_index.py:58,81).  Beyond what the filter's per-lane candidate
     // lists hold (LDS), an index that could actually return that many rows is searched by the exact pass alone.
-    const bool wide64 = ix->native16 || wide64_split(ix);
-    const bool lists_fit = k + kListMargin <= kMaxList && (!ix->native16 || f16_lds_bytes(pl->klist) <= 160 * 1024);
-    if (!lists_fit && (ix->native16 || ix->n > (int64_t)kMaxList)) {  // (float32, n <= 64: every row fits the lists)
+    const bool wide64 = wide64_split(ix);
+    const bool lists_fit = k + kListMargin <= kMaxList;
+    if (!lists_fit && ix->n > (int64_t)kMaxList) {  // (n <= 64: every row fits the lists)
         pl->exact_only = true;
         pl->ngroups = 0;
         pl->qpw = 32;
@@ -664,14 +679,14 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
         pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want16));
         return MIR_OK;
     }
-    if (ix->layout16 && pl->klist > kQ16MaxList) {  // k > 52 on a layout16 index: the exact pass alone (any n)
+    if ((ix->layout16 || ix->native16) && pl->klist > kQ16MaxList) {  // k > 52 on a 16-queries-per-wave index: the exact pass alone (any n)
         pl->exact_only = true;
         pl->ngroups = 0;
         pl->qpw = 32;
         pl->nwg = 1;
         return MIR_OK;
     }
-    if (ix->layout16) {  // the image only the 16-queries-per-wave kernel reads: it takes every k its buffers hold (k <= 52)
+    if (ix->layout16 || ix->native16) {  // the images only the 16-queries-per-wave kernels read: they take every k their buffers hold (k <= 52)
         pl->qpw = kQ16Queries;
         pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
         pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), (int64_t)ix->n_tiles));

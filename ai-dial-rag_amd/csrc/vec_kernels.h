@@ -816,6 +816,7 @@ struct FinalizeArgs {
     const _Float16 *docs16; // f16 [n][d] (float16-native index)
     const float *doc_sq;    // f32 [n]
     const float *max_norm;  // 1 float
+    double scan_rel_err;    // bound on |list value's dot - exact dot| / (|d||q|): kScanRelErr, or the hi-only float16 scan's
     const double *q;        // [b][d]
     const double *q_sq;     // [b]
     const double *q_norm;   // [b]
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
             const double tau = (double)key_value(keys[klist - 1]);
             const double qn = a.q_norm[qi];
             const double mx = (double)a.max_norm[0];
-            double eps = kScanRelErr * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0 : mx);
+            double eps = a.scan_rel_err * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0 : mx);
             if (a.metric == MIR_METRIC_SQEUCLIDEAN_DIST || a.metric == MIR_METRIC_EUCLIDEAN_DIST) eps *= 2.0;
             eps += 1e-6 * fabs(tau);
             const double vk = s_vk;

@@ -1,107 +1,15 @@
-// Device code of the float16-NATIVE vector index (BASELINE config C5: multimodal vectors,
-// d = 1024, float16 storage; `multimodal_retriever.py:96-153` passes `metric=index_config.metric`).
-//
-// A float16 index with 512 < d <= 1024 keeps the rows as they are (2 B per element; the fragment copy is
-// zero-padded to 1024 columns) in
-// fragment-major order and scans them with ONE pass of 2-byte data and TWO f16 MFMAs per k-step:
-//     dot(d, q) ~= d . q_hi + d . q_lo,   q_hi = f16(s q), q_lo = f16(s q - q_hi),
-// s a per-query power of two that puts max |q_i| near 2^7, so both parts are normal float16
-// numbers.  The documents are exact (they ARE float16); the query is reproduced to ~2^-22 and
-// the products accumulate in float32, which is well inside the scan's error bound kScanRelErr
-// (the bound of the bf16x3 path, kept: the completeness check stays valid, only looser than needed).
-// The generic path would widen such an index to float32 and split it into bf16 hi + lo: 4 B per
-// element scanned, another 4 B for the re-scoring copy, and at d > 384 only 32 queries per pass.
-//
-// Layout: [tile of 32 rows][k-step][64 lanes][8 f16]: lane l holds row (l & 31), columns
-// 16 ks + 8 (l >> 5) .. +7 - the A fragment of v_mfma_f32_32x32x16_f16; 1 KiB per (tile, k-step).
+// The 64-query K-split scan (round 1's float16-native kernel).  Since round 2 the float16-NATIVE index (BASELINE config
+// C5) is scanned by vec_kernels_h16.h; what still runs here is the SPLIT = true instantiation: float32 rows with
+// 384 < d <= 1024 (the multimodal / description retrievers' page embeddings) over their bf16 hi/lo image, three bf16
+// MFMAs per k-step, K split over four waves per 32-query tile.  The SPLIT = false form (one 2-byte fragment stream, two
+// f16 MFMAs per k-step for the query's hi and lo parts) is kept as the description of that layout:
+// [tile of 32 rows][k-step][64 lanes][8 f16], lane l = row (l & 31), columns 16 ks + 8 (l >> 5) .. +7.
 #pragma once
 #include "vec_kernels.h"
 
 namespace mir {
 
 typedef _Float16 __attribute__((ext_vector_type(8))) f16x8;
-
-// f16 [n][d] row-major -> fragment-major.  One thread per (tile, k-step, lane).  ksteps*16 >= d;
-// columns past d and rows past n are 0.
-__global__ __launch_bounds__(256) void pack_f16_kernel(const _Float16 *__restrict__ src, int64_t n, int d, int ksteps,
-                                                       int64_t total_lanes, uint4 *__restrict__ dst) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total_lanes) return;
-    const int lane = (int)(gid & 63);
-    const int64_t blk = gid >> 6;
-    const int s = (int)(blk % ksteps);
-    const int64_t tile = blk / ksteps;
-    const int64_t row = tile * kTileRows + (lane & 31);
-    const int col0 = 16 * s + 8 * (lane >> 5);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < n && col0 + 8 <= d && (d & 7) == 0) {
-        v = *reinterpret_cast<const uint4 *>(src + row * (int64_t)d + col0);
-    } else if (row < n) {
-        uint32_t hbits[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            hbits[j] = col0 + j < d ? (uint32_t)__builtin_bit_cast(uint16_t, src[row * (int64_t)d + col0 + j]) : 0u;
-        v = pack8(hbits);
-    }
-    dst[blk * 64 + lane] = v;
-}
-
-// Blocks [0, ntiles32*ksteps): B-operand fragments (hi, lo) of query tile g, k-step s.
-// Blocks [ntiles32*ksteps, +b): per-query sum of squares / norm (float64) and the scale.
-// qscale_inv[q] = 1 / s.
-__global__ __launch_bounds__(64) void prep_queries_f16_kernel(const double *__restrict__ q, int b, int d, int ksteps,
-                                                              int ntiles32, uint4 *__restrict__ qfrag,
-                                                              double *__restrict__ q_sq, double *__restrict__ q_norm,
-                                                              float *__restrict__ qscale_inv,
-                                                              unsigned long long *__restrict__ gthr, int gthr_words) {
-    const int lane = threadIdx.x;
-    const int blk = blockIdx.x;
-    if (gthr && blk * 64 + lane < gthr_words) gthr[blk * 64 + lane] = 0;  // as prep_queries_kernel
-    auto scale_of = [&](int qi) {  // wave-uniform per query only in the second block kind; recomputed per lane here
-        double m = 0.0;
-        for (int j = 0; j < d; ++j) {
-            const double x = fabs(q[(int64_t)qi * d + j]);
-            m = (x == x && x > m) ? x : m;
-        }
-        if (!(m > 0.0) || m > 1e300) return 1.0;
-        int e;
-        frexp(m, &e);               // m = f * 2^e, f in [0.5, 1)
-        return ldexp(1.0, 8 - e);   // s*m in [128, 256)
-    };
-    if (blk < ntiles32 * ksteps) {
-        const int s = blk % ksteps;
-        const int g = blk / ksteps;
-        const int qi = 32 * g + (lane & 31);
-        const int col0 = 16 * s + 8 * (lane >> 5);
-        uint32_t hi[8], lo[8];
-        const double sc = qi < b ? scale_of(qi) : 1.0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = (qi < b && col0 + j < d) ? (float)(q[(int64_t)qi * d + col0 + j] * sc) : 0.f;
-            const _Float16 h = (_Float16)x;
-            const float hf = (float)h;
-            const _Float16 l = (hf == hf && fabsf(hf) < 1e30f) ? (_Float16)(x - hf) : (_Float16)0.f;
-            hi[j] = __builtin_bit_cast(uint16_t, h);
-            lo[j] = __builtin_bit_cast(uint16_t, l);
-        }
-        qfrag[((int64_t)blk * 2 + 0) * 64 + lane] = pack8(hi);
-        qfrag[((int64_t)blk * 2 + 1) * 64 + lane] = pack8(lo);
-    } else {
-        const int qi = blk - ntiles32 * ksteps;
-        if (qi >= b) return;
-        double s = 0.0;
-        for (int j = lane; j < d; j += 64) {
-            const double x = q[(int64_t)qi * d + j];
-            s += x * x;
-        }
-        s = wave_sum(s);
-        if (lane == 0) {
-            q_sq[qi] = s;
-            q_norm[qi] = sqrt(s);
-            qscale_inv[qi] = (float)(1.0 / scale_of(qi));
-        }
-    }
-}
 
 // 64-query scan geometry
 constexpr int kF16Queries = 64;

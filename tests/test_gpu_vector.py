@@ -223,8 +223,8 @@ def test_batches_larger_than_a_query_group(amd):
 
 @pytest.mark.parametrize("metric", ["sqeuclidean_dist", "cosine_sim", "inner_product"])
 def test_large_shard_wide_scan_with_sample_thresholds(amd, metric):
-    """1.2M rows x 128 queries: the 128-query K-split scan including its sample pre-pass (only taken for
-    shards of >= 32768 tiles).  Oracle on 6 queries (the CPU path costs ~1 s per query here); planted
+    """1.2M rows x 128 queries: the 128-query scan (16 queries per wave) with its sample pre-pass and the two-launch
+    progressive thresholds (shards of >= 64 tiles per workgroup).  Oracle on 6 queries (the CPU path costs ~1 s per query here); planted
     duplicates must resolve to the lower row; every flag must be clear; repeated runs must agree bit for bit
     (the scan has inter-wave hand-offs: a race would show up as run-to-run differences)."""
     from oracle import embeddings_index as oi
@@ -285,9 +285,10 @@ def test_float16_storage_d1024_multimodal_shape(amd, metric):
 
 @pytest.mark.parametrize("metric", ["inner_product", "euclidean_dist", "sqeuclidean_dist", "cosine_sim"])
 def test_float16_native_scan_shapes(amd, metric):
-    """The float16-native path (d = 1024 kept as 2-byte fragments, 64 queries per pass): a ragged last
-    tile, batches of 1 / 33 / 64 / 100 queries (one and two passes, one and two query tiles), duplicates
-    across the tile boundary, queries of very different magnitude (per-query power-of-two scaling)."""
+    """The float16-native path (d = 1024 kept as 2-byte fragments, 128 queries per pass, 16 per wave, one float16 product
+    per fragment - vec_kernels_h16.h): a ragged last tile, batches of 1 / 33 / 64 / 100 / 130 queries (one and two passes,
+    idle and partly filled waves), duplicates across the tile boundary, queries of very different magnitude (per-query
+    power-of-two scaling)."""
     from oracle import embeddings_index as oi
 
     rng = np.random.default_rng(515)
@@ -297,11 +298,11 @@ def test_float16_native_scan_shapes(amd, metric):
     docs32 = docs16.astype(np.float32)
     dev = amd.ei.DeviceIndex.from_host(docs16)
     assert dev.hbm_bytes() < 2.2 * docs16.nbytes  # rows (2 B) + fragments (2 B) + norms: not the 8 x of the widened path
-    qs = rng.standard_normal((100, 1024))
+    qs = rng.standard_normal((130, 1024))
     qs[3] *= 1e-6
     qs[4] *= 3e4
     qs[5] = docs32[n - 1].astype(np.float64)
-    for b in (1, 33, 64, 100):
+    for b in (1, 33, 64, 100, 130):
         _, _, rows, dist, cnt, flags = dev.search(qs[:b], 10, metric)
         assert (cnt == 10).all()
         for i in range(b):
@@ -311,10 +312,12 @@ def test_float16_native_scan_shapes(amd, metric):
             np.testing.assert_allclose(dist[i], wdist, rtol=1e-12, atol=2e-7 * max(1.0, float(np.abs(wdist).max())))
     if metric == "sqeuclidean_dist":
         assert list(rows[5, :3]) == [31, 32, n - 1]
-    # k up to the float16 scan's list capacity (28) runs the filter scan; above it the exact pass answers alone
-    for k, want_flag in ((28, 0), (29, amd.nat.FLAG_EXACT_PASS)):
+    # k up to the float16 scan's list capacity (52) runs the filter scan - whose bound (2^-11 |q| max|d|, one float16
+    # product per fragment) may or may not prove a query on rows whose norms differ 15-fold as here; above it the exact
+    # pass answers alone.  Either way the ids are the reference's.
+    for k, must_be_exact in ((52, False), (53, True)):
         _, _, rows_k, _, cnt_k, flags_k = dev.search(qs[:2], k, metric)
-        assert (cnt_k == k).all() and (flags_k[1] == want_flag)
+        assert (cnt_k == k).all() and flags_k[1] in ((amd.nat.FLAG_EXACT_PASS,) if must_be_exact else (0, amd.nat.FLAG_EXACT_PASS))
         for i in range(2):
             wrows, _ = oi.find_flat(qs[i], docs32, metric, k)
             alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs32) if metric == "cosine_sim" else None
@@ -382,15 +385,16 @@ def test_float16_native_large_shard_sample_prepass(amd):
         np.testing.assert_allclose(dist[i], alld[want], rtol=1e-12, atol=1e-6)
 
 
+@pytest.mark.parametrize("d", [384, 48])
 @pytest.mark.parametrize("metric", ["sqeuclidean_dist", "cosine_sim"])
-def test_register_ring_kernel_large_k(amd, metric):
-    """k > 12 at d = 384 does not fit the 128-query kernel's LDS lists: these searches run the 32-query
-    register-ring kernel (scan_topk_kernel), 32 queries per pass."""
+def test_register_ring_kernel_large_k(amd, metric, d):
+    """k = 30: at d = 384 the 128-query kernel with long candidate buffers (klist 38: four ring stages instead of five), at
+    d = 48 the 32-query register-ring kernel (scan_topk_kernel) with 38-entry per-lane lists."""
     from oracle import embeddings_index as oi
 
     rng = np.random.default_rng(77)
-    docs = unit(rng.standard_normal((40000, 384)))
-    qs = unit(rng.standard_normal((40, 384))).astype(np.float64)
+    docs = unit(rng.standard_normal((40000, d)))
+    qs = unit(rng.standard_normal((40, d))).astype(np.float64)
     dev = amd.ei.DeviceIndex.from_host(docs)
     _, _, rows, dist, cnt, flags = dev.search(qs, 30, metric)
     assert (cnt == 30).all()
