@@ -456,8 +456,15 @@ static int32_t launch_scan_h16(const mir_index *ix, const uint4 *qfrag_g, const 
         set_error("internal: float16 scan has no instance for %d k-steps", ix->ksteps);
         return MIR_ERR_UNSUPPORTED;
     }
-    if (ns == 4) MIR_H16_LAUNCH(32, 4);
-    else MIR_H16_LAUNCH(32, 3);
+    switch (ns) {
+        case 8: MIR_H16_LAUNCH(32, 8); break;
+        case 7: MIR_H16_LAUNCH(32, 7); break;
+        case 6: MIR_H16_LAUNCH(32, 6); break;
+        case 5: MIR_H16_LAUNCH(32, 5); break;
+        case 4: MIR_H16_LAUNCH(32, 4); break;
+        case 3: MIR_H16_LAUNCH(32, 3); break;
+        default: MIR_H16_LAUNCH(32, 2); break;
+    }
 #undef MIR_H16_LAUNCH
     MIR_HIP(hipGetLastError());
     return MIR_OK;

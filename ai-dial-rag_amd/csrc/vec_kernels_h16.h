@@ -28,12 +28,20 @@ namespace mir {
 // float16's subnormal range add < 1e-8) plus the float32 accumulation of up to 1024 products (<= 1024 * 2^-24 = 6.1e-5 of
 // sum |x_i q_i| <= |x||q|): 5.5e-4, rounded up.
 constexpr double kH16RelErr = 6.0e-4;
-constexpr int kH16StageKs = 16;  // k-steps of 32 columns per ring stage (32 KiB)
+#ifndef H16_STAGE_KS
+#define H16_STAGE_KS 16
+#endif
+#ifndef H16_MAX_STAGES
+#define H16_MAX_STAGES 4
+#endif
+constexpr int kH16StageKs = H16_STAGE_KS;  // k-steps of 32 columns per ring stage (2 KiB each)
 // a query's candidate buffer: klist kept entries + room for 8 appended ones between compactions (16 would push the usual
 // klist = 18 past the LDS a four-stage ring leaves)
 __host__ __device__ constexpr int h16_buffer(int klist) { return klist + 8 < 64 ? klist + 8 : 64; }
-__host__ __device__ constexpr int h16_ring_stages(int klist) {  // 160 KiB of LDS: 4 stages beside small buffers, else 3
-    return 4 * kH16StageKs * 2048 + h16_buffer(klist) * kQ16Queries * 8 <= 160 * 1024 ? 4 : 3;
+__host__ __device__ constexpr int h16_ring_stages(int klist) {  // 160 KiB of LDS: the most stages that fit beside the buffers
+    int ns = H16_MAX_STAGES;
+    while (ns > 2 && ns * kH16StageKs * 2048 + h16_buffer(klist) * kQ16Queries * 8 > 160 * 1024) --ns;
+    return ns;
 }
 __host__ __device__ constexpr size_t h16_lds_bytes(int klist) {
     return (size_t)h16_ring_stages(klist) * kH16StageKs * 2048 + (size_t)h16_buffer(klist) * kQ16Queries * 8;
