@@ -144,7 +144,7 @@ def encoder_leg(np, torch, dist, args, world, rank, local_rank, barrier):
 def c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher):
     """BASELINE config 5 (SURVEY.md 8(d)): d = 1024 float16 vectors, not normalised, sqeuclidean;
     rows_per_gpu fixed (50M over 8 GPUs = 6.25M each), so this leg scales weakly with --gpus.
-    The index keeps the rows in float16 (2 B/element scanned, 64 queries per pass)."""
+    The index keeps the rows in float16 (2 B/element scanned, 128 queries per pass: vec_kernels_h16.h)."""
     device = torch.device("cuda", local_rank)
     n_loc, d, B, k = args.c5_rows, 1024, 128, args.k
     g = torch.Generator(device=device)
@@ -182,17 +182,17 @@ def c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex,
     elapsed = float(tmax.item())
     flags = int(out[3].sum().item())
     index.close()
-    bytes_pass = n_loc * d * 2 + 4 * n_loc + 64 * d * 4 + 64 * k * 12  # SURVEY 8(d), s = 2 (fp16), 64 queries per pass
+    bytes_pass = n_loc * d * 2 + 4 * n_loc + 128 * d * 4 + 128 * k * 12  # SURVEY 8(d), s = 2 (fp16), 128 queries per pass
     avg_ms = scan_ms / max(launches, 1)
     return {
         "workload": f"{n_loc} x {d} float16 rows per GPU (not normalised), sqeuclidean_dist, k={k}",
         "scaling": "weak",
         "queries_per_step": B,
-        "queries_per_pass": 64,
+        "queries_per_pass": 128,
         "ms_per_step": round(1e3 * elapsed / steps, 4),
         "qps": round(B * steps / elapsed, 1),
         "index_hbm_bytes_per_gpu": hbm,
-        "roofline": {"bound": "hbm", "kernel": "scan_topk_f16_kernel", "bytes_per_launch": bytes_pass,
+        "roofline": {"bound": "hbm", "kernel": "scan_topk_h16_kernel (2 launches per shard + list_threshold_kernel)", "bytes_per_launch": bytes_pass,
                      "avg_launch_ms": round(avg_ms, 4), "achieved": round(bytes_pass / (avg_ms * 1e-3) / 1e9, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_pass / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "launches": launches},
