@@ -452,19 +452,22 @@ static int32_t launch_scan_h16(const mir_index *ix, const uint4 *qfrag_g, const 
         kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qfrag_g, qscale_g, n_rows, tile0, n_tiles, nq, klist, part_g, \
                                                     gthr_g);                                                           \
     } while (0)
-    if (ix->ksteps != 64) {  // 512 < d <= 1024: 32 k-steps of 32 columns (128 VGPRs of query fragments per wave)
+    // ksteps = 64: 512 < d <= 1024, 32 k-steps of 32 columns (128 VGPRs of query fragments per wave); 32: 256 < d <= 512
+#define MIR_H16_CASES(KS)                                                                                              \
+    switch (ns) {                                                                                                      \
+        case 4: MIR_H16_LAUNCH(KS, 4); break;                                                                          \
+        case 3: MIR_H16_LAUNCH(KS, 3); break;                                                                          \
+        default: MIR_H16_LAUNCH(KS, 2); break;                                                                         \
+    }
+    if (ix->ksteps == 64) {
+        MIR_H16_CASES(32)
+    } else if (ix->ksteps == 32) {
+        MIR_H16_CASES(16)
+    } else {
         set_error("internal: float16 scan has no instance for %d k-steps", ix->ksteps);
         return MIR_ERR_UNSUPPORTED;
     }
-    switch (ns) {
-        case 8: MIR_H16_LAUNCH(32, 8); break;
-        case 7: MIR_H16_LAUNCH(32, 7); break;
-        case 6: MIR_H16_LAUNCH(32, 6); break;
-        case 5: MIR_H16_LAUNCH(32, 5); break;
-        case 4: MIR_H16_LAUNCH(32, 4); break;
-        case 3: MIR_H16_LAUNCH(32, 3); break;
-        default: MIR_H16_LAUNCH(32, 2); break;
-    }
+#undef MIR_H16_CASES
 #undef MIR_H16_LAUNCH
     MIR_HIP(hipGetLastError());
     return MIR_OK;
@@ -844,10 +847,10 @@ static int32_t create_common(const RowSource &src, int64_t n, int32_t d, int32_t
         }                                                                                          \
     } while (0)
     const size_t orig_bytes = (size_t)n * d * sizeof(float);
-    // float16 rows with 512 < d <= 1024: kept as they are and scanned as 2-byte fragments, columns
-    // zero-padded to 1024 (vec_kernels_f16.h); everything else goes through the float32 / bf16-split
-    // layout
-    ix->native16 = dtype == MIR_DTYPE_F16 && d > 512 && d <= 1024;
+    // float16 rows with 256 < d <= 1024: kept as they are and scanned as 2-byte fragments, columns
+    // zero-padded to 512 or 1024 (vec_kernels_h16.h); everything else goes through the float32 / bf16-split
+    // layout (at d <= 256 the padding to 512 columns would scan as many bytes as that does)
+    ix->native16 = dtype == MIR_DTYPE_F16 && d > 256 && d <= 1024;
     if (ix->native16) {
         MIR_TRY(hipMalloc(reinterpret_cast<void **>(&ix->d_f16), std::max<size_t>(orig_bytes / 2, 16)));
         ix->hbm_bytes += orig_bytes / 2;

@@ -32,8 +32,9 @@ constexpr double kH16RelErr = 6.0e-4;
 #define H16_STAGE_KS 16
 #endif
 #ifndef H16_MAX_STAGES
-#define H16_MAX_STAGES 4
+#define H16_MAX_STAGES 4  // (launch_scan_h16 instantiates 2, 3 and 4)
 #endif
+static_assert(H16_MAX_STAGES <= 4, "add the instances to launch_scan_h16");
 constexpr int kH16StageKs = H16_STAGE_KS;  // k-steps of 32 columns per ring stage (2 KiB each)
 // a query's candidate buffer: klist kept entries + room for 8 appended ones between compactions (16 would push the usual
 // klist = 18 past the LDS a four-stage ring leaves)

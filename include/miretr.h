@@ -52,9 +52,10 @@ extern "C" {
 
 /* element type of the stored embedding matrix.  F16 rows are scored as the
  * float32 values they widen to, exactly (the reference up-casts fp16 storage the
- * same way).  With 512 < d <= 1024 (MultimodalRetriever's embeddings,
- * multimodal_retriever.py:96-153) the index stays 2 bytes per element and k is
- * limited to 28; other F16 shapes are widened to float32 on the device. */
+ * same way).  With 256 < d <= 1024 (MultimodalRetriever's embeddings,
+ * multimodal_retriever.py:96-153) the index stays 2 bytes per element in HBM;
+ * other F16 shapes are widened to float32 on the device.  Any k is accepted on
+ * every index (beyond the filter scan's candidate lists the exact pass answers). */
 #define MIR_DTYPE_F32 0
 #define MIR_DTYPE_F16 1
 

@@ -324,6 +324,34 @@ def test_float16_native_scan_shapes(amd, metric):
             assert_same_ids(metric, rows_k[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} k={k} q={i}")
 
 
+@pytest.mark.parametrize("d", [257, 384, 512, 520])
+def test_float16_native_narrower_dims(amd, d):
+    """Float16 rows with 256 < d <= 1024 stay 2 bytes per element: d <= 512 is one ring stage per tile (16 k-steps of 32
+    columns, zero-padded), d = 520 the two-stage form with a mostly empty second half; odd d takes the element-wise
+    packing path."""
+    from oracle import embeddings_index as oi
+
+    rng = np.random.default_rng(100 + d)
+    n = 9000
+    docs16 = rng.standard_normal((n, d)).astype(np.float16)
+    docs16[4000] = docs16[17]
+    docs32 = docs16.astype(np.float32)
+    dev = amd.ei.DeviceIndex.from_host(docs16)
+    assert dev.hbm_bytes() < (2 * 2 * (512 if d <= 512 else 1024) + 64) * n  # rows + padded fragments + norms
+    qs = rng.standard_normal((40, d))
+    qs[7] = docs32[17].astype(np.float64)
+    for metric in ("sqeuclidean_dist", "cosine_sim", "inner_product"):
+        _, _, rows, dist, cnt, flags = dev.search(qs, 10, metric)
+        assert (cnt == 10).all()
+        for i in range(40):
+            wrows, wdist = oi.find_flat(qs[i], docs32, metric, 10)
+            alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs32) if metric == "cosine_sim" else None
+            assert_same_ids(metric, rows[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} d={d} q={i}")
+            np.testing.assert_allclose(dist[i], wdist, rtol=1e-12, atol=2e-7 * max(1.0, float(np.abs(wdist).max())))
+        if metric == "sqeuclidean_dist":
+            assert list(rows[7, :2]) == [17, 4000]
+
+
 @pytest.mark.parametrize("metric", METRICS)
 def test_float16_native_vs_reference_golden(amd, golden_dir, metric):
     """The d = 1024 fp16-rounded set of metrics_random.npz (outputs recorded from the imported reference
