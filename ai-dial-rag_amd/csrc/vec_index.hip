@@ -705,7 +705,11 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
             return (int64_t)(e && atoi(e) > 0 ? atoi(e) : 64);
         }();
         if ((int64_t)ix->n_tiles >= min_tiles_per_wg * (int64_t)pl->nwg) {  // many tiles per workgroup: scan 1/16 first, re-seed, scan the rest
-            pl->tiles_first = ix->n_tiles / 16;
+            static const uint32_t first_div = []() {  // tuning knob: MIR_PROGRESSIVE_DIV (the first launch scans 1/div of the tiles)
+                const char *e = getenv("MIR_PROGRESSIVE_DIV");
+                return (uint32_t)(e && atoi(e) > 1 ? atoi(e) : 16);
+            }();
+            pl->tiles_first = std::max<uint32_t>(ix->n_tiles / first_div, 4u * (uint32_t)pl->nwg);
             pl->nwg_first = pl->nwg;
             pl->nwg = 2 * pl->nwg;  // lists for finalize
         }
