@@ -25,6 +25,34 @@ extern "C" int32_t mir_rrf_fuse(const int64_t *keys, const int32_t *list_ptr, co
     const int total = list_ptr[n_lists];
     MIR_REQUIRE(total == 0 || (keys && out_keys && out_scores), "NULL buffer");
     typedef std::pair<int64_t, int64_t> Key;
+    constexpr int kSmall = 64;  // the product's case is <= 4 lists x 7 items: no containers, a linear scan for the key
+    if (total <= kSmall) {
+        Key uniq[kSmall];
+        double score[kSmall];
+        int order[kSmall], nu = 0;
+        for (int l = 0; l < n_lists; ++l) {
+            for (int i = list_ptr[l]; i < list_ptr[l + 1]; ++i) {
+                const Key k(keys[2 * i], keys[2 * i + 1]);
+                int s = 0;
+                while (s < nu && uniq[s] != k) ++s;
+                if (s == nu) { uniq[nu] = k; score[nu] = 0.0; ++nu; }
+                const int rank = i - list_ptr[l] + 1;
+                score[s] += weights[l] / (double)(rank + c);
+            }
+        }
+        for (int i = 0; i < nu; ++i) {  // stable insertion sort by score, descending
+            int j = i;
+            while (j > 0 && score[order[j - 1]] < score[i]) { order[j] = order[j - 1]; --j; }
+            order[j] = i;
+        }
+        for (int r = 0; r < nu; ++r) {
+            out_keys[2 * r] = uniq[order[r]].first;
+            out_keys[2 * r + 1] = uniq[order[r]].second;
+            out_scores[r] = score[order[r]];
+        }
+        *out_count = nu;
+        return MIR_OK;
+    }
     std::map<Key, int> slot;       // key -> position in first-seen order
     std::vector<Key> uniq;
     std::vector<double> score;

@@ -180,14 +180,21 @@ def fuse_batch(lists: Sequence[Tuple[np.ndarray, np.ndarray]], weights: Sequence
         lp[:, l + 1] = lp[:, l] + np.asarray(cnt, np.int32)
     cap = int(sum(ids.shape[1] for ids, _ in lists))
     keys = np.zeros((b, cap, 2), np.int64)
-    for l, (ids, cnt) in enumerate(lists):
-        ids = np.asarray(ids)
-        kl = ids.shape[1]
-        col = np.arange(kl)[None, :]
-        ok = col < np.asarray(cnt)[:, None]
-        dst = lp[:, l][:, None] + col
-        qq, cc = np.nonzero(ok)
-        keys[qq, dst[qq, cc], 0] = ids[qq, cc]
+    if all(int(np.min(cnt, initial=ids.shape[1])) == ids.shape[1] for ids, cnt in lists):
+        # every list full (the usual case): the lists side by side, no per-element placement
+        at = 0
+        for ids, _ in lists:
+            keys[:, at : at + ids.shape[1], 0] = ids
+            at += ids.shape[1]
+    else:
+        for l, (ids, cnt) in enumerate(lists):
+            ids = np.asarray(ids)
+            kl = ids.shape[1]
+            col = np.arange(kl)[None, :]
+            ok = col < np.asarray(cnt)[:, None]
+            dst = lp[:, l][:, None] + col
+            qq, cc = np.nonzero(ok)
+            keys[qq, dst[qq, cc], 0] = ids[qq, cc]
     key_base = (np.arange(b, dtype=np.int64) * cap)
     out_keys = np.zeros((b, cap, 2), np.int64)
     out_scores = np.zeros((b, cap), np.float64)
@@ -212,8 +219,28 @@ class ShardedHybrid:
         _, v_rows, v_cnt, _ = self.vector.search(query_vectors, self.k, metric)
         _, t_idx, t_cnt = self.keywords.search(query_terms, self.k, q_ptr)
         if self.vector.on_gpu:
-            self.vector.torch.cuda.current_stream(self.vector.device).synchronize()
-        v = (v_rows.cpu().numpy(), v_cnt.cpu().numpy())
-        t = (t_idx.cpu().numpy(), t_cnt.cpu().numpy())
+            # both legs' lists to the host in ONE copy: [vector rows | BM25 rows | counts (int32 pairs)] as int64
+            tt = self.vector.torch
+            b, k = int(v_rows.shape[0]), self.k
+            key = (b, k)
+            if getattr(self, "_stage_key", None) != key:
+                self._stage = tt.empty(b * (2 * k + 1), dtype=tt.int64, device=self.vector.device)
+                self._stage_host = tt.empty(b * (2 * k + 1), dtype=tt.int64, pin_memory=True)
+                self._stage_key = key
+            st = self._stage
+            st[: b * k].copy_(v_rows.reshape(-1))
+            st[b * k : 2 * b * k].copy_(t_idx.reshape(-1))
+            cnts = st[2 * b * k :].view(tt.int32).view(b, 2)
+            cnts[:, 0].copy_(v_cnt)
+            cnts[:, 1].copy_(t_cnt)
+            self._stage_host.copy_(st, non_blocking=True)
+            tt.cuda.current_stream(self.vector.device).synchronize()
+            h = self._stage_host.numpy()
+            hc = h[2 * b * k :].view(np.int32).reshape(b, 2)
+            v = (h[: b * k].reshape(b, k).copy(), hc[:, 0].copy())
+            t = (h[b * k : 2 * b * k].reshape(b, k).copy(), hc[:, 1].copy())
+        else:
+            v = (v_rows.cpu().numpy(), v_cnt.cpu().numpy())
+            t = (t_idx.cpu().numpy(), t_cnt.cpu().numpy())
         ids, scores, cnt = fuse_batch([v, t], self.weights, self.c)
         return ids, scores, cnt, v, t

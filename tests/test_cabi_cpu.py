@@ -80,7 +80,8 @@ def test_merge_host_orderings(nat):
 
 
 def test_rrf_fuse_matches_oracle(nat):
-    """Host-only entry point: runs without a GPU.  Random overlapping lists incl. in-list duplicates."""
+    """Host-only entry point: runs without a GPU.  Random overlapping lists incl. in-list duplicates; every fifth trial has
+    long lists (more than 64 items in all: the library's container path instead of its fixed-size one)."""
     from aidial_rag_amd.index_record import RetrievalType, to_metadata_doc
     from aidial_rag_amd.retrievers.ensemble_retriever import weighted_reciprocal_rank
     from oracle import fusion as of
@@ -88,7 +89,9 @@ def test_rrf_fuse_matches_oracle(nat):
     rng = np.random.default_rng(1)
     for trial in range(50):
         nl = int(rng.integers(1, 5))
-        lists = [[(int(rng.integers(0, 3)), int(rng.integers(0, 6))) for _ in range(int(rng.integers(0, 8)))] for _ in range(nl)]
+        long = trial % 5 == 4
+        lists = [[(int(rng.integers(0, 3)), int(rng.integers(0, 20 if long else 6))) for _ in range(int(rng.integers(20, 40) if long else rng.integers(0, 8)))]
+                 for _ in range(nl)]
         weights = [1.0] * nl if trial % 2 else [float(w) for w in rng.random(nl)]
         docs = [[to_metadata_doc(a, b, RetrievalType.TEXT) for a, b in l] for l in lists]
         got = [(d.metadata["doc_id"], d.metadata["chunk_id"]) for d in weighted_reciprocal_rank(docs, weights)]
