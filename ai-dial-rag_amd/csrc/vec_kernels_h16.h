@@ -16,7 +16,7 @@
 // Index image: per 32-row tile, block (s, rh) = k-step of 32 columns s, row half rh at [2 s + rh]: 64 lanes x 8 f16,
 // lane l = (row 16 rh + (l & 15), columns 32 s + 8 (l >> 4) .. + 7) - the A operand of v_mfma_f32_16x16x32_f16.
 // A stage of the LDS-DMA ring is 16 k-steps = 32 blocks = 32 KiB (half of a d = 1024 tile).
-// Candidate buffers, thresholds, the sample pre-pass and the progressive two-launch scheme are those of
+// Candidate buffers (Q16Lists), thresholds, the sample pre-pass and the progressive two-launch scheme are those of
 // vec_kernels_q16.h.
 #pragma once
 #include "vec_kernels_f16.h"
@@ -141,8 +141,6 @@ __global__ __launch_bounds__(512, 2) void scan_topk_h16_kernel(const uint4 *__re
     constexpr int TILE_U4 = SPT * STAGE_U4;
     constexpr int PPW = SB / 8;               // DMA pieces per wave per stage
     constexpr int D = NS - 1;                 // stages in flight beyond the one being read
-    typedef uint32_t __attribute__((ext_vector_type(16))) u32x16;
-
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *ring = reinterpret_cast<uint4 *>(smem);                                      // [NS][STAGE_U4]
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + (size_t)NS * STAGE_U4 * 16);  // [128][cap]
@@ -191,23 +189,6 @@ __global__ __launch_bounds__(512, 2) void scan_topk_h16_kernel(const uint4 *__re
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only in the last D - 1 stages of the launch
     };
 
-    // the tile's 32 norm values -> this lane's 8 (rows 16 rh + 4 jg + i): scalar fetch (a vector load would queue
-    // behind the DMA ring), then three selects per value
-    auto load_aux = [&](uint32_t t, float (&ax)[8]) {
-        u32x16 sa, sb;
-        const float *ap = aux + (size_t)__builtin_amdgcn_readfirstlane(t) * kTileRows;
-        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(sa), "=&s"(sb)
-                     : "s"(ap)
-                     : "memory");
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float a0 = __uint_as_float(sa[i]), a1 = __uint_as_float(sa[4 + i]), a2 = __uint_as_float(sa[8 + i]), a3 = __uint_as_float(sa[12 + i]);
-            const float b0 = __uint_as_float(sb[i]), b1 = __uint_as_float(sb[4 + i]), b2 = __uint_as_float(sb[8 + i]), b3 = __uint_as_float(sb[12 + i]);
-            ax[i] = jg == 0 ? a0 : jg == 1 ? a1 : jg == 2 ? a2 : a3;
-            ax[4 + i] = jg == 0 ? b0 : jg == 1 ? b1 : jg == 2 ? b2 : b3;
-        }
-    };
     // ranking values of this lane's 8 rows from the (scaled) dot products
     auto to_values = [&](const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], float (&v)[8]) {
 #pragma unroll
@@ -218,34 +199,7 @@ __global__ __launch_bounds__(512, 2) void scan_topk_h16_kernel(const uint4 *__re
         }
     };
 
-    // Column c's buffer -> its best klist entries, in order; the klist-th becomes the column's threshold.  Whole wave.
-    auto compact = [&](int c) {
-        uint64_t *lq = mylist + (size_t)c * cap;
-        const int n = __builtin_amdgcn_readlane(cnt, c);  // (lane c is the column's first lane)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const uint64_t mine = lane < n ? lq[lane] : 0;
-        int rank = 0;
-        for (int i0 = 0; i0 < n; i0 += 8) {  // eight broadcast reads in flight per step
-            uint64_t o[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) o[u] = i0 + u < n ? lq[i0 + u] : 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) rank += (o[u] > mine) ? 1 : 0;  // keys are distinct (they carry the row)
-        }
-        if (lane < n && rank < klist) lq[rank] = mine;  // every read above was issued before any of these writes
-        const int kept = n < klist ? n : klist;
-        uint64_t nthr = 0;
-        if (n >= klist) {
-            const unsigned long long at = __ballot(lane < n && rank == klist - 1);
-            const int src = __builtin_ctzll(at);
-            nthr = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), src) << 32) |
-                   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, src);
-        }
-        if (qc == c) {
-            cnt = kept;
-            if (nthr > thr) thr = nthr;
-        }
-    };
+    const Q16Lists L{mylist, cap, klist, lane, qc, jg, colmask};  // buffers, compaction, appends: vec_kernels_q16.h
 
     for (uint32_t ts = 0; ts < my_tiles; ++ts) {
         const uint32_t t = tile0 + blockIdx.x + ts * G;
@@ -259,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void scan_topk_h16_kernel(const uint4 *__re
             __builtin_amdgcn_s_barrier();
             if (g + D < NG) issue(g + D);
             if (active) {
-                if (j == 0 && KIND != SCAN_IP) load_aux(t, ax);
+                if (j == 0 && KIND != SCAN_IP) q16_load_aux(aux, t, jg, ax);
                 const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
                 uint4 f0[3], f1[3];
                 f0[0] = st[0 * 64]; f1[0] = st[1 * 64];
@@ -294,36 +248,7 @@ __global__ __launch_bounds__(512, 2) void scan_topk_h16_kernel(const uint4 *__re
             const uint32_t row = row0 + 16 * (r >> 2) + (r & 3);
             pm |= (uint32_t)(lane_live && row < n_rows && !(v[r] < vmin0)) << r;
         }
-        // candidates: every lane appends its lowest passing value per round; a column's appends get consecutive slots
-        while (__any(pm != 0)) {
-            const int r = pm ? __builtin_ctz(pm) : 0;
-            // v[r] for a lane-dependent r, kept in registers (a plain select chain becomes an indexed scratch array whose
-            // `s_waitcnt vmcnt(0)` would drain the DMA ring: the empty asm makes each element opaque)
-            float x = v[0];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) {
-                float c = v[j];
-                asm volatile("" : "+v"(c));
-                x = (r == j) ? c : x;
-            }
-            x = (x == x) ? x + 0.0f : -__builtin_inff();  // NaN ranks last; -0 -> +0
-            const uint64_t key = make_key(x, row0 + 16 * (r >> 2) + (r & 3));
-            const bool ok = pm != 0 && key > thr;  // thr = 0 while the column has no threshold yet
-            const unsigned long long bal = __ballot(ok);
-            const int tot = __popcll(bal & colmask);
-            if (__any(cnt + tot > cap)) {  // some column's buffer would overflow: compact those first, then redo the round
-                unsigned long long over = __ballot(cnt + tot > cap && jg == 0);
-                while (over) {
-                    const int c = __builtin_ctzll(over);
-                    over &= over - 1;
-                    compact(c);
-                }
-                continue;
-            }
-            if (ok) mylist[(size_t)qc * cap + cnt + __popcll(bal & colmask & ((1ull << lane) - 1ull))] = key;
-            cnt += tot;
-            pm &= pm - 1;
-        }
+        L.append(pm, v, row0, cnt, thr);
     }
     if (SAMPLE) {
         // four lanes hold a query's column: two values per query, each the maximum over distinct rows
@@ -334,13 +259,7 @@ __global__ __launch_bounds__(512, 2) void scan_topk_h16_kernel(const uint4 *__re
         return;
     }
     // ---- every buffer compacted once more (sorted, best first) and written out, empty entries as 0: [128][klist] per workgroup ----
-    uint64_t *out = part + (size_t)blockIdx.x * kQ16Queries * klist + (size_t)wave8 * 16 * klist;
-    for (int c = 0; c < 16; ++c) {
-        compact(c);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int n = __builtin_amdgcn_readlane(cnt, c);
-        if (lane < klist) out[(size_t)c * klist + lane] = lane < n ? mylist[(size_t)c * cap + lane] : 0;
-    }
+    L.write_out(part + (size_t)blockIdx.x * kQ16Queries * klist + (size_t)wave8 * 16 * klist, cnt, thr);
 }
 
 }  // namespace mir
