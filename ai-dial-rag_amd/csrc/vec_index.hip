@@ -700,18 +700,13 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
         pl->qpw = kQ16Queries;
         pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
         pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), (int64_t)ix->n_tiles));
-        static const int64_t min_tiles_per_wg = []() {  // tuning knob (tools/): MIR_PROGRESSIVE_MIN_TILES
-            const char *e = getenv("MIR_PROGRESSIVE_MIN_TILES");
-            return (int64_t)(e && atoi(e) > 0 ? atoi(e) : 64);
-        }();
-        if ((int64_t)ix->n_tiles >= min_tiles_per_wg * (int64_t)pl->nwg) {  // many tiles per workgroup: scan 1/16 first, re-seed, scan the rest
-            static const uint32_t first_div = []() {  // tuning knob: MIR_PROGRESSIVE_DIV (the first launch scans 1/div of the tiles)
-                const char *e = getenv("MIR_PROGRESSIVE_DIV");
-                return (uint32_t)(e && atoi(e) > 1 ? atoi(e) : 16);
-            }();
+        // Shards of >= 64 tiles per workgroup are scanned in two launches (1/16 first, re-seed, the rest).  Measured per
+        // 128-query step (1.25M / 2.5M / 5M rows): two launches 0.427 / 0.689 / 1.240 ms, one launch 0.441 / 0.773 / 1.496;
+        // first-launch fractions 1/8, 1/32, 1/64 on 10M rows: 2.351 / 2.346 / 2.445 ms against 2.324 at 1/16.
+        if ((int64_t)ix->n_tiles >= 64 * (int64_t)pl->nwg) {
             // 1/16 of the tiles, but not fewer than ~157K rows (their klist-th best is what makes the second launch's
             // thresholds tight: 1.25M rows measured 0.429 ms per step with 78K rows first, 0.411 with 156K) nor more than 1/4
-            pl->tiles_first = std::max<uint32_t>(ix->n_tiles / first_div, std::min<uint32_t>(ix->n_tiles / 4, 4896u));
+            pl->tiles_first = std::max<uint32_t>(ix->n_tiles / 16, std::min<uint32_t>(ix->n_tiles / 4, 4896u));
             pl->nwg_first = pl->nwg;
             pl->nwg = 2 * pl->nwg;  // lists for finalize
         }
