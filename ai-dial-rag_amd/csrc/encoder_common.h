@@ -214,6 +214,52 @@ __device__ __forceinline__ float ln_part_sum(f32x16 (&y)[NB], int fb0, const uin
     }
     return sum;
 }
+// ln_part_sum without the sum (y += bias + residual only), and the two running sums continued from a given value over
+// the blocks in the same element order: for a wave that takes over a half's statistics from another wave part-way
+// (ln_small_kernel's four waves per tile).  sum_from(apply(y), 0) == ln_part_sum(y) bit for bit.
+template <int NB>
+__device__ __forceinline__ void ln_part_apply(f32x16 (&y)[NB], int fb0, const uint4 *__restrict__ resid_tile,
+                                              const float *__restrict__ bias, int lane) {
+    const int h = lane >> 5;
+    uint4 rr[NB * 2];
+#pragma unroll
+    for (int i = 0; i < NB * 2; ++i) rr[i] = resid_tile[(fb0 * 2 + i) * 64 + lane];
+    float4 bb4[NB][4];
+#pragma unroll
+    for (int f = 0; f < NB; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bb4[f][g] = *reinterpret_cast<const float4 *>(bias + 32 * (fb0 + f) + 8 * g + 4 * h);
+#pragma unroll
+    for (int f = 0; f < NB; ++f)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float rv[8];
+            frag_to_floats(rr[f * 2 + s2], rv);
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {
+                const int g = 2 * s2 + gq;
+                const float bb[4] = {bb4[f][g].x, bb4[f][g].y, bb4[f][g].z, bb4[f][g].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[f][4 * g + i] = y[f][4 * g + i] + bb[i] + rv[4 * gq + i];
+            }
+        }
+}
+template <int NB>
+__device__ __forceinline__ float ln_part_sum_from(const f32x16 (&y)[NB], float sum) {
+#pragma unroll
+    for (int f = 0; f < NB; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += y[f][r];
+    return sum;
+}
+template <int NB>
+__device__ __forceinline__ float ln_part_sq_from(const f32x16 (&centred)[NB], float sq) {
+#pragma unroll
+    for (int f = 0; f < NB; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sq = fmaf(centred[f][r], centred[f][r], sq);
+    return sq;
+}
 template <int NB>
 __device__ __forceinline__ float ln_part_sq(f32x16 (&y)[NB], float mean) {
     float sq = 0.f;

@@ -313,31 +313,47 @@ __device__ __forceinline__ void store_acc_rows(float *__restrict__ Y, int tt, in
     for (int c = 0; c < 4; ++c) yo[c * 64] = make_float4(acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
 }
 
-__device__ __forceinline__ void ln_tile(const float *Y, int tt, const uint4 *__restrict__ resid,
-                                        const float *__restrict__ bias, const float *__restrict__ gamma,
-                                        const float *__restrict__ beta, uint4 *__restrict__ act_out, int lane) {
-    f32x16 y[NFB];
+// Y + bias + residual -> LayerNorm -> ACT; FOUR waves per token tile, three feature blocks each.  The LayerNorm statistics
+// are defined everywhere as half A + half B, each half a sequential float32 sum over its six blocks (ln_part_* in
+// encoder_common.h), so waves 0 and 2 start the halves' sums and waves 1 and 3 CONTINUE them from the value their partner
+// left in LDS: the same additions in the same order as the throughput kernels, bit for bit.  (One wave per tile loaded
+// all 192 accumulator rows and took ~10 us, half of a single query's GPU time: 489 -> 377 us per query with two waves.
+// Folding the LayerNorm into the product kernels - the tile's last wave to finish does it, counted with an atomic
+// between two device-scope fences - was measured too: the fences write back / invalidate the XCD's L2 per wave and cost
+// more than the launch they save: 1 tile 425 -> 412 us, 64 tiles 739 -> 1368 us.)
+__global__ __launch_bounds__(256) void ln_small_kernel(const float *__restrict__ Y, const uint4 *__restrict__ resid,
+                                                       const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, uint4 *__restrict__ act_out) {
+    __shared__ float xs[2][4][64];  // [sum | sum of squares][wave][lane]: running values of the halves
+    constexpr int QB = NFB / 4;
+    const int tt = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // w = 2 * half + quarter of the half
+    const bool second = w & 1;
+    f32x16 y[QB];
 #pragma unroll
-    for (int nt = 0; nt < NFB; ++nt) {
-        const float4 *yi = reinterpret_cast<const float4 *>(Y + (((size_t)tt * NFB + nt) * 16) * 64) + lane;
+    for (int i = 0; i < QB; ++i) {
+        const float4 *yi = reinterpret_cast<const float4 *>(Y + (((size_t)tt * NFB + QB * w + i) * 16) * 64) + lane;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float4 v = yi[c * 64];
-            y[nt][4 * c + 0] = v.x; y[nt][4 * c + 1] = v.y; y[nt][4 * c + 2] = v.z; y[nt][4 * c + 3] = v.w;
+            y[i][4 * c + 0] = v.x; y[i][4 * c + 1] = v.y; y[i][4 * c + 2] = v.z; y[i][4 * c + 3] = v.w;
         }
     }
-    residual_ln_store<true>(y, resid + (size_t)tt * (NFB * 2 * 64), bias, gamma, beta, act_out + (size_t)tt * (NFB * 2 * 64), lane,
-                            true);
-}
-
-// Y + bias + residual -> LayerNorm -> ACT; one wave per token tile.  (Folding this into the product kernels -
-// the tile's last wave to finish does the LayerNorm, counted with an atomic between two device-scope fences -
-// was measured: the fences write back / invalidate the XCD's L2 per wave and cost more than the launch they
-// save: 1 tile 425 -> 412 us, 64 tiles 739 -> 1368 us.)
-__global__ __launch_bounds__(64) MIR_ONE_WAVE void ln_small_kernel(const float *__restrict__ Y, const uint4 *__restrict__ resid,
-                                                                   const float *__restrict__ bias, const float *__restrict__ gamma,
-                                                                   const float *__restrict__ beta, uint4 *__restrict__ act_out) {
-    ln_tile(Y, blockIdx.x, resid, bias, gamma, beta, act_out, threadIdx.x);
+    ln_part_apply<QB>(y, QB * w, resid + (size_t)tt * (NFB * 2 * 64), bias, lane);
+    if (!second) xs[0][w][lane] = ln_part_sum_from<QB>(y, 0.f);
+    __syncthreads();
+    if (second) xs[0][w][lane] = ln_part_sum_from<QB>(y, xs[0][w - 1][lane]);
+    __syncthreads();
+    const float mean = half_sum(xs[0][1][lane] + xs[0][3][lane]) * (1.0f / H);  // half A + half B
+#pragma unroll
+    for (int f = 0; f < QB; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[f][r] = y[f][r] - mean;
+    if (!second) xs[1][w][lane] = ln_part_sq_from<QB>(y, 0.f);
+    __syncthreads();
+    if (second) xs[1][w][lane] = ln_part_sq_from<QB>(y, xs[1][w - 1][lane]);
+    __syncthreads();
+    const float rstd = rsqrtf(half_sum(xs[1][1][lane] + xs[1][3][lane]) * (1.0f / H) + LN_EPS);
+    ln_part_store<QB, true>(y, QB * w, rstd, gamma, beta, act_out + (size_t)tt * (NFB * 2 * 64), lane, true);
 }
 
 __global__ __launch_bounds__(64) MIR_ONE_WAVE void oproj_small_kernel(const uint4 *__restrict__ ctx, const uint4 *__restrict__ wo,
