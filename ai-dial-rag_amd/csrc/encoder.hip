@@ -325,8 +325,11 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
             const Layer &l = e->L[li];
             float *Y = reinterpret_cast<float *>(w + o_y);
             uint4 *hb = reinterpret_cast<uint4 *>(w + o_hb);
-            qkv_small_kernel<<<dim3(36, nt), dim3(64), 0, s>>>(a0, l.wqkv, l.bqkv, qf, kf, vf);
-            {
+            if (nt == s1 - s0) {  // every sequence a single tile (queries): projection + attention in one dispatch
+                const int32_t arc = launch_qkv_attention_single(a0, l.wqkv, l.bqkv, d_ti, nt, a1, s);  // a1 = context
+                if (arc != MIR_OK) return arc;
+            } else {
+                qkv_small_kernel<<<dim3(36, nt), dim3(64), 0, s>>>(a0, l.wqkv, l.bqkv, qf, kf, vf);
                 const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);  // a1 = context
                 if (arc != MIR_OK) return arc;
             }

@@ -6,6 +6,58 @@
 namespace mir {
 namespace enc {
 
+// The running state of one (head, query tile) and one key tile's worth of attention: S^T = K Q^T - ref, P = exp2,
+// O^T += V^T P^T, lsum += 1 P^T (the lazy softmax reference is described at attention_kernel).  Shared by the throughput /
+// general kernel and the single-tile fused kernel of the latency path, so both round alike.
+struct AttnState {
+    f32x16 o = {0}, lsum = {0}, nref = {0};  // lsum: every register holds the lane's query's running sum
+};
+__device__ __forceinline__ void attn_step(AttnState &st, const uint4 &q0, const uint4 &q1, const uint4 &kc0, const uint4 &kc1,
+                                          const uint4 &vc0, const uint4 &vc1, bool first, bool last, int key0, int seq_len, int h) {
+    constexpr float kSlack = 6.0f;
+    const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
+    f32x16 s = mfma(kc0, q0, st.nref);
+    s = mfma(kc1, q1, s);
+    if (last) {  // only the sequence's last key tile can hold padding
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = (key0 + fi(r, h) < seq_len) ? s[r] : -__builtin_inff();
+    }
+    const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]), a2 = fmaxf(fmaxf(s[6], s[7]), s[8]);
+    const float a3 = fmaxf(fmaxf(s[9], s[10]), s[11]), a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+    const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(a4, s[15]));  // this lane's half of the keys
+    if (first || __any(mx > kSlack)) {  // wave-uniform; rare after the first tile
+        const float mq = half_max(mx);
+        const float delta = first ? mq : fmaxf(mq, 0.f);  // the reference only rises after the first tile
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] -= delta;
+            st.nref[r] -= delta;
+            st.o[r] *= alpha;
+            st.lsum[r] *= alpha;
+        }
+    }
+    // v_exp_f32 directly: exp2f() wraps it in a compare / select / ldexp to keep results below 2^-126 exact, ~4 extra
+    // instructions per value; a softmax term that small is zero next to the row's largest term either way
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+    // P to float16 with the packed convert (two values per instruction; the scalar casts cost three)
+    const uint4 p0 = make_uint4(pack2_rn(s[0], s[1]), pack2_rn(s[2], s[3]), pack2_rn(s[4], s[5]), pack2_rn(s[6], s[7]));
+    const uint4 p1 = make_uint4(pack2_rn(s[8], s[9]), pack2_rn(s[10], s[11]), pack2_rn(s[12], s[13]), pack2_rn(s[14], s[15]));
+    st.o = mfma(vc0, p0, st.o);
+    st.lsum = mfma(ones, p0, st.lsum);
+    st.o = mfma(vc1, p1, st.o);
+    st.lsum = mfma(ones, p1, st.lsum);
+}
+// normalise and write the context fragments of the (head, query tile)
+__device__ __forceinline__ void attn_store(AttnState &st, uint4 *__restrict__ out) {
+    const float inv = 1.0f / st.lsum[0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st.o[r] *= inv;
+    out[0] = acc_to_frag(st.o, 0);
+    out[64] = acc_to_frag(st.o, 1);
+}
+
 // One wave per (head, query tile): light on registers, so several waves share a SIMD and
 // the softmax's VALU work overlaps other waves' MFMAs (at hd = 32 a 32x32 score tile is 4
 // MFMAs against ~100 VALU instructions: a one-wave-per-SIMD kernel is VALU-bound 4:1).
@@ -44,45 +96,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict_
     //   * the row sums come from the matrix pipe (ones x P^T into a second accumulator): no adds, no cross-half shuffle;
     //   * P stays <= 2^kSlack: float16 holds it with the same relative precision as values <= 1.
     // (~110 -> ~50 VALU instructions per key tile, tools/run_enc_pmc.sh.)
-    constexpr float kSlack = 6.0f;
-    f32x16 o = {0}, lsum = {0}, nref = {0};  // lsum: every register holds the lane's query's running sum
-    const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
-
-    // one key tile: S^T = K Q^T - ref, P = exp2, O^T += V^T P^T, lsum += 1 P^T
+    AttnState st;
     auto step = [&](int kt, const uint4 &kc0, const uint4 &kc1, const uint4 &vc0, const uint4 &vc1) {
-        f32x16 s = mfma(kc0, q0, nref);
-        s = mfma(kc1, q1, s);
-        if (kt == n_kt - 1) {  // only the sequence's last key tile can hold padding
-            const int key0 = 32 * kt;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = (key0 + fi(r, h) < seq_len) ? s[r] : -__builtin_inff();
-        }
-        const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]), a2 = fmaxf(fmaxf(s[6], s[7]), s[8]);
-        const float a3 = fmaxf(fmaxf(s[9], s[10]), s[11]), a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
-        const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(a4, s[15]));  // this lane's half of the keys
-        if (kt == 0 || __any(mx > kSlack)) {  // wave-uniform; rare after the first tile
-            const float mq = half_max(mx);
-            const float delta = kt == 0 ? mq : fmaxf(mq, 0.f);  // the reference only rises after the first tile
-            const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] -= delta;
-                nref[r] -= delta;
-                o[r] *= alpha;
-                lsum[r] *= alpha;
-            }
-        }
-        // v_exp_f32 directly: exp2f() wraps it in a compare / select / ldexp to keep results below 2^-126 exact, ~4 extra
-        // instructions per value; a softmax term that small is zero next to the row's largest term either way
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
-        // P to float16 with the packed convert (two values per instruction; the scalar casts cost three)
-        const uint4 p0 = make_uint4(pack2_rn(s[0], s[1]), pack2_rn(s[2], s[3]), pack2_rn(s[4], s[5]), pack2_rn(s[6], s[7]));
-        const uint4 p1 = make_uint4(pack2_rn(s[8], s[9]), pack2_rn(s[10], s[11]), pack2_rn(s[12], s[13]), pack2_rn(s[14], s[15]));
-        o = mfma(vc0, p0, o);
-        lsum = mfma(ones, p0, lsum);
-        o = mfma(vc1, p1, o);
-        lsum = mfma(ones, p1, lsum);
+        attn_step(st, q0, q1, kc0, kc1, vc0, vc1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
     };
     // Two key tiles per trip, each in its own registers: a tile's K/V are requested one step ahead.  vmcnt counts in
     // order, so the wait for the older buffer leaves the younger one's loads in flight.  (The requests are unconditional -
@@ -102,14 +118,59 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict_
             step(kt + 1, kb0, kb1, vb0, vb1);
         }
     }
-    const float inv = 1.0f / lsum[0];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= inv;
-    uint4 *out = ctx + (size_t)tt * (NFB * 2 * 64) + (size_t)(head * 2) * 64 + lane;
-    out[0] = acc_to_frag(o, 0);
-    out[64] = acc_to_frag(o, 1);
+    attn_store(st, ctx + (size_t)tt * (NFB * 2 * 64) + (size_t)(head * 2) * 64 + lane);
 }
 
+
+// Latency path, batches whose sequences all fit one token tile (queries): QKV projection and attention of one (head,
+// tile) in ONE dispatch.  Three waves compute the head's Q, K and V fragments exactly as qkv_small_kernel does (same
+// chains, same bias / scale arithmetic), hand them over through LDS, and the first wave runs the one attention step:
+// 12 of a query's 86 dependent dispatches go, and Q / K / V never touch global memory.
+__global__ __launch_bounds__(192) void qkv_attention_single_kernel(const uint4 *__restrict__ act, const uint4 *__restrict__ wqkv,
+                                                                   const float *__restrict__ bqkv, const TileInfo *__restrict__ ti,
+                                                                   uint4 *__restrict__ ctx) {
+    __shared__ uint4 frag[3][2][64];
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = threadIdx.x >> 6;  // j: 0 = Q, 1 = K, 2 = V
+    const int head = blockIdx.x, tt = blockIdx.y;
+    const int tile = j * NH + head;
+    {
+        const uint4 *xin = act + (size_t)tt * (NFB * 2 * 64) + lane;
+        const uint4 *wp = wqkv + (size_t)tile * (KS_H * 64) + lane;
+        uint4 x[KS_H], w[KS_H];
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) { x[ks] = xin[ks * 64]; w[ks] = wp[ks * 64]; }
+        f32x16 acc = {0};
+        const float *b = bqkv + tile * 32;
+        if (j == 2) {  // V: x W (rows = tokens)
+#pragma unroll
+            for (int ks = 0; ks < KS_H; ++ks) acc = mfma(x[ks], w[ks], acc);
+            const float bv = b[lane & 31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += bv;
+        } else {       // Q, K: W^T x^T (rows = head features)
+#pragma unroll
+            for (int ks = 0; ks < KS_H; ++ks) acc = mfma(w[ks], x[ks], acc);
+            const float qs = j == 0 ? kQScaleLog2e : 1.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + b[fi(r, h)]) * qs;
+        }
+        frag[j][0][lane] = acc_to_frag(acc, 0);
+        frag[j][1][lane] = acc_to_frag(acc, 1);
+    }
+    __syncthreads();
+    if (j != 0) return;
+    AttnState st;
+    attn_step(st, frag[0][0][lane], frag[0][1][lane], frag[1][0][lane], frag[1][1][lane], frag[2][0][lane], frag[2][1][lane], true, true, 0,
+              ti[tt].seq_len, h);
+    attn_store(st, ctx + (size_t)tt * (NFB * 2 * 64) + (size_t)(head * 2) * 64 + lane);
+}
+
+int32_t launch_qkv_attention_single(const uint4 *act, const uint4 *wqkv, const float *bqkv, const TileInfo *ti, int n_tiles,
+                                    uint4 *ctx, hipStream_t stream) {
+    qkv_attention_single_kernel<<<dim3(NH, n_tiles), dim3(192), 0, stream>>>(act, wqkv, bqkv, ti, ctx);
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
 
 int32_t launch_attention(const uint4 *qf, const uint4 *kf, const uint4 *vf, const TileInfo *ti, int n_tiles,
                          uint4 *ctx, hipStream_t stream) {

@@ -176,6 +176,9 @@ __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ a
 // the separate file.
 int32_t launch_attention(const uint4 *qf, const uint4 *kf, const uint4 *vf, const TileInfo *ti, int n_tiles,
                          uint4 *ctx, hipStream_t stream);
+// latency path, every sequence of the batch a single tile: QKV projection + attention in one dispatch (encoder_attention.hip)
+int32_t launch_qkv_attention_single(const uint4 *act, const uint4 *wqkv, const float *bqkv, const TileInfo *ti, int n_tiles,
+                                    uint4 *ctx, hipStream_t stream);
 
 // ---------------------------------------------------------------- E3b: output projection + residual + LN
 // Workgroup = 8 waves = 128 tokens (4 token tiles), two waves per SIMD: wave (tile tl, half hf) keeps the tile's context
