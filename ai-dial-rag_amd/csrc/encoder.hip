@@ -334,8 +334,8 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
                 if (arc != MIR_OK) return arc;
             }
             oproj_small_kernel<<<dim3(NFB, nt), dim3(64), 0, s>>>(a1, l.wo, Y);
-            ln_small_kernel<<<dim3(nt), dim3(256), 0, s>>>(Y, a0, l.attn_params, l.attn_params + H, l.attn_params + 2 * H, a1);
-            ffn1_small_kernel<<<dim3(NHT, nt), dim3(64), 0, s>>>(a1, l.wffn, l.ffn_params, hb);
+            ln_ffn1_small_kernel<<<dim3(NHT / 4, nt), dim3(256), 0, s>>>(Y, a0, l.attn_params, l.attn_params + H, l.attn_params + 2 * H, a1,
+                                                                       l.wffn, l.ffn_params, hb);  // LayerNorm -> a1, FFN1 -> hb
             ffn2_small_kernel<<<dim3(NFB, nt), dim3(64), 0, s>>>(hb, l.wffn, Y);
             ln_small_kernel<<<dim3(nt), dim3(256), 0, s>>>(Y, a1, l.ffn_params + FF, l.ffn_params + FF + H,
                                                           l.ffn_params + FF + 2 * H, a0);

@@ -324,12 +324,11 @@ __device__ __forceinline__ void store_acc_rows(float *__restrict__ Y, int tt, in
 // Folding the LayerNorm into the product kernels - the tile's last wave to finish does it, counted with an atomic
 // between two device-scope fences - was measured too: the fences write back / invalidate the XCD's L2 per wave and cost
 // more than the launch they save: 1 tile 425 -> 412 us, 64 tiles 739 -> 1368 us.)
-__global__ __launch_bounds__(256) void ln_small_kernel(const float *__restrict__ Y, const uint4 *__restrict__ resid,
-                                                       const float *__restrict__ bias, const float *__restrict__ gamma,
-                                                       const float *__restrict__ beta, uint4 *__restrict__ act_out) {
-    __shared__ float xs[2][4][64];  // [sum | sum of squares][wave][lane]: running values of the halves
+// (the body: four waves, w = threadIdx.x >> 6; `out_tile` may be global memory or LDS; xs = [2][4][64] floats of LDS)
+__device__ __forceinline__ void ln4_tile(const float *__restrict__ Y, int tt, const uint4 *__restrict__ resid,
+                                         const float *__restrict__ bias, const float *__restrict__ gamma,
+                                         const float *__restrict__ beta, uint4 *out_tile, int lane, int w, float (*xs)[4][64]) {
     constexpr int QB = NFB / 4;
-    const int tt = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // w = 2 * half + quarter of the half
     const bool second = w & 1;
     f32x16 y[QB];
 #pragma unroll
@@ -356,7 +355,14 @@ __global__ __launch_bounds__(256) void ln_small_kernel(const float *__restrict__
     if (second) xs[1][w][lane] = ln_part_sq_from<QB>(y, xs[1][w - 1][lane]);
     __syncthreads();
     const float rstd = rsqrtf(half_sum(xs[1][1][lane] + xs[1][3][lane]) * (1.0f / H) + LN_EPS);
-    ln_part_store<QB, true>(y, QB * w, rstd, gamma, beta, act_out + (size_t)tt * (NFB * 2 * 64), lane, true);
+    ln_part_store<QB, true>(y, QB * w, rstd, gamma, beta, out_tile, lane, true);
+}
+
+__global__ __launch_bounds__(256) void ln_small_kernel(const float *__restrict__ Y, const uint4 *__restrict__ resid,
+                                                       const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, uint4 *__restrict__ act_out) {
+    __shared__ float xs[2][4][64];  // [sum | sum of squares][wave][lane]: running values of the halves
+    ln4_tile(Y, blockIdx.x, resid, bias, gamma, beta, act_out + (size_t)blockIdx.x * (NFB * 2 * 64), threadIdx.x & 63, threadIdx.x >> 6, xs);
 }
 
 __global__ __launch_bounds__(64) MIR_ONE_WAVE void oproj_small_kernel(const uint4 *__restrict__ ctx, const uint4 *__restrict__ wo,
@@ -375,16 +381,14 @@ __global__ __launch_bounds__(64) MIR_ONE_WAVE void oproj_small_kernel(const uint
     store_acc_rows(Y, tt, nt, lane, acc);
 }
 
-__global__ __launch_bounds__(64) MIR_ONE_WAVE void ffn1_small_kernel(const uint4 *__restrict__ act_in,
-                                                        const unsigned char *__restrict__ wffn,
-                                                        const float *__restrict__ b1, uint4 *__restrict__ hbuf) {
-    const int lane = threadIdx.x, h = lane >> 5;
-    const int ht = blockIdx.x, tt = blockIdx.y;
-    const uint4 *xin = act_in + (size_t)tt * (NFB * 2 * 64) + lane;
+// one wave: intermediate tile ht of token tile tt from the tile's activation fragments x -> GELU -> h fragments
+__device__ __forceinline__ void ffn1_wave(const uint4 (&x)[KS_H], const unsigned char *__restrict__ wffn, const float *__restrict__ b1,
+                                          int ht, int tt, uint4 *__restrict__ hbuf, int lane) {
+    const int h = lane >> 5;
     const uint4 *wp = reinterpret_cast<const uint4 *>(wffn + (size_t)(2 * ht) * (24 * 1024)) + lane;  // W1(ht)
-    uint4 x[KS_H], w[KS_H];
+    uint4 w[KS_H];
 #pragma unroll
-    for (int ks = 0; ks < KS_H; ++ks) { x[ks] = xin[ks * 64]; w[ks] = wp[ks * 64]; }
+    for (int ks = 0; ks < KS_H; ++ks) w[ks] = wp[ks * 64];
     float4 bq[4];  // register group g = four consecutive features 8g + 4h ..
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) bq[gq] = *reinterpret_cast<const float4 *>(b1 + 32 * ht + 8 * gq + 4 * h);
@@ -411,6 +415,42 @@ __global__ __launch_bounds__(64) MIR_ONE_WAVE void ffn1_small_kernel(const uint4
     uint4 *ho = hbuf + ((size_t)tt * (2 * NHT) + 2 * ht) * 64 + lane;
     ho[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
     ho[64] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+}
+
+__global__ __launch_bounds__(64) MIR_ONE_WAVE void ffn1_small_kernel(const uint4 *__restrict__ act_in,
+                                                        const unsigned char *__restrict__ wffn,
+                                                        const float *__restrict__ b1, uint4 *__restrict__ hbuf) {
+    const int lane = threadIdx.x;
+    const int ht = blockIdx.x, tt = blockIdx.y;
+    const uint4 *xin = act_in + (size_t)tt * (NFB * 2 * 64) + lane;
+    uint4 x[KS_H];
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) x[ks] = xin[ks * 64];
+    ffn1_wave(x, wffn, b1, ht, tt, hbuf, lane);
+}
+
+// Latency path: the attention block's LayerNorm and FFN1 in one dispatch.  Workgroup (g, tile): its four waves compute
+// the tile's LayerNorm together (ln4_tile, into LDS: every one of the 12 workgroups of a tile repeats it - 48 KiB of
+// accumulators from L2 each - which costs less than the dispatch it saves), workgroup g = 0 also writes it out (the FFN
+// block's residual), then wave w runs intermediate tile 4 g + w from the fragments in LDS.
+__global__ __launch_bounds__(256) void ln_ffn1_small_kernel(const float *__restrict__ Y, const uint4 *__restrict__ resid,
+                                                            const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, uint4 *__restrict__ act_out,
+                                                            const unsigned char *__restrict__ wffn, const float *__restrict__ b1,
+                                                            uint4 *__restrict__ hbuf) {
+    __shared__ float xs[2][4][64];
+    __shared__ uint4 xf[NFB * 2 * 64];  // the tile's LayerNorm output, ACT fragments (24 KiB)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tt = blockIdx.y;
+    ln4_tile(Y, tt, resid, bias, gamma, beta, xf, lane, w, xs);
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        uint4 *out = act_out + (size_t)tt * (NFB * 2 * 64);
+        for (int i = threadIdx.x; i < NFB * 2 * 64; i += 256) out[i] = xf[i];
+    }
+    uint4 x[KS_H];
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) x[ks] = xf[ks * 64 + lane];
+    ffn1_wave(x, wffn, b1, 4 * blockIdx.x + w, tt, hbuf, lane);
 }
 
 __global__ __launch_bounds__(64) MIR_ONE_WAVE void ffn2_small_kernel(const uint4 *__restrict__ hbuf,
