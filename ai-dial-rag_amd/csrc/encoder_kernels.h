@@ -269,7 +269,9 @@ int32_t ffn_prepare();  // once per process: dynamic-LDS attribute
 //   oproj_small    grid (12, tiles)   24 MFMAs -> pre-LayerNorm float32 tile rows in Y
 //   ffn1_small     grid (48, tiles)   24 MFMAs + GELU -> h fragments
 //   ffn2_small     grid (12, tiles)   96 MFMAs over the h fragments -> Y
-//   ln_small       grid (tiles)       Y + bias + residual -> LayerNorm -> ACT
+//   ln_small       grid (tiles)       Y + bias + residual -> LayerNorm -> ACT (four waves per tile)
+//   ln_ffn1_small  grid (12, tiles)   the attention block's LayerNorm (repeated per workgroup, into LDS) + four FFN1 tiles
+//   qkv_attention_single (encoder_attention.hip)  grid (12, tiles): QKV + attention of a head when every sequence is one tile
 // Y: float32 [tile][12 output tiles][16 registers][64 lanes] (the accumulators as they are).
 // Same arithmetic in the same order as the throughput kernels (MFMA chains over k ascending, the same
 // GELU and residual_ln_store): a sequence's embedding is bit-identical on either path, which
