@@ -321,24 +321,35 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         const dim3 g4((nt + 3) / 4), blk(256);
         embed_ln_kernel<<<g4, blk, 0, s>>>(d_ids, d_ti, nt, e->word, e->pos, e->type0, e->emb_g, e->emb_b, a0);
         // latency path (encoder_kernels.h, section L): the same products spread over the weight dimension
+        // Single-tile sequences (queries): the layer's closing LayerNorm moves into the NEXT layer's first dispatch, so a
+        // layer is 4 dispatches instead of 7 (the context goes to the otherwise unused Q buffer: the fused kernel still
+        // reads the residual from a1 while it writes).
+        const bool single = small && nt == s1 - s0;
         for (int li = 0; li < nl && small; ++li) {
             const Layer &l = e->L[li];
             float *Y = reinterpret_cast<float *>(w + o_y);
             uint4 *hb = reinterpret_cast<uint4 *>(w + o_hb);
-            if (nt == s1 - s0) {  // every sequence a single tile (queries): projection + attention in one dispatch
-                const int32_t arc = launch_qkv_attention_single(a0, l.wqkv, l.bqkv, d_ti, nt, a1, s);  // a1 = context
+            uint4 *cx = single ? qf : a1;  // context
+            if (single && li == 0) {
+                const int32_t arc = launch_qkv_attention_single(a0, l.wqkv, l.bqkv, d_ti, nt, cx, s);
+                if (arc != MIR_OK) return arc;
+            } else if (single) {
+                const Layer &p = e->L[li - 1];  // its FFN block's LayerNorm: Y + b2 + residual a1 -> a0
+                const int32_t arc = launch_ln_qkv_attention_single(Y, a1, p.ffn_params + FF, p.ffn_params + FF + H, p.ffn_params + FF + 2 * H,
+                                                                   a0, l.wqkv, l.bqkv, d_ti, nt, cx, s);
                 if (arc != MIR_OK) return arc;
             } else {
                 qkv_small_kernel<<<dim3(36, nt), dim3(64), 0, s>>>(a0, l.wqkv, l.bqkv, qf, kf, vf);
-                const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);  // a1 = context
+                const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, cx, s);
                 if (arc != MIR_OK) return arc;
             }
-            oproj_small_kernel<<<dim3(NFB, nt), dim3(64), 0, s>>>(a1, l.wo, Y);
+            oproj_small_kernel<<<dim3(NFB, nt), dim3(64), 0, s>>>(cx, l.wo, Y);
             ln_ffn1_small_kernel<<<dim3(NHT / 4, nt), dim3(256), 0, s>>>(Y, a0, l.attn_params, l.attn_params + H, l.attn_params + 2 * H, a1,
                                                                        l.wffn, l.ffn_params, hb);  // LayerNorm -> a1, FFN1 -> hb
             ffn2_small_kernel<<<dim3(NFB, nt), dim3(64), 0, s>>>(hb, l.wffn, Y);
-            ln_small_kernel<<<dim3(nt), dim3(256), 0, s>>>(Y, a1, l.ffn_params + FF, l.ffn_params + FF + H,
-                                                          l.ffn_params + FF + 2 * H, a0);
+            if (!single || li == nl - 1)
+                ln_small_kernel<<<dim3(nt), dim3(256), 0, s>>>(Y, a1, l.ffn_params + FF, l.ffn_params + FF + H,
+                                                              l.ffn_params + FF + 2 * H, a0);
         }
         for (int li = 0; li < nl && !small; ++li) {
             const Layer &l = e->L[li];

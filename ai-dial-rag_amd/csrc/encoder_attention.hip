@@ -126,36 +126,45 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict_
 // tile) in ONE dispatch.  Three waves compute the head's Q, K and V fragments exactly as qkv_small_kernel does (same
 // chains, same bias / scale arithmetic), hand them over through LDS, and the first wave runs the one attention step:
 // 12 of a query's 86 dependent dispatches go, and Q / K / V never touch global memory.
+// wave j (0 = Q, 1 = K, 2 = V) of a head: the fragment pair from the tile's activation fragments x, as qkv_small_kernel
+__device__ __forceinline__ void qkv_single_wave(const uint4 (&x)[KS_H], const uint4 *__restrict__ wqkv, const float *__restrict__ bqkv,
+                                                int j, int head, int lane, uint4 (*frag)[2][64]) {
+    const int h = lane >> 5, tile = j * NH + head;
+    const uint4 *wp = wqkv + (size_t)tile * (KS_H * 64) + lane;
+    uint4 w[KS_H];
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) w[ks] = wp[ks * 64];
+    f32x16 acc = {0};
+    const float *b = bqkv + tile * 32;
+    if (j == 2) {  // V: x W (rows = tokens)
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) acc = mfma(x[ks], w[ks], acc);
+        const float bv = b[lane & 31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += bv;
+    } else {       // Q, K: W^T x^T (rows = head features)
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) acc = mfma(w[ks], x[ks], acc);
+        const float qs = j == 0 ? kQScaleLog2e : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + b[fi(r, h)]) * qs;
+    }
+    frag[j][0][lane] = acc_to_frag(acc, 0);
+    frag[j][1][lane] = acc_to_frag(acc, 1);
+}
+
 __global__ __launch_bounds__(192) void qkv_attention_single_kernel(const uint4 *__restrict__ act, const uint4 *__restrict__ wqkv,
                                                                    const float *__restrict__ bqkv, const TileInfo *__restrict__ ti,
                                                                    uint4 *__restrict__ ctx) {
     __shared__ uint4 frag[3][2][64];
     const int lane = threadIdx.x & 63, h = lane >> 5, j = threadIdx.x >> 6;  // j: 0 = Q, 1 = K, 2 = V
     const int head = blockIdx.x, tt = blockIdx.y;
-    const int tile = j * NH + head;
     {
         const uint4 *xin = act + (size_t)tt * (NFB * 2 * 64) + lane;
-        const uint4 *wp = wqkv + (size_t)tile * (KS_H * 64) + lane;
-        uint4 x[KS_H], w[KS_H];
+        uint4 x[KS_H];
 #pragma unroll
-        for (int ks = 0; ks < KS_H; ++ks) { x[ks] = xin[ks * 64]; w[ks] = wp[ks * 64]; }
-        f32x16 acc = {0};
-        const float *b = bqkv + tile * 32;
-        if (j == 2) {  // V: x W (rows = tokens)
-#pragma unroll
-            for (int ks = 0; ks < KS_H; ++ks) acc = mfma(x[ks], w[ks], acc);
-            const float bv = b[lane & 31];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += bv;
-        } else {       // Q, K: W^T x^T (rows = head features)
-#pragma unroll
-            for (int ks = 0; ks < KS_H; ++ks) acc = mfma(w[ks], x[ks], acc);
-            const float qs = j == 0 ? kQScaleLog2e : 1.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + b[fi(r, h)]) * qs;
-        }
-        frag[j][0][lane] = acc_to_frag(acc, 0);
-        frag[j][1][lane] = acc_to_frag(acc, 1);
+        for (int ks = 0; ks < KS_H; ++ks) x[ks] = xin[ks * 64];
+        qkv_single_wave(x, wqkv, bqkv, j, head, lane, frag);
     }
     __syncthreads();
     if (j != 0) return;
@@ -165,9 +174,51 @@ __global__ __launch_bounds__(192) void qkv_attention_single_kernel(const uint4 *
     attn_store(st, ctx + (size_t)tt * (NFB * 2 * 64) + (size_t)(head * 2) * 64 + lane);
 }
 
+// The same with the PREVIOUS layer's closing LayerNorm in front (layers 1 .. 11 of the single-tile path): the workgroup's
+// four waves compute the tile's LayerNorm into LDS (each of a tile's 12 workgroups repeats it; workgroup 0 writes it out
+// for the later residual), waves 0-2 project from those fragments, wave 0 attends.  `ctx` must not be the residual's
+// buffer (other workgroups of the tile may still be reading it).
+__global__ __launch_bounds__(256) void ln_qkv_attention_single_kernel(const float *__restrict__ Y, const uint4 *__restrict__ resid,
+                                                                      const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                                      const float *__restrict__ beta, uint4 *__restrict__ act_out,
+                                                                      const uint4 *__restrict__ wqkv, const float *__restrict__ bqkv,
+                                                                      const TileInfo *__restrict__ ti, uint4 *__restrict__ ctx) {
+    __shared__ float xs[2][4][64];
+    __shared__ uint4 xf[NFB * 2 * 64];  // the tile's LayerNorm output, ACT fragments (24 KiB)
+    __shared__ uint4 frag[3][2][64];
+    const int lane = threadIdx.x & 63, h = lane >> 5, w = threadIdx.x >> 6;
+    const int head = blockIdx.x, tt = blockIdx.y;
+    ln4_tile(Y, tt, resid, bias, gamma, beta, xf, lane, w, xs);
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        uint4 *out = act_out + (size_t)tt * (NFB * 2 * 64);
+        for (int i = threadIdx.x; i < NFB * 2 * 64; i += 256) out[i] = xf[i];
+    }
+    if (w < 3) {
+        uint4 x[KS_H];
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) x[ks] = xf[ks * 64 + lane];
+        qkv_single_wave(x, wqkv, bqkv, w, head, lane, frag);
+    }
+    __syncthreads();
+    if (w != 0) return;
+    AttnState st;
+    attn_step(st, frag[0][0][lane], frag[0][1][lane], frag[1][0][lane], frag[1][1][lane], frag[2][0][lane], frag[2][1][lane], true, true, 0,
+              ti[tt].seq_len, h);
+    attn_store(st, ctx + (size_t)tt * (NFB * 2 * 64) + (size_t)(head * 2) * 64 + lane);
+}
+
 int32_t launch_qkv_attention_single(const uint4 *act, const uint4 *wqkv, const float *bqkv, const TileInfo *ti, int n_tiles,
                                     uint4 *ctx, hipStream_t stream) {
     qkv_attention_single_kernel<<<dim3(NH, n_tiles), dim3(192), 0, stream>>>(act, wqkv, bqkv, ti, ctx);
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
+int32_t launch_ln_qkv_attention_single(const float *Y, const uint4 *resid, const float *bias, const float *gamma, const float *beta,
+                                       uint4 *act_out, const uint4 *wqkv, const float *bqkv, const TileInfo *ti, int n_tiles,
+                                       uint4 *ctx, hipStream_t stream) {
+    ln_qkv_attention_single_kernel<<<dim3(NH, n_tiles), dim3(256), 0, stream>>>(Y, resid, bias, gamma, beta, act_out, wqkv, bqkv, ti, ctx);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }

@@ -348,5 +348,42 @@ __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 
 }
 
 
+// The latency path's LayerNorm of one token tile by a workgroup's first four waves (ln_small_kernel and the fused kernels
+// that repeat it: encoder_kernels.h, encoder_attention.hip).
+// (the body: four waves, w = threadIdx.x >> 6; `out_tile` may be global memory or LDS; xs = [2][4][64] floats of LDS)
+__device__ __forceinline__ void ln4_tile(const float *__restrict__ Y, int tt, const uint4 *__restrict__ resid,
+                                         const float *__restrict__ bias, const float *__restrict__ gamma,
+                                         const float *__restrict__ beta, uint4 *out_tile, int lane, int w, float (*xs)[4][64]) {
+    constexpr int QB = NFB / 4;
+    const bool second = w & 1;
+    f32x16 y[QB];
+#pragma unroll
+    for (int i = 0; i < QB; ++i) {
+        const float4 *yi = reinterpret_cast<const float4 *>(Y + (((size_t)tt * NFB + QB * w + i) * 16) * 64) + lane;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 v = yi[c * 64];
+            y[i][4 * c + 0] = v.x; y[i][4 * c + 1] = v.y; y[i][4 * c + 2] = v.z; y[i][4 * c + 3] = v.w;
+        }
+    }
+    ln_part_apply<QB>(y, QB * w, resid + (size_t)tt * (NFB * 2 * 64), bias, lane);
+    if (!second) xs[0][w][lane] = ln_part_sum_from<QB>(y, 0.f);
+    __syncthreads();
+    if (second) xs[0][w][lane] = ln_part_sum_from<QB>(y, xs[0][w - 1][lane]);
+    __syncthreads();
+    const float mean = half_sum(xs[0][1][lane] + xs[0][3][lane]) * (1.0f / H);  // half A + half B
+#pragma unroll
+    for (int f = 0; f < QB; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[f][r] = y[f][r] - mean;
+    if (!second) xs[1][w][lane] = ln_part_sq_from<QB>(y, 0.f);
+    __syncthreads();
+    if (second) xs[1][w][lane] = ln_part_sq_from<QB>(y, xs[1][w - 1][lane]);
+    __syncthreads();
+    const float rstd = rsqrtf(half_sum(xs[1][1][lane] + xs[1][3][lane]) * (1.0f / H) + LN_EPS);
+    ln_part_store<QB, true>(y, QB * w, rstd, gamma, beta, out_tile, lane, true);
+}
+
+
 }  // namespace enc
 }  // namespace mir

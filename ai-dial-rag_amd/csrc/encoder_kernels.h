@@ -179,6 +179,10 @@ int32_t launch_attention(const uint4 *qf, const uint4 *kf, const uint4 *vf, cons
 // latency path, every sequence of the batch a single tile: QKV projection + attention in one dispatch (encoder_attention.hip)
 int32_t launch_qkv_attention_single(const uint4 *act, const uint4 *wqkv, const float *bqkv, const TileInfo *ti, int n_tiles,
                                     uint4 *ctx, hipStream_t stream);
+// ... with the previous layer's closing LayerNorm (Y + bias + residual -> act_out) in front
+int32_t launch_ln_qkv_attention_single(const float *Y, const uint4 *resid, const float *bias, const float *gamma, const float *beta,
+                                       uint4 *act_out, const uint4 *wqkv, const float *bqkv, const TileInfo *ti, int n_tiles,
+                                       uint4 *ctx, hipStream_t stream);
 
 // ---------------------------------------------------------------- E3b: output projection + residual + LN
 // Workgroup = 8 waves = 128 tokens (4 token tiles), two waves per SIMD: wave (tile tl, half hf) keeps the tile's context
@@ -271,7 +275,8 @@ int32_t ffn_prepare();  // once per process: dynamic-LDS attribute
 //   ffn2_small     grid (12, tiles)   96 MFMAs over the h fragments -> Y
 //   ln_small       grid (tiles)       Y + bias + residual -> LayerNorm -> ACT (four waves per tile)
 //   ln_ffn1_small  grid (12, tiles)   the attention block's LayerNorm (repeated per workgroup, into LDS) + four FFN1 tiles
-//   qkv_attention_single (encoder_attention.hip)  grid (12, tiles): QKV + attention of a head when every sequence is one tile
+//   qkv_attention_single, ln_qkv_attention_single (encoder_attention.hip)  grid (12, tiles): QKV + attention of a head when
+//                  every sequence is one tile; the second with the previous layer's closing LayerNorm in front
 // Y: float32 [tile][12 output tiles][16 registers][64 lanes] (the accumulators as they are).
 // Same arithmetic in the same order as the throughput kernels (MFMA chains over k ascending, the same
 // GELU and residual_ln_store): a sequence's embedding is bit-identical on either path, which
@@ -326,40 +331,6 @@ __device__ __forceinline__ void store_acc_rows(float *__restrict__ Y, int tt, in
 // Folding the LayerNorm into the product kernels - the tile's last wave to finish does it, counted with an atomic
 // between two device-scope fences - was measured too: the fences write back / invalidate the XCD's L2 per wave and cost
 // more than the launch they save: 1 tile 425 -> 412 us, 64 tiles 739 -> 1368 us.)
-// (the body: four waves, w = threadIdx.x >> 6; `out_tile` may be global memory or LDS; xs = [2][4][64] floats of LDS)
-__device__ __forceinline__ void ln4_tile(const float *__restrict__ Y, int tt, const uint4 *__restrict__ resid,
-                                         const float *__restrict__ bias, const float *__restrict__ gamma,
-                                         const float *__restrict__ beta, uint4 *out_tile, int lane, int w, float (*xs)[4][64]) {
-    constexpr int QB = NFB / 4;
-    const bool second = w & 1;
-    f32x16 y[QB];
-#pragma unroll
-    for (int i = 0; i < QB; ++i) {
-        const float4 *yi = reinterpret_cast<const float4 *>(Y + (((size_t)tt * NFB + QB * w + i) * 16) * 64) + lane;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 v = yi[c * 64];
-            y[i][4 * c + 0] = v.x; y[i][4 * c + 1] = v.y; y[i][4 * c + 2] = v.z; y[i][4 * c + 3] = v.w;
-        }
-    }
-    ln_part_apply<QB>(y, QB * w, resid + (size_t)tt * (NFB * 2 * 64), bias, lane);
-    if (!second) xs[0][w][lane] = ln_part_sum_from<QB>(y, 0.f);
-    __syncthreads();
-    if (second) xs[0][w][lane] = ln_part_sum_from<QB>(y, xs[0][w - 1][lane]);
-    __syncthreads();
-    const float mean = half_sum(xs[0][1][lane] + xs[0][3][lane]) * (1.0f / H);  // half A + half B
-#pragma unroll
-    for (int f = 0; f < QB; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y[f][r] = y[f][r] - mean;
-    if (!second) xs[1][w][lane] = ln_part_sq_from<QB>(y, 0.f);
-    __syncthreads();
-    if (second) xs[1][w][lane] = ln_part_sq_from<QB>(y, xs[1][w - 1][lane]);
-    __syncthreads();
-    const float rstd = rsqrtf(half_sum(xs[1][1][lane] + xs[1][3][lane]) * (1.0f / H) + LN_EPS);
-    ln_part_store<QB, true>(y, QB * w, rstd, gamma, beta, out_tile, lane, true);
-}
-
 __global__ __launch_bounds__(256) void ln_small_kernel(const float *__restrict__ Y, const uint4 *__restrict__ resid,
                                                        const float *__restrict__ bias, const float *__restrict__ gamma,
                                                        const float *__restrict__ beta, uint4 *__restrict__ act_out) {
