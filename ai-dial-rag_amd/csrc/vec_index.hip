@@ -223,7 +223,7 @@ static int32_t check_create_args(int64_t n, int32_t d, int32_t dtype, mir_index 
 
 // Threshold pre-pass of the wide scans: kSampleWgs workgroups x up to kSampleTilesPerWg tiles (32K rows)
 constexpr int kSampleWgs = 256;
-constexpr int kSampleTilesPerWg = 4;
+constexpr int kSampleTilesPerWg = 4;  // (8 / 16 / 32 tiles per workgroup measured within 0.5 % on 10M x 384, 1-4 % slower on 6.25M x 1024 float16)
 
 // carve helper
 struct Carver {
