@@ -466,6 +466,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 code path on a box with ONE GPU (every rank on device 0, collectives over gloo): exercises the
+    # sharding, the gathered blobs and the merge kernels end to end; its numbers mean nothing.
+    rehearsal = os.environ.get("MIR_BENCH_ONE_GPU_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if nat.device_count() < 1:
@@ -474,7 +479,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     n, d, B, k = args.rows, args.dim, args.batch, args.k
     lo, hi = shard_bounds(n, world, rank)
@@ -609,6 +617,7 @@ def main():
         "uncertain_queries": 0,  # never returned since the exact pass exists (flag bit 1)
         "exact_pass_queries": int(flags_total.item()) // 2,  # queries the filter could not prove (flag bit 2), recomputed exactly
         "preconditioning_steps": precondition,
+        **({"rehearsal_one_gpu": True} if rehearsal else {}),
         "index_build_s": {"generate": round(t_gen, 2), "upload_pack_norms": round(t_build, 2)},
     }
 
