@@ -186,7 +186,9 @@ int32_t mir_wordpiece_encode(const mir_wordpiece *t, const char *texts, const in
     if (n == 0) return MIR_OK;
     MIR_REQUIRE(texts && text_ptr && out_ids && out_len && fallback, "NULL buffer");
     int nthr = threads > 0 ? threads : (int)std::min<unsigned>(32, std::max<unsigned>(1, std::thread::hardware_concurrency()));
-    nthr = std::max(1, std::min(nthr, (n + 15) / 16));
+    // at least 64 texts (~0.5 ms) per thread: the index build calls this from up to 32 Python threads at once with outer
+    // batches of 128 texts, and 8 threads per call were 256 on the cores of one GPU's share of the host
+    nthr = std::max(1, std::min(nthr, (n + 63) / 64));
     auto work = [&](int lo, int hi) {
         std::vector<int32_t> ids;
         std::vector<uint32_t> norm;
