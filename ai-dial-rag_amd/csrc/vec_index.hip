@@ -447,9 +447,9 @@ static int32_t launch_scan_h16(const mir_index *ix, const uint4 *qfrag_g, const 
     const int ns = h16_ring_stages(klist);
 #define MIR_H16_LAUNCH(KS, NSV)                                                                                        \
     do {                                                                                                               \
-        auto kern = sample ? scan_topk_h16_kernel<KS, KIND, true, NSV> : scan_topk_h16_kernel<KS, KIND, false, NSV>;   \
+        auto kern = sample ? scan_topk_h16_kernel<KS, KIND, true, NSV, H16_QT> : scan_topk_h16_kernel<KS, KIND, false, NSV, H16_QT>;   \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qfrag_g, qscale_g, n_rows, tile0, n_tiles, nq, klist, part_g, \
+        kern<<<dim3(nwg), dim3(512 / H16_QT), lds, stream>>>(ix->d_split, aux, qfrag_g, qscale_g, n_rows, tile0, n_tiles, nq, klist, part_g, \
                                                     gthr_g);                                                           \
     } while (0)
     // ksteps = 64: 512 < d <= 1024, 32 k-steps of 32 columns (128 VGPRs of query fragments per wave); 32: 256 < d <= 512
@@ -670,11 +670,11 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
 static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
     // one exact-pass workgroup per CU, fewer on small shards (a workgroup's 16 waves take a row each)
     pl->exact_grid = (int)std::max<int64_t>(1, std::min<int64_t>(ix->num_cus, (ix->n + kExactWaves - 1) / kExactWaves));
-    pl->klist = std::min(k + kListMargin, kMaxList);
+    pl->klist = std::min(k + (ix->native16 ? kH16ListMargin : kListMargin), kMaxList);
     // The reference takes any `limit` (embeddings_index.py:58,81).  Beyond what the filter's per-lane candidate
     // lists hold (LDS), an index that could actually return that many rows is searched by the exact pass alone.
     const bool wide64 = wide64_split(ix);
-    const bool lists_fit = k + kListMargin <= kMaxList;
+    const bool lists_fit = k + (ix->native16 ? kH16ListMargin : kListMargin) <= kMaxList;
     if (!lists_fit && ix->n > (int64_t)kMaxList) {  // (n <= 64: every row fits the lists)
         pl->exact_only = true;
         pl->ngroups = 0;
@@ -689,14 +689,14 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
         pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), want16));
         return MIR_OK;
     }
-    if ((ix->layout16 || ix->native16) && pl->klist > kQ16MaxList) {  // k > 52 on a 16-queries-per-wave index: the exact pass alone (any n)
+    if ((ix->layout16 || ix->native16) && pl->klist > kQ16MaxList) {  // k > 52 (48 on a float16-native index) on a 16-queries-per-wave index: the exact pass alone (any n)
         pl->exact_only = true;
         pl->ngroups = 0;
         pl->qpw = 32;
         pl->nwg = 1;
         return MIR_OK;
     }
-    if (ix->layout16 || ix->native16) {  // the images only the 16-queries-per-wave kernels read: they take every k their buffers hold (k <= 52)
+    if (ix->layout16 || ix->native16) {  // the images only the 16-queries-per-wave kernels read: they take every k their buffers hold (k <= 52; 48 on a float16-native index)
         pl->qpw = kQ16Queries;
         pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
         pl->nwg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), (int64_t)ix->n_tiles));

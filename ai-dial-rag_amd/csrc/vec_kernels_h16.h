@@ -31,14 +31,23 @@ constexpr double kH16RelErr = 6.0e-4;
 #ifndef H16_STAGE_KS
 #define H16_STAGE_KS 16
 #endif
+#ifndef H16_QT
+#define H16_QT 1  // query tiles per wave of the float16 scan (see scan_topk_h16_kernel)
+#endif
 #ifndef H16_MAX_STAGES
 #define H16_MAX_STAGES 4  // (launch_scan_h16 instantiates 2, 3 and 4)
 #endif
 static_assert(H16_MAX_STAGES <= 4, "add the instances to launch_scan_h16");
 constexpr int kH16StageKs = H16_STAGE_KS;  // k-steps of 32 columns per ring stage (2 KiB each)
-// a query's candidate buffer: klist kept entries + room for 8 appended ones between compactions (16 would push the usual
-// klist = 18 past the LDS a four-stage ring leaves)
-__host__ __device__ constexpr int h16_buffer(int klist) { return klist + 8 < 64 ? klist + 8 : 64; }
+// The lists of this scan are k + kH16ListMargin long, half as much again as the float32 scans' margin: its bound is 30 x
+// theirs, and with k + 8 about one random query in 10^4 on 6.25M x 1024 rows had its k-th and klist-th candidates closer
+// than the bound and took the exact pass (10 ms there - ~6 % of the average throughput); the gap to the (k + 12)-th is 1.5 x
+// as wide in the mean and the chance of falling under the bound ~1e-9 on the same data.  (k + 16 measured 3-5 % slower
+// per step - longer lists to fill, write, merge and re-score - k + 12 about 2 %.)
+constexpr int kH16ListMargin = 12;
+// a query's candidate buffer: klist kept entries + room for 6 appended ones between compactions (k = 10: 28 entries; a
+// four-stage ring leaves room for 32)
+__host__ __device__ constexpr int h16_buffer(int klist) { return klist + 6 < 64 ? klist + 6 : 64; }
 __host__ __device__ constexpr int h16_ring_stages(int klist) {  // 160 KiB of LDS: the most stages that fit beside the buffers
     int ns = H16_MAX_STAGES;
     while (ns > 2 && ns * kH16StageKs * 2048 + h16_buffer(klist) * kQ16Queries * 8 > 160 * 1024) --ns;
@@ -128,58 +137,70 @@ __global__ __launch_bounds__(64) void prep_queries_h16_kernel(const double *__re
     qfrag[(int64_t)blk * 64 + lane] = pack8(hi);
 }
 
-template <int KS32, int KIND, bool SAMPLE, int NS>
-__global__ __launch_bounds__(512, 2) void scan_topk_h16_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
-                                                               const uint4 *__restrict__ qfrag, const float *__restrict__ qscale_inv,
-                                                               uint32_t n_rows, uint32_t tile0, uint32_t n_tiles, int nq, int klist,
-                                                               uint64_t *__restrict__ part, const uint64_t *__restrict__ gthr) {
+// QT = query tiles (16 queries each) per wave: 1 -> 8 waves, two per SIMD; 2 -> 4 waves, one per SIMD, each 1-KiB document
+// fragment read from LDS once per wave feeds BOTH query tiles' MFMAs (half the LDS reads per byte streamed; the wave then
+// holds 256 VGPRs of query fragments at d = 1024).
+template <int KS32, int KIND, bool SAMPLE, int NS, int QT>
+__global__ __launch_bounds__(512 / QT, QT == 1 ? 2 : 1) void scan_topk_h16_kernel(
+    const uint4 *__restrict__ docs, const float *__restrict__ aux, const uint4 *__restrict__ qfrag, const float *__restrict__ qscale_inv,
+    uint32_t n_rows, uint32_t tile0, uint32_t n_tiles, int nq, int klist, uint64_t *__restrict__ part, const uint64_t *__restrict__ gthr) {
     // this launch walks tiles [tile0, tile0 + n_tiles) of the shard
     static_assert(KS32 % kH16StageKs == 0, "h16 scan: d padded to a multiple of 512");
+    static_assert(QT == 1 || QT == 2, "query tiles per wave");
+    constexpr int WAVES = 8 / QT;
     constexpr int SPT = KS32 / kH16StageKs;   // stages per tile
     constexpr int SB = kH16StageKs * 2;       // 1-KiB blocks per stage
     constexpr int STAGE_U4 = SB * 64;
     constexpr int TILE_U4 = SPT * STAGE_U4;
-    constexpr int PPW = SB / 8;               // DMA pieces per wave per stage
+    constexpr int PPW = SB / WAVES;           // DMA pieces per wave per stage
     constexpr int D = NS - 1;                 // stages in flight beyond the one being read
+    static_assert(SB % WAVES == 0, "pieces per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *ring = reinterpret_cast<uint4 *>(smem);                                      // [NS][STAGE_U4]
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + (size_t)NS * STAGE_U4 * 16);  // [128][cap]
 
     const int tid = threadIdx.x, lane = tid & 63, qc = lane & 15, jg = lane >> 4;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qloc = wave8 * 16 + qc;              // this lane's query in the launch
-    const bool lane_live = qloc < nq;
-    const bool active = nq > wave8 * 16;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t G = gridDim.x;
     const int cap = h16_buffer(klist);
-    uint64_t *mylist = lists + (size_t)wave8 * 16 * cap;  // this wave's 16 buffers, query-major
     const unsigned long long colmask = 0x0001000100010001ull << qc;  // the four lanes of this lane's column
-    // per-query state, replicated in the four lanes of a column
-    const uint64_t seed_thr = (SAMPLE || !lane_live) ? 0 : gthr[qloc];
-    uint64_t thr = seed_thr;   // admission threshold: max(seed, list minimum once the list is full)
-    int cnt = 0;               // entries in the query's list
-    float best = -__builtin_inff();
-    const float inv_s = lane_live ? qscale_inv[qloc] : 0.f;
-
-    f16x8 qh[KS32];
-    {
-        const uint4 *qs = qfrag + (size_t)wave8 * KS32 * 64 + lane;
+    // per query tile u of the wave: the lane's query and its state (replicated in the four lanes of a column)
+    int qloc[QT], cnt[QT];
+    bool lane_live[QT], active[QT];
+    uint64_t thr[QT];   // admission threshold: max(seed, list minimum once the list is full)
+    float best[QT], inv_s[QT];
+    f16x8 qh[QT][KS32];
+    bool any_active = false;
 #pragma unroll
-        for (int s = 0; s < KS32; ++s) qh[s] = __builtin_bit_cast(f16x8, qs[s * 64]);
+    for (int u = 0; u < QT; ++u) {
+        const int t16 = wv * QT + u;  // the query tile's index in the launch
+        qloc[u] = t16 * 16 + qc;
+        lane_live[u] = qloc[u] < nq;
+        active[u] = nq > t16 * 16;
+        any_active |= active[u];
+        thr[u] = (SAMPLE || !lane_live[u]) ? 0 : gthr[qloc[u]];
+        cnt[u] = 0;
+        best[u] = -__builtin_inff();
+        inv_s[u] = lane_live[u] ? qscale_inv[qloc[u]] : 0.f;
+        const uint4 *qs = qfrag + (size_t)t16 * KS32 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) qh[u][s] = __builtin_bit_cast(f16x8, qs[s * 64]);
     }
     const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + G - 1) / G : 0;
     const uint32_t NG = my_tiles * SPT;
 
     auto issue = [&](uint32_t g) {
         const uint32_t tile = tile0 + blockIdx.x + (g / SPT) * G;
-        const uint4 *src = docs + (size_t)tile * TILE_U4 + (size_t)(g % SPT) * STAGE_U4 + (wave8 * PPW) * 64 + lane;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave8 * PPW) * 64) * 16);
+        const uint4 *src = docs + (size_t)tile * TILE_U4 + (size_t)(g % SPT) * STAGE_U4 + (wv * PPW) * 64 + lane;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wv * PPW) * 64) * 16);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
     };
     // ordinary loads are complete before the first DMA (the counted waits below count DMAs only)
 #pragma unroll
-    for (int s = 0; s < KS32; ++s) asm volatile("" : "+v"(qh[s]));
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) asm volatile("" : "+v"(qh[u][s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t g = 0; g < (uint32_t)D && g < NG; ++g) issue(g);
 
@@ -189,22 +210,22 @@ __global__ __launch_bounds__(512, 2) void scan_topk_h16_kernel(const uint4 *__re
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only in the last D - 1 stages of the launch
     };
 
-    // ranking values of this lane's 8 rows from the (scaled) dot products
-    auto to_values = [&](const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], float (&v)[8]) {
+    // ranking values of this lane's 8 rows from the (scaled) dot products of query tile u
+    auto to_values = [&](int u, const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], float (&v)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float d0 = c0[i] * inv_s, d1 = c1[i] * inv_s;
+            const float d0 = c0[i] * inv_s[u], d1 = c1[i] * inv_s[u];
             v[i] = KIND == SCAN_IP ? d0 : KIND == SCAN_L2 ? fmaf(2.0f, d0, -ax[i]) : d0 * ax[i];
             v[4 + i] = KIND == SCAN_IP ? d1 : KIND == SCAN_L2 ? fmaf(2.0f, d1, -ax[4 + i]) : d1 * ax[4 + i];
         }
     };
 
-    const Q16Lists L{mylist, cap, klist, lane, qc, jg, colmask};  // buffers, compaction, appends: vec_kernels_q16.h
-
     for (uint32_t ts = 0; ts < my_tiles; ++ts) {
         const uint32_t t = tile0 + blockIdx.x + ts * G;
         const uint32_t row0 = t * kTileRows + 4 * jg;  // this lane's rows: row0 + 16 rh + i
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 c0[QT], c1[QT];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) { c0[u] = f32x4{0.f, 0.f, 0.f, 0.f}; c1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         float ax[8] = {};
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
@@ -212,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void scan_topk_h16_kernel(const uint4 *__re
             wait_stage(g);
             __builtin_amdgcn_s_barrier();
             if (g + D < NG) issue(g + D);
-            if (active) {
+            if (any_active) {
                 if (j == 0 && KIND != SCAN_IP) q16_load_aux(aux, t, jg, ax);
                 const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
                 uint4 f0[3], f1[3];
@@ -225,41 +246,52 @@ __global__ __launch_bounds__(512, 2) void scan_topk_h16_kernel(const uint4 *__re
                         f1[(s + 2) % 3] = st[(2 * (s + 2) + 1) * 64];
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f0[s % 3]), qh[j * kH16StageKs + s], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f1[s % 3]), qh[j * kH16StageKs + s], c1, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < QT; ++u) {
+                        c0[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f0[s % 3]), qh[u][j * kH16StageKs + s], c0[u], 0, 0, 0);
+                        c1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f1[s % 3]), qh[u][j * kH16StageKs + s], c1[u], 0, 0, 0);
+                    }
                 }
             }
         }
-        if (!active) continue;
-        float v[8];
-        to_values(c0, c1, ax, v);
-        const float mx = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
-        if (SAMPLE) {
-            // thresholds and list values are in the same (hi-only) units: the maximum itself is the bound (sample tiles are whole tiles)
-            if (lane_live) best = fmaxf(best, mx);
-            continue;
-        }
-        // can any row reach this lane's threshold?  (NaN passes: `!(x < y)`; an open list takes everything)
-        const float vmin0 = thr == 0 ? -__builtin_inff() : key_value(thr);
-        if (!__any(lane_live && !(mx < vmin0))) continue;
-        uint32_t pm = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const uint32_t row = row0 + 16 * (r >> 2) + (r & 3);
-            pm |= (uint32_t)(lane_live && row < n_rows && !(v[r] < vmin0)) << r;
+        for (int u = 0; u < QT; ++u) {
+            if (!active[u]) continue;
+            float v[8];
+            to_values(u, c0[u], c1[u], ax, v);
+            const float mx = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+            if (SAMPLE) {
+                // thresholds and list values are in the same (hi-only) units: the maximum itself is the bound (sample tiles are whole tiles)
+                if (lane_live[u]) best[u] = fmaxf(best[u], mx);
+                continue;
+            }
+            // can any row reach this lane's threshold?  (NaN passes: `!(x < y)`; an open list takes everything)
+            const float vmin0 = thr[u] == 0 ? -__builtin_inff() : key_value(thr[u]);
+            if (!__any(lane_live[u] && !(mx < vmin0))) continue;
+            uint32_t pm = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t row = row0 + 16 * (r >> 2) + (r & 3);
+                pm |= (uint32_t)(lane_live[u] && row < n_rows && !(v[r] < vmin0)) << r;
+            }
+            const Q16Lists L{lists + (size_t)(wv * QT + u) * 16 * cap, cap, klist, lane, qc, jg, colmask};  // vec_kernels_q16.h
+            L.append(pm, v, row0, cnt[u], thr[u]);
         }
-        L.append(pm, v, row0, cnt, thr);
     }
-    if (SAMPLE) {
-        // four lanes hold a query's column: two values per query, each the maximum over distinct rows
-        const float o = __shfl_xor(best, 16, 64);
-        const float b2 = fmaxf(best, o);
-        if (lane_live && (jg == 0 || jg == 2))
-            reinterpret_cast<float *>(part)[((size_t)blockIdx.x * kQ16Queries + qloc) * 2 + (jg >> 1)] = b2;
-        return;
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        if (SAMPLE) {
+            // four lanes hold a query's column: two values per query, each the maximum over distinct rows
+            const float o = __shfl_xor(best[u], 16, 64);
+            const float b2 = fmaxf(best[u], o);
+            if (lane_live[u] && (jg == 0 || jg == 2))
+                reinterpret_cast<float *>(part)[((size_t)blockIdx.x * kQ16Queries + qloc[u]) * 2 + (jg >> 1)] = b2;
+        } else {
+            // every buffer compacted once more (sorted, best first) and written out, empty entries as 0: [128][klist] per workgroup
+            const Q16Lists L{lists + (size_t)(wv * QT + u) * 16 * cap, cap, klist, lane, qc, jg, colmask};
+            L.write_out(part + (size_t)blockIdx.x * kQ16Queries * klist + (size_t)(wv * QT + u) * 16 * klist, cnt[u], thr[u]);
+        }
     }
-    // ---- every buffer compacted once more (sorted, best first) and written out, empty entries as 0: [128][klist] per workgroup ----
-    L.write_out(part + (size_t)blockIdx.x * kQ16Queries * klist + (size_t)wave8 * 16 * klist, cnt, thr);
 }
 
 }  // namespace mir

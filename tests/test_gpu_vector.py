@@ -312,10 +312,10 @@ def test_float16_native_scan_shapes(amd, metric):
             np.testing.assert_allclose(dist[i], wdist, rtol=1e-12, atol=2e-7 * max(1.0, float(np.abs(wdist).max())))
     if metric == "sqeuclidean_dist":
         assert list(rows[5, :3]) == [31, 32, n - 1]
-    # k up to the float16 scan's list capacity (52) runs the filter scan - whose bound (2^-11 |q| max|d|, one float16
-    # product per fragment) may or may not prove a query on rows whose norms differ 15-fold as here; above it the exact
-    # pass answers alone.  Either way the ids are the reference's.
-    for k, must_be_exact in ((52, False), (53, True)):
+    # k up to the float16 scan's list capacity (48: lists of k + 12 <= 60) runs the filter scan - whose bound
+    # (2^-11 |q| max|d|, one float16 product per fragment) may or may not prove a query on rows whose norms differ 15-fold
+    # as here; above it the exact pass answers alone.  Either way the ids are the reference's.
+    for k, must_be_exact in ((48, False), (49, True)):
         _, _, rows_k, _, cnt_k, flags_k = dev.search(qs[:2], k, metric)
         assert (cnt_k == k).all() and flags_k[1] in ((amd.nat.FLAG_EXACT_PASS,) if must_be_exact else (0, amd.nat.FLAG_EXACT_PASS))
         for i in range(2):
