@@ -98,3 +98,27 @@ def test_rrf_fuse_matches_oracle(nat):
         assert got == of.weighted_reciprocal_rank(lists, weights)
     with pytest.raises(ValueError):
         weighted_reciprocal_rank([[]], [1.0, 1.0])
+
+
+def test_fuse_batch_full_and_ragged_lists(nat):
+    """`fuse_batch` (the hybrid step's batched fusion over mir_rrf_fuse_batch): full lists take the side-by-side fast path,
+    a batch with a short list the per-element placement - both must equal the oracle's fusion query by query."""
+    from aidial_rag_amd.retrievers.sharded_bm25 import fuse_batch
+    from oracle import fusion as of
+
+    rng = np.random.default_rng(3)
+    b, k = 9, 7
+    for ragged in (False, True):
+        ids_v = rng.integers(0, 40, (b, k)).astype(np.int64)
+        ids_t = rng.integers(0, 40, (b, k)).astype(np.int64)
+        cnt_v = np.full(b, k, np.int32)
+        cnt_t = np.full(b, k, np.int32)
+        if ragged:
+            cnt_t[2], cnt_v[5], cnt_t[5] = 3, 0, 1
+        ids, scores, cnt = fuse_batch([(ids_v, cnt_v), (ids_t, cnt_t)], (1.0, 1.0), 60)
+        for q in range(b):
+            lists = [[(int(x), 0) for x in ids_v[q, : cnt_v[q]]], [(int(x), 0) for x in ids_t[q, : cnt_t[q]]]]
+            want = of.weighted_reciprocal_rank(lists, [1.0, 1.0])
+            assert [(int(x), 0) for x in ids[q, : cnt[q]]] == want, (ragged, q)
+            sc = of.rrf_scores(lists, [1.0, 1.0])
+            np.testing.assert_array_equal(scores[q, : cnt[q]], [sc[key] for key in want])
