@@ -14,8 +14,14 @@ using namespace mir::enc;
 
 namespace {
 
-constexpr int kMaxTilesPerPass = 3072;  // 98 304 tokens per pass (~0.4 GB of activations): 1024 waves x 3 tiles in qkv_kernel
-                                        // = one round of the chip, 768 four-tile blocks = three rounds elsewhere
+// Token tiles per pass (the workspace holds five activation buffers of 24 KiB per tile, twice: 3 GB of the 288).  3072
+// tiles (98 304 tokens) fill the chip exactly once in qkv_kernel; larger passes amortise the per-pass work and the
+// launch tails: 8192 chunks of ~220 tokens ran at 62.9k chunks/s with 3072, 63.9k with 6144, 64.8k with 9216 and
+// 65.5k with 12288 tiles per pass (52.4k with 1536).
+#ifndef ENC_PASS_TILES
+#define ENC_PASS_TILES 12288
+#endif
+constexpr int kMaxTilesPerPass = ENC_PASS_TILES;
 
 // Pack a Hugging Face Linear weight W[out][in] (y = x W^T + b) into MFMA A-fragment
 // order for out^T = W x^T: block (nt, ks) = 64 lanes x 8 halfs, lane (row = l&31,
