@@ -364,7 +364,7 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
                 const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);  // a1 = context
                 if (arc != MIR_OK) return arc;
             }
-            oproj_ln_kernel<<<g4, dim3(512), OPROJ_LDS_BYTES, s>>>(a1, nt, l.wo, l.attn_params, l.attn_params + H, l.attn_params + 2 * H,
+            oproj_ln_kernel<<<dim3(std::min((nt + 3) / 4, OPROJ_MAX_GRID)), dim3(512), OPROJ_LDS_BYTES, s>>>(a1, nt, l.wo, l.attn_params, l.attn_params + H, l.attn_params + 2 * H,
                                                                    a0, a1);  // in place: a tile's two waves read its context before the first barrier and write after the last
             {
                 const int32_t frc = launch_ffn(a1, nt, l.wffn, l.ffn_params, a0, s);

@@ -150,6 +150,15 @@ __device__ __forceinline__ void enc_glds16(const void *gsrc, uint32_t lds_byte_a
                  : "v"(gsrc), "s"(lds_byte_addr)
                  : "memory");
 }
+// the same with a wave-uniform base in SGPRs and a 32-bit per-lane byte offset: a kernel that issues many pieces per wave keeps
+// ONE offset register instead of a 64-bit address per piece
+__device__ __forceinline__ void enc_glds16_s(const void *uniform_base, uint32_t lane_byte_off, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_off), "s"(uniform_base), "s"(lds_byte_addr)
+                 : "memory");
+}
 __device__ __forceinline__ uint32_t enc_lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
@@ -174,15 +183,16 @@ struct TileInfo {
 // residual_ln_part: the work of one wave on feature blocks [FB0, FB0 + NB) of a tile: y += bias + residual (in place),
 // returns the partial sum; then, given the mean, centres y and returns the partial sum of squares; then, given rstd,
 // scales, shifts and stores.  residual_ln_store strings the three steps together for a wave that holds all 12 blocks.
+// the residual fragments of blocks [fb0, fb0 + NB): ln_part_sum's loads, for a caller that wants them in flight earlier
 template <int NB>
-__device__ __forceinline__ float ln_part_sum(f32x16 (&y)[NB], int fb0, const uint4 *__restrict__ resid_tile,
-                                             const float *__restrict__ bias, int lane, float sum = 0.f) {
-    const int h = lane >> 5;
-    // Loads first, arithmetic after: written load-next-to-use, hipcc waited for every one of the loads of this
-    // epilogue separately (s_waitcnt vmcnt(0) each), which with one wave per SIMD is that many exposed round trips.
-    uint4 rr[NB * 2];
+__device__ __forceinline__ void ln_part_load(uint4 (&rr)[NB * 2], int fb0, const uint4 *__restrict__ resid_tile, int lane) {
 #pragma unroll
     for (int i = 0; i < NB * 2; ++i) rr[i] = resid_tile[(fb0 * 2 + i) * 64 + lane];
+}
+template <int NB>
+__device__ __forceinline__ float ln_part_sum_rr(f32x16 (&y)[NB], int fb0, const uint4 (&rr)[NB * 2],
+                                                const float *__restrict__ bias, int lane, float sum = 0.f) {
+    const int h = lane >> 5;
     auto load4 = [&](const float *p, int fb, float4 (&dst)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const float4 *>(p + 32 * fb + 8 * g + 4 * h);
@@ -213,6 +223,15 @@ __device__ __forceinline__ float ln_part_sum(f32x16 (&y)[NB], int fb0, const uin
         for (int g = 0; g < 4; ++g) bcur[g] = bnext[g];
     }
     return sum;
+}
+template <int NB>
+__device__ __forceinline__ float ln_part_sum(f32x16 (&y)[NB], int fb0, const uint4 *__restrict__ resid_tile,
+                                             const float *__restrict__ bias, int lane, float sum = 0.f) {
+    // Loads first, arithmetic after: written load-next-to-use, hipcc waited for every one of the loads of this
+    // epilogue separately (s_waitcnt vmcnt(0) each), which with one wave per SIMD is that many exposed round trips.
+    uint4 rr[NB * 2];
+    ln_part_load<NB>(rr, fb0, resid_tile, lane);
+    return ln_part_sum_rr<NB>(y, fb0, rr, bias, lane, sum);
 }
 // ln_part_sum without the sum (y += bias + residual only), and the two running sums continued from a given value over
 // the blocks in the same element order: for a wave that takes over a half's statistics from another wave part-way

@@ -185,76 +185,184 @@ int32_t launch_ln_qkv_attention_single(const float *Y, const uint4 *resid, const
                                        uint4 *ctx, hipStream_t stream);
 
 // ---------------------------------------------------------------- E3b: output projection + residual + LN
-// Workgroup = 8 waves = 128 tokens (4 token tiles), two waves per SIMD: wave (tile tl, half hf) keeps the tile's context
-// (24 fragments, 96 VGPRs) as the B operand and accumulates the output tiles 6 hf .. 6 hf + 5 (96 registers).  W_o
-// streams ONCE per workgroup through LDS (LDS-DMA, 6 pieces per wave and stage; stage = output tiles {st, st + 6} =
-// 48 KiB, two slots), where round 1's kernel had every wave stream all 288 KiB of it through its own register ring:
-// four copies per CU at the ~29 B/clk a CU draws from L2 were 80 us of a 12-us product.  LayerNorm: the two waves of
-// a tile exchange their partial sums through LDS (ln_part_* in encoder_common.h: the statistics are defined as
-// half A + half B everywhere, so this kernel and the latency path round alike).
-constexpr int OPROJ_STAGE_BYTES = 2 * KS_H * 1024;                       // two output tiles x 24 k-steps
-constexpr int OPROJ_LDS_BYTES = 2 * OPROJ_STAGE_BYTES + 2 * 8 * 64 * 4;  // + [2 rounds][8 waves][64 lanes] partial sums
+// Workgroup = 8 waves = one GROUP of 128 tokens (4 token tiles) at a time, two waves per SIMD: wave (tile tl, half hf)
+// accumulates the tile's output blocks 6 hf .. 6 hf + 5 (96 registers).  One workgroup per CU, PERSISTENT over the groups
+// blockIdx.x, blockIdx.x + gridDim.x, ...: with one launch-time group per workgroup (round 2's first form: the tile's
+// context held in 96 registers, 220 VGPRs, so ONE workgroup per CU) the phases of a group ran one after the other - wait
+// for the context from HBM, six stages of products, wait for the residual, LayerNorm, stores - 23 us per group for 6 us
+// of MFMAs, the matrix pipe 15 % busy.  Now the products run K-OUTER: stage st = k-steps 4 st .. 4 st + 3 of W_o for
+// all 12 output blocks (48 KiB, two slots) and of the group's four context tiles (16 KiB, three slots), both by LDS-DMA,
+// W_o one stage ahead (L2) and the context two stages ahead (HBM) - across the group boundary, so the next group's first
+// context stages land during this group's LayerNorm; the residual fragments are requested at the start of the last stage.
+// Every accumulator still sees its 24 products in ascending k, so the sums are the ones oproj_small_kernel forms.
+// LayerNorm: the two waves of a tile exchange their partial sums through LDS (ln_part_* in encoder_common.h: the
+// statistics are defined as half A + half B everywhere, so this kernel and the latency path round alike).
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+constexpr int OPROJ_KC = 4;                                 // k-steps per stage
+constexpr int OPROJ_NST = KS_H / OPROJ_KC;                  // 6 stages per group
+constexpr int OPROJ_W_SLOT = NFB * OPROJ_KC * 1024;         // [12 output blocks][4 k-steps] fragments of 1 KiB
+constexpr int OPROJ_C_SLOT = 4 * OPROJ_KC * 1024;           // [4 token tiles][4 k-steps]
+constexpr int OPROJ_C_BASE = 2 * OPROJ_W_SLOT;
+constexpr int OPROJ_XS_BASE = OPROJ_C_BASE + 3 * OPROJ_C_SLOT;
+constexpr int OPROJ_PAR_BASE = OPROJ_XS_BASE + 2 * 8 * 64 * 4;  // after the [2 rounds][8 waves][64 lanes] partial sums
+constexpr int OPROJ_LDS_BYTES = OPROJ_PAR_BASE + 3 * H * 4;      // + bias | gamma | beta
+#ifndef OPROJ_PARAMS_LDS
+#define OPROJ_PARAMS_LDS 1
+#endif
+#ifndef OPROJ_RR_ASM
+#define OPROJ_RR_ASM 1
+#endif
+#ifndef OPROJ_ABL
+#define OPROJ_ABL 0  // timing ablations (wrong results): 1 no W_o DMA after the first stage, 2 no context DMA, 4 no LayerNorm, 8 no MFMA
+#endif
+constexpr int OPROJ_MAX_GRID = 256;                         // one workgroup per CU of an MI355X
+static_assert(OPROJ_NST % 2 == 0 && OPROJ_NST % 3 == 0, "slot indices continue across groups");
 
-__global__ __launch_bounds__(512, 2) void oproj_ln_kernel(const uint4 *__restrict__ ctx, int n_tiles,
+__global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restrict__ ctx, int n_tiles,
                                                           const uint4 *__restrict__ wo, const float *__restrict__ bo,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           const uint4 *__restrict__ act_in, uint4 *__restrict__ act_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *xs = reinterpret_cast<float *>(smem + 2 * OPROJ_STAGE_BYTES);  // [2][8][64]
+    float *xs = reinterpret_cast<float *>(smem + OPROJ_XS_BASE);  // [2][8][64]
     constexpr int HB = NFB / 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tl = wave & 3, hf = wave >> 2;
-    const int tt_raw = blockIdx.x * 4 + tl;
-    const bool live = tt_raw < n_tiles;
-    const int tt = live ? tt_raw : n_tiles - 1;  // idle waves shadow a real tile: they join the barriers and the DMA
+    const int n_groups = (n_tiles + 3) >> 2;
+    const uint32_t lds0 = enc_lds_addr(smem);
 
-    // stage st -> slot st & 1: [ W_o tile st (24 KiB) | W_o tile st + 6 ]; this wave moves pieces 3 wave .. 3 wave + 2 of each
-    auto issue = [&](int st) {
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)((st & 1) * OPROJ_STAGE_BYTES + (wave * 3) * 1024));
+    // W_o stage st -> slot st & 1; this wave moves pieces 6 wave .. 6 wave + 5 (piece p = block p / 4, k-step 4 st + p % 4)
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    auto issue_w = [&](int st) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((st & 1) * OPROJ_W_SLOT + wave * 6 * 1024));
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const uint4 *src = wo + (size_t)(st + HB * half) * (KS_H * 64) + (size_t)(wave * 3) * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) enc_glds16(src + i * 64, dst + half * (KS_H * 1024) + i * 1024);
+        for (int i = 0; i < 6; ++i) {
+            const int p = wave * 6 + i;
+            enc_glds16_s(wo + (size_t)((p >> 2) * KS_H + OPROJ_KC * st + (p & 3)) * 64, lane16, dst + i * 1024);
         }
     };
-    issue(0);
-    const uint4 *cin = ctx + (size_t)tt * (NFB * 2 * 64) + lane;
-    uint4 c[KS_H];
+    // context stage st of group g -> slot st % 3; this wave moves k-steps 2 (wave & 1), + 1 of the group's tile wave / 2
+    auto issue_c = [&](int g, int st) {
+        const int t_raw = g * 4 + (wave >> 1);
+        const int t = t_raw < n_tiles ? t_raw : n_tiles - 1;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(OPROJ_C_BASE + (st % 3) * OPROJ_C_SLOT + wave * 2 * 1024));
+        const uint4 *src = ctx + (size_t)t * (NFB * 2 * 64) + (size_t)(OPROJ_KC * st + 2 * (wave & 1)) * 64;
+        enc_glds16_s(src, lane16, dst);
+        enc_glds16_s(src + 64, lane16, dst + 1024);
+    };
+
+    int g = blockIdx.x;
+    issue_w(0);
+    issue_c(g, 0);
+    issue_c(g, 1);
+#if OPROJ_PARAMS_LDS
+    // bias | gamma | beta (contiguous at bo) once per workgroup into LDS: every wave reads all of its 288 parameter values
+    // per group, which as global loads were 72 KiB per wave and group through the texture path - as much as the data
+    for (int i = tid; i < 3 * H; i += 512) reinterpret_cast<float *>(smem + OPROJ_PAR_BASE)[i] = bo[i];  // visible after the first stage's barrier
+#else
+    const float *p_bias = bo, *p_gamma = gamma, *p_beta = beta;
+#endif
+    bool stores_in_flight = false;
+    for (; g < n_groups; g += gridDim.x) {
+        const int gn = g + (int)gridDim.x < n_groups ? g + (int)gridDim.x : g;  // no next group: the prefetch re-reads this one
+        const int tt_raw = g * 4 + tl;
+        const bool live = tt_raw < n_tiles;
+        const int tt = live ? tt_raw : n_tiles - 1;  // idle waves shadow a real tile: they join the barriers and the DMA
+        const uint4 *resid = act_in + (size_t)tt * (NFB * 2 * 64);
+        uint4 rr[HB * 2];
+        f32x16 y[HB];
 #pragma unroll
-    for (int ks = 0; ks < KS_H; ++ks) c[ks] = cin[ks * 64];
-    f32x16 y[HB];
+        for (int j = 0; j < HB; ++j) y[j] = f32x16{0};
 #pragma unroll
-    for (int st = 0; st < HB; ++st) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage st (and, at st = 0, its context) have landed
-        __syncthreads();                                   // stage st is complete; everyone is done with the other slot
-        if (st + 1 < HB) issue(st + 1);
-        const uint4 *w = reinterpret_cast<const uint4 *>(smem + (size_t)(st & 1) * OPROJ_STAGE_BYTES + (size_t)hf * (KS_H * 1024)) + lane;
-        uint4 fr[4];
-        fr[0] = w[0 * 64];
-        fr[1] = w[1 * 64];
-        fr[2] = w[2 * 64];
-        f32x16 acc = {0};
+        for (int st = 0; st < OPROJ_NST; ++st) {
+            // this wave's pieces of stage st have landed; what may still be in flight is younger: the two context pieces of
+            // stage st + 1 and, at a group's first stage, the previous group's 12 output stores (vmcnt counts stores on gfx9)
+            if (st == 0 && stores_in_flight)
+                asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+#if OPROJ_RR_ASM
+            else if (st == OPROJ_NST - 1)
+                asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // + the 12 residual loads of the stage before
+#endif
+            else
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __syncthreads();  // stage st is complete; everyone is done with stage st - 1's slots
+            if (!(OPROJ_ABL & 1)) issue_w(st + 1 < OPROJ_NST ? st + 1 : 0);
+            if (!(OPROJ_ABL & 2)) { if (st + 2 < OPROJ_NST) issue_c(g, st + 2); else issue_c(gn, st + 2 - OPROJ_NST); }
+#if OPROJ_RR_ASM
+            // the residual fragments, requested two stages before the LayerNorm.  As asm: hipcc moves a plain load of
+            // read-only memory down to its first use (the loads are not on the memory chain, sched_barrier does not hold
+            // them), which is after the last MFMA.  The registers are not touched until the s_waitcnt + pass-through below.
+            if (st == OPROJ_NST - 2) {
 #pragma unroll
-        for (int ks = 0; ks < KS_H; ++ks) {
-            if (ks + 3 < KS_H) fr[(ks + 3) & 3] = w[(ks + 3) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            acc = mfma(fr[ks & 3], c[ks], acc);
+                for (int i = 0; i < HB * 2; ++i) {
+                    u32x4 t;
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t) : "v"(lane16), "s"(resid + (HB * hf * 2 + i) * 64) : "memory");
+                    rr[i] = make_uint4(t.x, t.y, t.z, t.w);
+                }
+            }
+#else
+            if (st == OPROJ_NST - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                ln_part_load<HB>(rr, HB * hf, resid, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+            const uint4 *wl = reinterpret_cast<const uint4 *>(smem + (size_t)(st & 1) * OPROJ_W_SLOT + (size_t)(HB * hf) * OPROJ_KC * 1024) + lane;
+            const uint4 *cl = reinterpret_cast<const uint4 *>(smem + OPROJ_C_BASE + (size_t)(st % 3) * OPROJ_C_SLOT + (size_t)tl * OPROJ_KC * 1024) + lane;
+            uint4 cf[2], wf[2][HB];
+            cf[0] = cl[0];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) wf[0][j] = wl[(j * OPROJ_KC) * 64];
+#pragma unroll
+            for (int kk = 0; kk < OPROJ_KC; ++kk) {
+                if (kk + 1 < OPROJ_KC) {
+                    cf[(kk + 1) & 1] = cl[(kk + 1) * 64];
+#pragma unroll
+                    for (int j = 0; j < HB; ++j) wf[(kk + 1) & 1][j] = wl[(j * OPROJ_KC + kk + 1) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    if (OPROJ_ABL & 8) y[j][0] += __uint_as_float(wf[kk & 1][j].x ^ cf[kk & 1].x);
+                    else y[j] = mfma(wf[kk & 1][j], cf[kk & 1], y[j]);
+                }
+            }
         }
-        y[st] = acc;
+        // LayerNorm over the tile's 384 features: this wave holds blocks [6 hf, 6 hf + 6)
+#if OPROJ_PARAMS_LDS
+        // the table's address is made opaque per group: left loop-invariant, hipcc keeps a dozen of its lane addresses in
+        // registers through the product stages and spills some (each reload in the store phase waits on vmcnt(0))
+        uint32_t par_off = OPROJ_PAR_BASE;
+        asm volatile("" : "+v"(par_off));
+        const float *p_bias = reinterpret_cast<const float *>(smem + par_off), *p_gamma = p_bias + H, *p_beta = p_bias + 2 * H;
+#endif
+#if OPROJ_RR_ASM
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // younger than the residual loads: the last stage's 6 + 2 DMA pieces
+#pragma unroll
+        for (int i = 0; i < HB * 2; ++i) {
+            u32x4 t = {rr[i].x, rr[i].y, rr[i].z, rr[i].w};
+            asm volatile("" : "+v"(t));
+            rr[i] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+#endif
+#if OPROJ_ABL & 4
+        y[0][0] += __uint_as_float(rr[0].x ^ rr[3].y ^ rr[7].z ^ rr[11].w);
+        ln_part_store<HB, false>(y, HB * hf, 1.0f, p_gamma, p_beta, act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
+        stores_in_flight = live;
+        continue;
+#endif
+        const float ps = ln_part_sum_rr<HB>(y, HB * hf, rr, p_bias, lane);
+        xs[(0 * 8 + wave) * 64 + lane] = ps;
+        __syncthreads();
+        const float mean = half_sum(xs[(0 * 8 + tl) * 64 + lane] + xs[(0 * 8 + 4 + tl) * 64 + lane]) * (1.0f / H);  // half A + half B
+        const float pq = ln_part_sq<HB>(y, mean);
+        xs[(1 * 8 + wave) * 64 + lane] = pq;
+        __syncthreads();
+        const float rstd = rsqrtf(half_sum(xs[(1 * 8 + tl) * 64 + lane] + xs[(1 * 8 + 4 + tl) * 64 + lane]) * (1.0f / H) + LN_EPS);
+        ln_part_store<HB, false>(y, HB * hf, rstd, p_gamma, p_beta, act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
+        stores_in_flight = live;
     }
-    // LayerNorm over the tile's 384 features: this wave holds blocks [6 hf, 6 hf + 6)
-    const uint4 *resid = act_in + (size_t)tt * (NFB * 2 * 64);
-    const float ps = ln_part_sum<HB>(y, HB * hf, resid, bo, lane);
-    xs[(0 * 8 + wave) * 64 + lane] = ps;
-    __syncthreads();
-    const float mean = half_sum(xs[(0 * 8 + tl) * 64 + lane] + xs[(0 * 8 + 4 + tl) * 64 + lane]) * (1.0f / H);  // half A + half B
-    const float pq = ln_part_sq<HB>(y, mean);
-    xs[(1 * 8 + wave) * 64 + lane] = pq;
-    __syncthreads();
-    const float rstd = rsqrtf(half_sum(xs[(1 * 8 + tl) * 64 + lane] + xs[(1 * 8 + 4 + tl) * 64 + lane]) * (1.0f / H) + LN_EPS);
-    ln_part_store<HB, false>(y, HB * hf, rstd, gamma, beta, act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetches target this workgroup's LDS: they land before it is released
 }
 
 // ---------------------------------------------------------------- E4: FFN1 + GELU + FFN2 + residual + LN
