@@ -359,7 +359,7 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         }
         for (int li = 0; li < nl && !small; ++li) {
             const Layer &l = e->L[li];
-            qkv_kernel<<<dim3((nt + 4 * QKV_G - 1) / (4 * QKV_G)), blk, QKV_LDS_BYTES, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
+            qkv_kernel<<<dim3((nt + QKV_WAVES * QKV_G - 1) / (QKV_WAVES * QKV_G)), dim3(64 * QKV_WAVES), QKV_LDS_BYTES, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
             {
                 const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);  // a1 = context
                 if (arc != MIR_OK) return arc;

@@ -62,20 +62,33 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 }
 
 // ---------------------------------------------------------------- E2: QKV projection
-// One wave per QKV_G = 3 token tiles (96 tokens), 4 waves per block = 384 tokens.  wqkv: 36 tiles x 24 k-steps of
-// 1-KiB fragments: tiles 0-11 = Q heads, 12-23 = K heads, 24-35 = V heads.  The weights enter LDS ONCE per workgroup:
-// a ring of QKV_NS stages (one stage = one weight tile = 24 KiB), filled by LDS-DMA (6 pieces per wave and stage) with
-// counted waits, one barrier per stage; a fragment read from LDS feeds three MFMAs (three token tiles' activations stay
-// in registers: 288 VGPRs).  Round 1's form had every wave stream all 864 KiB through its own register ring - four
-// copies per CU, at the ~29 B/clk a CU draws from L2 that stream (57 us per pass) was longer than the MFMAs (40 us).
+// One wave per QKV_G = 2 token tiles (64 tokens), 8 waves per block = 512 tokens, two waves per SIMD.  wqkv: 36 tiles x
+// 24 k-steps of 1-KiB fragments: tiles 0-11 = Q heads, 12-23 = K heads, 24-35 = V heads.  The weights enter LDS ONCE per
+// workgroup: a ring of QKV_NS stages (one stage = one weight tile = 24 KiB), filled by LDS-DMA (3 pieces per wave and
+// stage) with counted waits, one barrier per stage; a fragment read from LDS feeds two MFMAs (two token tiles'
+// activations stay in registers: 192 VGPRs).  Round 1's form had every wave stream all 864 KiB through its own register
+// ring - four copies per CU, at the ~29 B/clk a CU draws from L2 that stream (57 us per pass) was longer than the MFMAs.
+// Measured per 12288-tile pass: three tiles per wave and one wave per SIMD (288 VGPRs of activations) 376-381 us, this
+// form 363 us; letting the second wave of each SIMD run half a stage late (its epilogue under the first wave's MFMAs)
+// needs the accumulators across the barrier, spills 28 registers, and every spill reload waits behind the DMAs in
+// flight: 484 us.  By ablation the 376 us are ~200 us of MFMAs, ~75 us attributable to the Q/K/V stores (0.9 GB per pass)
+// and the per-stage epilogue; the kernel is not L2-bound (24 KiB of weights per stage and CU).
 // Q, K come out as W^T x^T (rows = head features, lanes = tokens); V as x W (rows = tokens, lanes = head features) so
 // that each is directly the operand the attention kernel needs.  Output fragment buffers: [tile][head][s2][64].
-constexpr int QKV_G = 3;
+#ifndef QKV_G_
+#define QKV_G_ 2
+#endif
+#ifndef QKV_WAVES_
+#define QKV_WAVES_ 8
+#endif
+constexpr int QKV_G = QKV_G_;                                 // token tiles per wave
+constexpr int QKV_WAVES = QKV_WAVES_;                         // waves per workgroup
+constexpr int QKV_PIECES = KS_H / QKV_WAVES;                  // DMA pieces per wave and stage
 constexpr int QKV_NS = 4;                                     // ring stages
 constexpr int QKV_STAGE_BYTES = KS_H * 1024;                  // one weight tile
 constexpr int QKV_LDS_BYTES = QKV_NS * QKV_STAGE_BYTES + 3 * H * 4;  // + the biases
 
-__global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ act, int n_tiles,
+__global__ __launch_bounds__(64 * QKV_WAVES, 1) void qkv_kernel(const uint4 *__restrict__ act, int n_tiles,
                                                      const uint4 *__restrict__ wqkv, const float *__restrict__ bqkv,
                                                      uint4 *__restrict__ qf, uint4 *__restrict__ kf,
                                                      uint4 *__restrict__ vf) {
@@ -83,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ a
     float *bias = reinterpret_cast<float *>(smem + QKV_NS * QKV_STAGE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t0 = (blockIdx.x * 4 + wave) * QKV_G;
+    const int t0 = (blockIdx.x * QKV_WAVES + wave) * QKV_G;
     int tt[QKV_G];
     bool live[QKV_G];
 #pragma unroll
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ a
         live[g] = t0 + g < n_tiles;
         tt[g] = live[g] ? t0 + g : n_tiles - 1;  // a missing tile shadows a real one; nothing is stored for it (idle waves still
     }                                             // join the barriers and move their share of the weights)
-    for (int i = tid; i < 3 * H; i += 256) bias[i] = bqkv[i];
+    for (int i = tid; i < 3 * H; i += 64 * QKV_WAVES) bias[i] = bqkv[i];
     __syncthreads();  // (the stage barriers below are raw s_barrier: they do not wait for LDS writes)
     uint4 x[QKV_G][KS_H];
 #pragma unroll
@@ -108,10 +121,10 @@ __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     auto issue = [&](int tile) {  // weight tile `tile` -> slot tile % QKV_NS; this wave moves pieces 6 wave .. 6 wave + 5
-        const uint4 *src = wqkv + (size_t)tile * (KS_H * 64) + (size_t)(wave * 6) * 64 + lane;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)((tile % QKV_NS) * QKV_STAGE_BYTES + (wave * 6) * 1024));
+        const uint4 *src = wqkv + (size_t)tile * (KS_H * 64) + (size_t)(wave * QKV_PIECES) * 64;  // wave-uniform
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)((tile % QKV_NS) * QKV_STAGE_BYTES + (wave * QKV_PIECES) * 1024));
 #pragma unroll
-        for (int i = 0; i < 6; ++i) enc_glds16(src + i * 64, dst + i * 1024);
+        for (int i = 0; i < QKV_PIECES; ++i) enc_glds16_s(src + i * 64, (uint32_t)lane * 16u, dst + i * 1024);
     };
     for (int t = 0; t < QKV_NS - 1; ++t) issue(t);
 
@@ -120,9 +133,9 @@ __global__ __launch_bounds__(256, 1) void qkv_kernel(const uint4 *__restrict__ a
     auto run_tiles = [&](int tile_lo, int tile_hi, auto IS_V_) {
         constexpr bool is_v = decltype(IS_V_)::value;
         for (int tile = tile_lo; tile < tile_hi; ++tile) {
-            // Younger than this stage's 6 DMA pieces, in issue order: stores(tile-3), DMA(tile+1), stores(tile-2), DMA(tile+2),
-            // stores(tile-1) = 30 operations once the pipeline is full; the first and last stages simply drain.
-            if (tile >= 3 && tile + QKV_NS - 1 <= 36) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+            // Younger than this stage's DMA pieces, in issue order: stores(tile-3), DMA(tile+1), stores(tile-2), DMA(tile+2),
+            // stores(tile-1) = 3 * 2 QKV_G + 2 QKV_PIECES operations once the pipeline is full; the first and last stages simply drain.
+            if (tile >= 3 && tile + QKV_NS - 1 <= 36) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * 2 * QKV_G + 2 * QKV_PIECES) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // stage `tile` is in LDS for everyone; everyone is done with stage tile - 1
             if (tile + QKV_NS - 1 < 36) issue(tile + QKV_NS - 1);
@@ -206,15 +219,7 @@ constexpr int OPROJ_C_BASE = 2 * OPROJ_W_SLOT;
 constexpr int OPROJ_XS_BASE = OPROJ_C_BASE + 3 * OPROJ_C_SLOT;
 constexpr int OPROJ_PAR_BASE = OPROJ_XS_BASE + 2 * 8 * 64 * 4;  // after the [2 rounds][8 waves][64 lanes] partial sums
 constexpr int OPROJ_LDS_BYTES = OPROJ_PAR_BASE + 3 * H * 4;      // + bias | gamma | beta
-#ifndef OPROJ_PARAMS_LDS
-#define OPROJ_PARAMS_LDS 1
-#endif
-#ifndef OPROJ_RR_ASM
-#define OPROJ_RR_ASM 1
-#endif
-#ifndef OPROJ_ABL
-#define OPROJ_ABL 0  // timing ablations (wrong results): 1 no W_o DMA after the first stage, 2 no context DMA, 4 no LayerNorm, 8 no MFMA
-#endif
+
 constexpr int OPROJ_MAX_GRID = 256;                         // one workgroup per CU of an MI355X
 static_assert(OPROJ_NST % 2 == 0 && OPROJ_NST % 3 == 0, "slot indices continue across groups");
 
@@ -255,13 +260,10 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
     issue_w(0);
     issue_c(g, 0);
     issue_c(g, 1);
-#if OPROJ_PARAMS_LDS
-    // bias | gamma | beta (contiguous at bo) once per workgroup into LDS: every wave reads all of its 288 parameter values
-    // per group, which as global loads were 72 KiB per wave and group through the texture path - as much as the data
+    // bias | gamma | beta (contiguous at bo; `gamma`, `beta` point into the same block) once per workgroup into LDS: every
+    // wave reads all of its 288 parameter values per group, which as global loads were 72 KiB per wave and group through the
+    // texture path - as much as the data (241 -> 212 us per 12288-tile pass)
     for (int i = tid; i < 3 * H; i += 512) reinterpret_cast<float *>(smem + OPROJ_PAR_BASE)[i] = bo[i];  // visible after the first stage's barrier
-#else
-    const float *p_bias = bo, *p_gamma = gamma, *p_beta = beta;
-#endif
     bool stores_in_flight = false;
     for (; g < n_groups; g += gridDim.x) {
         const int gn = g + (int)gridDim.x < n_groups ? g + (int)gridDim.x : g;  // no next group: the prefetch re-reads this one
@@ -279,19 +281,17 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
             // stage st + 1 and, at a group's first stage, the previous group's 12 output stores (vmcnt counts stores on gfx9)
             if (st == 0 && stores_in_flight)
                 asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-#if OPROJ_RR_ASM
             else if (st == OPROJ_NST - 1)
                 asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // + the 12 residual loads of the stage before
-#endif
             else
                 asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __syncthreads();  // stage st is complete; everyone is done with stage st - 1's slots
-            if (!(OPROJ_ABL & 1)) issue_w(st + 1 < OPROJ_NST ? st + 1 : 0);
-            if (!(OPROJ_ABL & 2)) { if (st + 2 < OPROJ_NST) issue_c(g, st + 2); else issue_c(gn, st + 2 - OPROJ_NST); }
-#if OPROJ_RR_ASM
+            issue_w(st + 1 < OPROJ_NST ? st + 1 : 0);
+            if (st + 2 < OPROJ_NST) issue_c(g, st + 2); else issue_c(gn, st + 2 - OPROJ_NST);
             // the residual fragments, requested two stages before the LayerNorm.  As asm: hipcc moves a plain load of
             // read-only memory down to its first use (the loads are not on the memory chain, sched_barrier does not hold
-            // them), which is after the last MFMA.  The registers are not touched until the s_waitcnt + pass-through below.
+            // them), which is after the last MFMA.  The registers must not be touched until the s_waitcnt + pass-through
+            // below: tools/check_pending_loads.py reads the ISA of a build for exactly that.
             if (st == OPROJ_NST - 2) {
 #pragma unroll
                 for (int i = 0; i < HB * 2; ++i) {
@@ -300,13 +300,6 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
                     rr[i] = make_uint4(t.x, t.y, t.z, t.w);
                 }
             }
-#else
-            if (st == OPROJ_NST - 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                ln_part_load<HB>(rr, HB * hf, resid, lane);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
             const uint4 *wl = reinterpret_cast<const uint4 *>(smem + (size_t)(st & 1) * OPROJ_W_SLOT + (size_t)(HB * hf) * OPROJ_KC * 1024) + lane;
             const uint4 *cl = reinterpret_cast<const uint4 *>(smem + OPROJ_C_BASE + (size_t)(st % 3) * OPROJ_C_SLOT + (size_t)tl * OPROJ_KC * 1024) + lane;
             uint4 cf[2], wf[2][HB];
@@ -322,21 +315,15 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < HB; ++j) {
-                    if (OPROJ_ABL & 8) y[j][0] += __uint_as_float(wf[kk & 1][j].x ^ cf[kk & 1].x);
-                    else y[j] = mfma(wf[kk & 1][j], cf[kk & 1], y[j]);
-                }
+                for (int j = 0; j < HB; ++j) y[j] = mfma(wf[kk & 1][j], cf[kk & 1], y[j]);
             }
         }
         // LayerNorm over the tile's 384 features: this wave holds blocks [6 hf, 6 hf + 6)
-#if OPROJ_PARAMS_LDS
         // the table's address is made opaque per group: left loop-invariant, hipcc keeps a dozen of its lane addresses in
         // registers through the product stages and spills some (each reload in the store phase waits on vmcnt(0))
         uint32_t par_off = OPROJ_PAR_BASE;
         asm volatile("" : "+v"(par_off));
         const float *p_bias = reinterpret_cast<const float *>(smem + par_off), *p_gamma = p_bias + H, *p_beta = p_bias + 2 * H;
-#endif
-#if OPROJ_RR_ASM
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // younger than the residual loads: the last stage's 6 + 2 DMA pieces
 #pragma unroll
         for (int i = 0; i < HB * 2; ++i) {
@@ -344,13 +331,6 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
             asm volatile("" : "+v"(t));
             rr[i] = make_uint4(t.x, t.y, t.z, t.w);
         }
-#endif
-#if OPROJ_ABL & 4
-        y[0][0] += __uint_as_float(rr[0].x ^ rr[3].y ^ rr[7].z ^ rr[11].w);
-        ln_part_store<HB, false>(y, HB * hf, 1.0f, p_gamma, p_beta, act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
-        stores_in_flight = live;
-        continue;
-#endif
         const float ps = ln_part_sum_rr<HB>(y, HB * hf, rr, p_bias, lane);
         xs[(0 * 8 + wave) * 64 + lane] = ps;
         __syncthreads();
