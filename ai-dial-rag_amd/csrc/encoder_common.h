@@ -128,6 +128,7 @@ __device__ __forceinline__ uint32_t gelu_lut_addr(float x, float &xc, uint32_t b
     return addr;
 }
 typedef float __attribute__((ext_vector_type(2))) f32x2;
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;  // a register quad as an inline-asm operand (HIP's uint4 is a struct)
 __device__ __forceinline__ f32x2 lds_read_f2(uint32_t byte_addr) {
     return *reinterpret_cast<const __attribute__((address_space(3))) f32x2 *>(byte_addr);
 }
@@ -189,7 +190,9 @@ __device__ __forceinline__ void ln_part_load(uint4 (&rr)[NB * 2], int fb0, const
 #pragma unroll
     for (int i = 0; i < NB * 2; ++i) rr[i] = resid_tile[(fb0 * 2 + i) * 64 + lane];
 }
-template <int NB>
+// PF: fetch the NEXT block's parameters before working on this one (parameters in global memory: hides their latency, 16
+// more live registers here, 32 in ln_part_store); callers whose parameters sit in LDS and whose registers are full pass false.
+template <int NB, bool PF = true>
 __device__ __forceinline__ float ln_part_sum_rr(f32x16 (&y)[NB], int fb0, const uint4 (&rr)[NB * 2],
                                                 const float *__restrict__ bias, int lane, float sum = 0.f) {
     const int h = lane >> 5;
@@ -198,10 +201,11 @@ __device__ __forceinline__ float ln_part_sum_rr(f32x16 (&y)[NB], int fb0, const 
         for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const float4 *>(p + 32 * fb + 8 * g + 4 * h);
     };
     float4 bcur[4], bnext[4];
-    load4(bias, fb0, bcur);
+    if (PF) load4(bias, fb0, bcur);
 #pragma unroll
     for (int f = 0; f < NB; ++f) {
-        if (f + 1 < NB) load4(bias, fb0 + f + 1, bnext);
+        if (PF) { if (f + 1 < NB) load4(bias, fb0 + f + 1, bnext); }
+        else load4(bias, fb0 + f, bcur);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float rv[8];
@@ -219,19 +223,21 @@ __device__ __forceinline__ float ln_part_sum_rr(f32x16 (&y)[NB], int fb0, const 
                 }
             }
         }
+        if (PF) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bcur[g] = bnext[g];
+            for (int g = 0; g < 4; ++g) bcur[g] = bnext[g];
+        }
     }
     return sum;
 }
-template <int NB>
+template <int NB, bool PF = true>
 __device__ __forceinline__ float ln_part_sum(f32x16 (&y)[NB], int fb0, const uint4 *__restrict__ resid_tile,
                                              const float *__restrict__ bias, int lane, float sum = 0.f) {
     // Loads first, arithmetic after: written load-next-to-use, hipcc waited for every one of the loads of this
     // epilogue separately (s_waitcnt vmcnt(0) each), which with one wave per SIMD is that many exposed round trips.
     uint4 rr[NB * 2];
     ln_part_load<NB>(rr, fb0, resid_tile, lane);
-    return ln_part_sum_rr<NB>(y, fb0, rr, bias, lane, sum);
+    return ln_part_sum_rr<NB, PF>(y, fb0, rr, bias, lane, sum);
 }
 // ln_part_sum without the sum (y += bias + residual only), and the two running sums continued from a given value over
 // the blocks in the same element order: for a wave that takes over a half's statistics from another wave part-way
@@ -292,7 +298,7 @@ __device__ __forceinline__ float ln_part_sq(f32x16 (&y)[NB], float mean) {
         }
     return sq;
 }
-template <int NB, bool PIN_CVT>
+template <int NB, bool PIN_CVT, bool PF = true>
 __device__ __forceinline__ void ln_part_store(f32x16 (&y)[NB], int fb0, float rstd, const float *__restrict__ gamma,
                                               const float *__restrict__ beta, uint4 *__restrict__ out_tile, int lane, bool store) {
     const int h = lane >> 5;
@@ -301,11 +307,16 @@ __device__ __forceinline__ void ln_part_store(f32x16 (&y)[NB], int fb0, float rs
         for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const float4 *>(p + 32 * fb + 8 * g + 4 * h);
     };
     float4 gcur[4], ecur[4], gnext[4], enext[4];
-    load4(gamma, fb0, gcur);
-    load4(beta, fb0, ecur);
+    if (PF) {
+        load4(gamma, fb0, gcur);
+        load4(beta, fb0, ecur);
+    }
 #pragma unroll
     for (int f = 0; f < NB; ++f) {
-        if (f + 1 < NB) {
+        if (!PF) {
+            load4(gamma, fb0 + f, gcur);
+            load4(beta, fb0 + f, ecur);
+        } else if (f + 1 < NB) {
             load4(gamma, fb0 + f + 1, gnext);
             load4(beta, fb0 + f + 1, enext);
         }
@@ -316,8 +327,10 @@ __device__ __forceinline__ void ln_part_store(f32x16 (&y)[NB], int fb0, float rs
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[4 * g + i] = fmaf(y[f][4 * g + i] * rstd, gg[i], ee[i]);
         }
+        if (PF) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { gcur[g] = gnext[g]; ecur[g] = enext[g]; }
+            for (int g = 0; g < 4; ++g) { gcur[g] = gnext[g]; ecur[g] = enext[g]; }
+        }
         if (store) {
             const int fb = fb0 + f;
             out_tile[(fb * 2 + 0) * 64 + lane] =
@@ -335,7 +348,7 @@ __device__ __forceinline__ void ln_part_store(f32x16 (&y)[NB], int fb0, float rs
 // g = r>>2 are four CONSECUTIVE features, so bias / gamma / beta are read as float4.
 // QUARTERS: load the residual three blocks at a time instead of six (a wave that also holds other state: the FFN kernel);
 // the sums run over the blocks in the same order either way, so the result is the same bit for bit.
-template <bool PIN_CVT = false, bool QUARTERS = false>
+template <bool PIN_CVT = false, bool QUARTERS = false, bool PF = true>
 __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 *__restrict__ resid_tile,
                                                   const float *__restrict__ bias, const float *__restrict__ gamma,
                                                   const float *__restrict__ beta, uint4 *__restrict__ out_tile,
@@ -350,20 +363,20 @@ __device__ __forceinline__ void residual_ln_store(f32x16 (&y)[NFB], const uint4 
         f32x16(&y1)[QB] = *reinterpret_cast<f32x16(*)[QB]>(&y[QB]);
         f32x16(&y2)[QB] = *reinterpret_cast<f32x16(*)[QB]>(&y[2 * QB]);
         f32x16(&y3)[QB] = *reinterpret_cast<f32x16(*)[QB]>(&y[3 * QB]);
-        sa = ln_part_sum<QB>(y0, 0, resid_tile, bias, lane);
-        sa = ln_part_sum<QB>(y1, QB, resid_tile, bias, lane, sa);
-        sb = ln_part_sum<QB>(y2, 2 * QB, resid_tile, bias, lane);
-        sb = ln_part_sum<QB>(y3, 3 * QB, resid_tile, bias, lane, sb);
+        sa = ln_part_sum<QB, PF>(y0, 0, resid_tile, bias, lane);
+        sa = ln_part_sum<QB, PF>(y1, QB, resid_tile, bias, lane, sa);
+        sb = ln_part_sum<QB, PF>(y2, 2 * QB, resid_tile, bias, lane);
+        sb = ln_part_sum<QB, PF>(y3, 3 * QB, resid_tile, bias, lane, sb);
     } else {
-        sa = ln_part_sum<HB>(ya, 0, resid_tile, bias, lane);
-        sb = ln_part_sum<HB>(yb, HB, resid_tile, bias, lane);
+        sa = ln_part_sum<HB, PF>(ya, 0, resid_tile, bias, lane);
+        sb = ln_part_sum<HB, PF>(yb, HB, resid_tile, bias, lane);
     }
     const float mean = half_sum(sa + sb) * (1.0f / H);
     const float qa = ln_part_sq<HB>(ya, mean);
     const float qb = ln_part_sq<HB>(yb, mean);
     const float rstd = rsqrtf(half_sum(qa + qb) * (1.0f / H) + LN_EPS);
-    ln_part_store<HB, PIN_CVT>(ya, 0, rstd, gamma, beta, out_tile, lane, store);
-    ln_part_store<HB, PIN_CVT>(yb, HB, rstd, gamma, beta, out_tile, lane, store);
+    ln_part_store<HB, PIN_CVT, PF>(ya, 0, rstd, gamma, beta, out_tile, lane, store);
+    ln_part_store<HB, PIN_CVT, PF>(yb, HB, rstd, gamma, beta, out_tile, lane, store);
 }
 
 

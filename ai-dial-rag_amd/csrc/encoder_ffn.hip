@@ -23,6 +23,7 @@
 // role B alone: 1.0K; everything together 3.3K (3.9K with the A waves also moving the weights through registers, the
 // round-1 single-role kernel 4.0-4.3K).  So: a memory-pipe floor next to the MFMA time, plus a serial GELU chain that the
 // partner wave cannot take over without also holding x.
+#include <algorithm>
 #include "common.h"
 #include "encoder_common.h"
 #include "encoder_ffn_kernel.h"
@@ -38,7 +39,7 @@ int32_t ffn_prepare() {
 
 int32_t launch_ffn(const uint4 *act_in, int n_tiles, const unsigned char *wffn, const float *params, uint4 *act_out,
                    hipStream_t stream) {
-    ffn_ln_kernel<false><<<dim3((n_tiles + 3) / 4), dim3(512), FFN_LDS_BYTES, stream>>>(act_in, n_tiles, wffn, params, act_out, nullptr);
+    ffn_ln_kernel<false><<<dim3(std::min((n_tiles + 3) / 4, FFN_MAX_GRID)), dim3(512), FFN_LDS_BYTES, stream>>>(act_in, n_tiles, wffn, params, act_out, nullptr);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }

@@ -210,7 +210,6 @@ int32_t launch_ln_qkv_attention_single(const float *Y, const uint4 *resid, const
 // Every accumulator still sees its 24 products in ascending k, so the sums are the ones oproj_small_kernel forms.
 // LayerNorm: the two waves of a tile exchange their partial sums through LDS (ln_part_* in encoder_common.h: the
 // statistics are defined as half A + half B everywhere, so this kernel and the latency path round alike).
-typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 constexpr int OPROJ_KC = 4;                                 // k-steps per stage
 constexpr int OPROJ_NST = KS_H / OPROJ_KC;                  // 6 stages per group
 constexpr int OPROJ_W_SLOT = NFB * OPROJ_KC * 1024;         // [12 output blocks][4 k-steps] fragments of 1 KiB
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
 #pragma unroll
                 for (int i = 0; i < HB * 2; ++i) {
                     u32x4 t;
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t) : "v"(lane16), "s"(resid + (HB * hf * 2 + i) * 64) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, %2 ; pending" : "=v"(t) : "v"(lane16), "s"(resid + (HB * hf * 2 + i) * 64) : "memory");
                     rr[i] = make_uint4(t.x, t.y, t.z, t.w);
                 }
             }
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
         uint32_t par_off = OPROJ_PAR_BASE;
         asm volatile("" : "+v"(par_off));
         const float *p_bias = reinterpret_cast<const float *>(smem + par_off), *p_gamma = p_bias + H, *p_beta = p_bias + 2 * H;
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // younger than the residual loads: the last stage's 6 + 2 DMA pieces
+        asm volatile("s_waitcnt vmcnt(8) ; release-pending" ::: "memory");  // younger than the residual loads: the last stage's 6 + 2 DMA pieces
 #pragma unroll
         for (int i = 0; i < HB * 2; ++i) {
             u32x4 t = {rr[i].x, rr[i].y, rr[i].z, rr[i].w};

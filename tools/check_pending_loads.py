@@ -1,8 +1,12 @@
-"""oproj_ln_kernel requests its residual fragments with inline-asm `global_load_dwordx4 v[..], v, s[..]` two stages before
-it waits for them (`s_waitcnt vmcnt(8)`): the compiler does not know that those registers are pending.  This script
-compiles encoder.hip to ISA the way the Makefile does and checks that NO instruction between the loads and that wait
-reads or writes one of the destination registers (a copy or spill there would pick up stale data).  Also reports
-spills of the kernels whose waits are counted by hand (a spill reload waits behind every DMA in flight).
+"""Two encoder kernels request data with inline-asm `global_load_dwordx4 ... ; pending` long before they wait for it
+(`s_waitcnt ... ; release-pending`): oproj_ln_kernel its residual fragments (two stages early), ffn_ln_kernel the next
+group's activations (a stage early, across a barrier).  The compiler does not know that those registers are pending, so
+this script compiles the two translation units to ISA the way the Makefile does and checks that
+
+  * every marked load is followed by a marked release, and NO instruction between a load and that release reads or
+    writes one of the load's destination registers (a copy or a spill there would pick up stale data);
+  * the kernels whose waits are counted by hand do not spill inside their stage loops (a spill reload waits behind every
+    DMA in flight): none at all in oproj_ln_kernel / qkv_kernel, and in ffn_ln_kernel none between the two markers.
 
     python tools/check_pending_loads.py          # exit code 0 = clean
 """
@@ -14,13 +18,24 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ai-dial-rag_amd", "csrc")
-FLAGS = "-O3 -std=c++17 -fPIC -ffp-contract=on --offload-arch=gfx950".split()
+BASE = "-O3 -std=c++17 -fPIC -ffp-contract=on --offload-arch=gfx950".split()
+UNITS = {  # translation unit -> extra flags (ai-dial-rag_amd/csrc/Makefile)
+    "encoder": [],
+    "encoder_ffn": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+}
 
 
-def kernel_body(asm: str, mangled_prefix: str) -> list:
+def compile_asm(unit: str) -> str:
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = ["/opt/rocm/bin/hipcc", *BASE, *UNITS[unit], "-I" + CSRC, "-save-temps", "-c", os.path.join(CSRC, unit + ".hip"), "-o", os.devnull]
+        subprocess.run(cmd, cwd=tmp, check=True, stderr=subprocess.DEVNULL)
+        return open(os.path.join(tmp, unit + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+
+
+def kernel_body(asm: str, needle: str) -> list:
     lines = asm.split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith(mangled_prefix) and l.rstrip().split(";")[0].strip().endswith(":"))
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    start = next(i for i, l in enumerate(lines) if needle in l and l.startswith("_Z") and l.split(";")[0].strip().endswith(":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     return lines[start:end]
 
 
@@ -32,35 +47,43 @@ def regs_of(text: str):
             yield int(m.group(3))
 
 
-def main() -> int:
-    with tempfile.TemporaryDirectory() as tmp:
-        cmd = ["/opt/rocm/bin/hipcc", *FLAGS, "-I" + CSRC, "-save-temps", "-c", os.path.join(CSRC, "encoder.hip"), "-o", os.devnull]
-        subprocess.run(cmd, cwd=tmp, check=True, stderr=subprocess.DEVNULL)
-        asm = open(os.path.join(tmp, "encoder-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+def check_pending(name: str, body: list, expect_loads: int) -> int:
+    loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l and "; pending" in l]
+    releases = [i for i, l in enumerate(body) if "release-pending" in l]
     rc = 0
-    body = kernel_body(asm, "_ZN3mir3enc15oproj_ln_kernel")
-    loads = [(i, l) for i, l in enumerate(body) if "global_load_dwordx4" in l and ", s[" in l]
-    wait = next(i for i, l in enumerate(body) if "s_waitcnt vmcnt(8)" in l)
+    if len(loads) != expect_loads or len(releases) != 1 or not all(i < releases[0] for i in loads):
+        print(f"  {name}: UNEXPECTED: {len(loads)} marked loads (expected {expect_loads}), releases at {releases}")
+        return 1
+    release = releases[0]
     pending = {}
-    for i, l in loads:
-        for r in regs_of(l.split(",")[0]):
+    for i in loads:
+        for r in regs_of(body[i].split(";")[0].split(",")[0]):
             pending[r] = i
-    print(f"oproj_ln_kernel: {len(loads)} asm loads into {len(pending)} registers, wait at line {wait}")
-    if len(loads) != 12 or not all(i < wait for i, _ in loads):
-        print("  UNEXPECTED: 12 loads before the wait were expected")
-        rc = 1
-    for i in range(loads[0][0], wait):
-        line = body[i].split(";")[0]
-        if (i, body[i]) in loads:
+    for i in range(loads[0], release):
+        if i in loads:
             continue
-        hit = [r for r in regs_of(line) if r in pending and pending[r] < i]
-        if hit:
-            print(f"  TOUCHED before the wait: line {i}: {line.strip()}")
+        line = body[i].split(";")[0]
+        if any(r in pending and pending[r] < i for r in regs_of(line)):
+            print(f"  {name}: TOUCHED before the release: line {i}: {line.strip()}")
             rc = 1
-    for name in ("_ZN3mir3enc15oproj_ln_kernel", "_ZN3mir3enc10qkv_kernel"):
-        n = sum("scratch_" in l for l in kernel_body(asm, name))
+        if "scratch_" in line:
+            print(f"  {name}: spill between the loads and the release: line {i}: {line.strip()}")
+            rc = 1
+    print(f"{name}: {len(loads)} pending loads into {len(pending)} registers, released at line {release}: {'ok' if rc == 0 else 'NOT ok'}")
+    return rc
+
+
+def main() -> int:
+    rc = 0
+    enc = compile_asm("encoder")
+    oproj = kernel_body(enc, "oproj_ln_kernel")
+    rc |= check_pending("oproj_ln_kernel", oproj, 12)
+    for name in ("oproj_ln_kernel", "qkv_kernel"):
+        n = sum("scratch_" in l.split(";")[0] for l in kernel_body(enc, name))
         print(f"{name}: {n} scratch instructions")
         rc |= 1 if n else 0
+    ffn = kernel_body(compile_asm("encoder_ffn"), "ffn_ln_kernel")
+    rc |= check_pending("ffn_ln_kernel", ffn, 24)
     print("clean" if rc == 0 else "NOT clean")
     return rc
 
