@@ -1,7 +1,8 @@
 // FFN of the bge-small-en encoder: FFN1 + GELU + FFN2 + residual + LayerNorm in one kernel - see encoder_common.h
 // for the layouts.  Own translation unit, built with -mllvm -amdgpu-mfma-vgpr-form=1 (accumulators in VGPRs).
 //
-// Workgroup = 8 waves = 128 tokens, TWO waves per SIMD with different ROLES on the same 32-token tile:
+// Workgroup = 8 waves = one GROUP of 128 tokens at a time (one persistent workgroup per CU walks the groups, the pipeline
+// below does not drain between them: encoder_ffn_kernel.h), TWO waves per SIMD with different ROLES on the same 32-token tile:
 //   role A (waves 0-3)  h^T(ht) = gelu(W1(ht)^T x^T + b1): the tile's activations x stay in registers (96 VGPRs) as the B
 //                       operand, W1 streams through LDS; 24 MFMAs + 16 GELUs (~290 VALU) per intermediate tile ht;
 //                       hands h(ht) (2 KiB of float16 fragments) to its partner through LDS;
