@@ -107,13 +107,9 @@ class WordPieceTokenizer:
             raise NotImplementedError("the encoder path tokenises with special tokens and truncation (sentence-transformers does)")
         return {"input_ids": [a.tolist() for a in self.encode_arrays(texts, max_length)]}
 
-    def encode_arrays(self, texts: Sequence[str], max_length: int = 512) -> List[np.ndarray]:
-        """The same ids as int32 arrays (views of one matrix): what ``BgeEncoder`` feeds to ``mir_encoder_encode`` -
-        building 8192 Python lists of ~220 ints only to turn them back into arrays cost more than the GPU pass."""
-        texts = list(texts)
+    def _encode_matrix(self, texts: List[str], max_length: int):
+        """(ids [n, max_length] int32, lens [n] int32); rows the native tokenizer cannot do go through the fallback."""
         n = len(texts)
-        if n == 0:
-            return []
         enc = [t.encode("utf-8", "surrogatepass") for t in texts]
         ptr = np.zeros(n + 1, np.int64)
         np.cumsum([len(e) for e in enc], out=ptr[1:])
@@ -122,7 +118,6 @@ class WordPieceTokenizer:
         lens = np.zeros(n, np.int32)
         fb = np.zeros(n, np.uint8)
         nat.check(nat.lib.mir_wordpiece_encode(self._h, blob, nat.ptr(ptr), n, max_length, self.threads, nat.ptr(ids), nat.ptr(lens), nat.ptr(fb)))
-        out: List[np.ndarray] = [ids[i, : lens[i]] for i in range(n)]
         todo = np.flatnonzero(fb)
         if len(todo):
             if self.fallback is None:
@@ -130,8 +125,27 @@ class WordPieceTokenizer:
                                  "and no fallback tokenizer was given")
             got = self.fallback([texts[i] for i in todo], add_special_tokens=True, truncation=True, max_length=max_length)["input_ids"]
             for i, g in zip(todo, got):
-                out[int(i)] = np.asarray(g, dtype=np.int32)
-        return out
+                ids[int(i), : len(g)] = np.asarray(g, dtype=np.int32)
+                lens[int(i)] = len(g)
+        return ids, lens
+
+    def encode_arrays(self, texts: Sequence[str], max_length: int = 512) -> List[np.ndarray]:
+        """The same ids as int32 arrays (views of one matrix): what ``BgeEncoder`` feeds to ``mir_encoder_encode`` -
+        building 8192 Python lists of ~220 ints only to turn them back into arrays cost more than the GPU pass."""
+        texts = list(texts)
+        if not texts:
+            return []
+        ids, lens = self._encode_matrix(texts, max_length)
+        return [ids[i, : lens[i]] for i in range(len(texts))]
+
+    def encode_packed(self, texts: Sequence[str], max_length: int = 512):
+        """(flat ids int32, lens int32): the layout ``mir_encoder_encode`` takes, without a Python object per text - an
+        outer batch travels through the group commit of ``BgeEncoder.embed_documents_numpy`` as these two arrays."""
+        texts = list(texts)
+        if not texts:
+            return np.zeros(0, np.int32), np.zeros(0, np.int32)
+        ids, lens = self._encode_matrix(texts, max_length)
+        return np.ascontiguousarray(ids[np.arange(max_length, dtype=np.int32)[None, :] < lens[:, None]]), lens
 
     def close(self):
         if self._h:

@@ -1,6 +1,6 @@
 """Host logic of the index-build surface (embeddings.py:79-108, batched.py:35-53 upstream): outer batches of 128,
 results in order, progress lines - with concurrent outer batches sharing encoder passes.  No GPU: the encoder's
-forward (`encode_ids`, the only thing that crosses the C ABI) is replaced by a recording stand-in; the GPU run of
+forward (`encode_packed`, the only thing that crosses the C ABI) is replaced by a recording stand-in; the GPU run of
 the same surface is tests/test_gpu_encoder.py::test_build_embeddings_through_the_product_surface."""
 
 import asyncio
@@ -24,14 +24,17 @@ class RecordingEncoder(emb.BgeEncoder):
         self.passes = []
         self.lock = threading.Lock()
 
-    def encode_ids(self, sequences, normalize=True):
+    def encode_packed(self, flat, lens, normalize=True):
+        assert flat.dtype == np.int32 and lens.dtype == np.int32 and int(lens.sum()) == flat.shape[0]
         with self.lock:
-            self.passes.append(len(sequences))
+            self.passes.append(len(lens))
         time.sleep(0.02)  # a pass costs the same whatever its fill
-        out = np.zeros((len(sequences), emb.EMBEDDING_LENGTH), np.float32)
-        for i, s in enumerate(sequences):
-            out[i, 0] = len(s)
-            out[i, 1] = sum(s) % 9973
+        out = np.zeros((len(lens), emb.EMBEDDING_LENGTH), np.float32)
+        at = 0
+        for i, n in enumerate(lens):
+            out[i, 0] = n
+            out[i, 1] = int(flat[at : at + n].sum()) % 9973
+            at += n
         return out
 
     def close(self):

@@ -90,3 +90,19 @@ def test_beyond_bmp_goes_to_the_fallback_or_raises(toks):
         lone(["\U0001f600"])
     with pytest.raises(ValueError):
         WordPieceTokenizer(["a", "b"])  # no [UNK] / [CLS] / [SEP]
+
+
+def test_encode_packed_is_the_concatenation_of_encode_arrays(toks):
+    """The layout mir_encoder_encode takes (all ids back to back + lengths), incl. rows that went through the fallback,
+    truncated rows and the empty batch."""
+    import numpy as np
+
+    ref, mine, words = toks
+    texts = ["plain words here", "emoji \U0001f600 here", "", " ".join(words[:700]), "x"]
+    arrays = mine.encode_arrays(texts, 64)
+    flat, lens = mine.encode_packed(texts, 64)
+    assert flat.dtype == np.int32 and lens.dtype == np.int32 and flat.flags["C_CONTIGUOUS"]
+    assert lens.tolist() == [len(a) for a in arrays] and max(lens) == 64
+    assert flat.tolist() == [int(t) for a in arrays for t in a]
+    f0, l0 = mine.encode_packed([], 64)
+    assert f0.shape == (0,) and l0.shape == (0,)

@@ -1,9 +1,10 @@
 import os, sys, time, asyncio, tempfile
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 from aidial_rag_amd.embeddings import embeddings as emb
 from aidial_rag_amd.embeddings.wordpiece import WordPieceTokenizer
+if len(sys.argv) > 1: emb.BUILD_IN_FLIGHT = int(sys.argv[1])   # experiment: outer batches in flight
 rng = np.random.default_rng(7)
 letters = "abcdefghijklmnopqrstuvwxyz"
 words = ["".join(rng.choice(list(letters), rng.integers(2, 9))) for _ in range(20000)]
