@@ -164,6 +164,21 @@ __device__ __forceinline__ uint32_t enc_lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
 
+// Persistent kernels: every workgroup does the same work per group, so all 256 of them reach their HBM-heavy phase (the
+// epilogue's residual loads and stores, the next group's activations) at the same moment.  ENC_STAGGER > 0 starts the
+// workgroups in four phases, ENC_STAGGER x 64 clocks apart, so that those bursts interleave with the other phases' products.
+// Measured per 12288-tile pass (0 / 30 / 60 / 120): oproj_ln_kernel 206.8 / 204.7 / 198.2 / 197.6 us, ffn_ln_kernel 899.0 /
+// 897.0 / 893.8 / 893.0 us; the last phase finishes 3 x ENC_STAGGER x 64 clocks (~7 us) after the first.
+#ifndef ENC_STAGGER
+#define ENC_STAGGER 60
+#endif
+__device__ __forceinline__ void enc_stagger_start() {
+#if ENC_STAGGER > 0
+    const int phase = (blockIdx.x >> 3) & 3;  // workgroups go to the 8 XCDs round-robin: phases alternate inside an XCD
+    for (int i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(ENC_STAGGER);
+#endif
+}
+
 // Per-tile bookkeeping: which sequence a 32-token tile belongs to.
 struct TileInfo {
     int seq_first_tile;  // first tile of the tile's sequence

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
     auto tile_of = [&](int g) { const int t = g * 4 + tl; return t < n_tiles ? t : n_tiles - 1; };
     const uint32_t lane16 = (uint32_t)lane * 16u;
 
+    enc_stagger_start();
     for (int i = tid; i < FFN_PARAM_FLOATS; i += 512) prm[i] = params[i];
     for (int i = tid; i < GELU_LUT_FLOATS; i += 512) reinterpret_cast<float *>(lds_all)[i] = params[FFN_PARAM_FLOATS + i];
 

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
         enc_glds16_s(src + 64, lane16, dst + 1024);
     };
 
+    enc_stagger_start();
     int g = blockIdx.x;
     issue_w(0);
     issue_c(g, 0);

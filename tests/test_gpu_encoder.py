@@ -80,6 +80,28 @@ def test_batching_is_invariant(setup):
         np.testing.assert_array_equal(big[: len(small)], small)
 
 
+def test_persistent_kernels_across_groups_and_passes(setup):
+    """The FFN and output-projection kernels are persistent: one workgroup per CU walks 128-token groups and hands state
+    across group boundaries (next group's activations and first product, the finished group's LayerNorm inside the next
+    group's first stage, DMA rings that continue).  test_batching_is_invariant's 365 tiles are ONE group per workgroup;
+    here ~13 300 tiles = 3 300 groups (13 per workgroup, the last ones partial, not a multiple of 4 tiles) in two encoder
+    passes, and every sampled sequence must equal, bit for bit, its embedding computed alone on the latency kernels."""
+    model, enc, seqs, oe = setup
+    rng = np.random.default_rng(11)
+    lens = rng.integers(1, 513, 1600).tolist() + [33, 1, 512, 65]
+    many = [rng.integers(999, 30522, int(L)).tolist() for L in lens]
+    tiles = sum((len(s) + 31) // 32 for s in many)
+    assert tiles > 12288 + 256 and tiles % 4 != 0, tiles
+    got = enc.encode_ids(many)
+    assert np.isfinite(got).all()
+    pick = list(range(0, len(many), 97)) + list(range(len(many) - 6, len(many)))
+    alone = np.stack([enc.encode_ids([many[i]])[0] for i in pick])
+    np.testing.assert_array_equal(got[pick], alone)
+    # and against the float32 reference model
+    want = oe.embed(model, [many[i] for i in pick[:8]])
+    assert ((got[pick[:8]] * want).sum(1)).min() > 0.9995
+
+
 def test_argument_errors(setup):
     model, enc, seqs, oe = setup
     with pytest.raises(ValueError):
