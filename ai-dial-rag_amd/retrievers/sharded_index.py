@@ -80,7 +80,10 @@ class ShardedSearcher:
         """queries: float64 [b, d] torch tensor on `self.device` (GPU path) or array-like (CPU path).
         Returns (dist[b,k] f64, rows[b,k] i64 global, count[b] i32, flags[b] i32) tensors; asynchronous on
         the current stream on the GPU path.  `out_flags` (GPU path): an int32 [b] tensor to receive this call's
-        flags instead of the searcher's own buffer, which the next call overwrites."""
+        flags instead of the searcher's own buffer, which the next call overwrites.  The flags are THIS rank's and
+        informational (MIR_FLAG_EXACT_PASS: the shard answered the query by its exact pass): every shard's top-k is the
+        exact one either way (vec_index.hip), so the merged result does not depend on another rank's flags and the
+        all-gather does not carry them."""
         t = self.torch
         metric = Metric(metric).value
         b = int(queries.shape[0])
