@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 // form 363 us; letting the second wave of each SIMD run half a stage late (its epilogue under the first wave's MFMAs)
 // needs the accumulators across the barrier, spills 28 registers, and every spill reload waits behind the DMAs in
 // flight: 484 us.  By ablation the 376 us are ~200 us of MFMAs, ~75 us attributable to the Q/K/V stores (0.9 GB per pass)
-// and the per-stage epilogue; the kernel is not L2-bound (24 KiB of weights per stage and CU).
+// and the per-stage epilogue; the kernel is not L2-bound (24 KiB of weights per stage and CU).  Starting the workgroups
+// in four phases 2.4 or 4.8 us apart (enc_stagger_start, which helps the persistent kernels) changes nothing here: 348 / 350 / 352 us.
 // Q, K come out as W^T x^T (rows = head features, lanes = tokens); V as x W (rows = tokens, lanes = head features) so
 // that each is directly the operand the attention kernel needs.  Output fragment buffers: [tile][head][s2][64].
 #ifndef QKV_G_
