@@ -5,6 +5,7 @@ import bench
 from aidial_rag_amd.embeddings import embeddings as emb
 from aidial_rag_amd.embeddings.wordpiece import WordPieceTokenizer
 if len(sys.argv) > 1: emb.BUILD_IN_FLIGHT = int(sys.argv[1])   # experiment: outer batches in flight
+if len(sys.argv) > 2: sys.setswitchinterval(float(sys.argv[2]))  # experiment: the GIL's switch interval (default 0.005 s)
 rng = np.random.default_rng(7)
 letters = "abcdefghijklmnopqrstuvwxyz"
 words = ["".join(rng.choice(list(letters), rng.integers(2, 9))) for _ in range(20000)]
