@@ -371,7 +371,10 @@ int32_t ffn_prepare();  // once per process: dynamic-LDS attribute
 // GELU and residual_ln_store): a sequence's embedding is bit-identical on either path, which
 // test_batching_is_invariant holds both to.
 // measured crossover (tools/encoder_latency.py): 64 tiles 1.07 vs 2.38 ms, 256 tiles 1.80 vs 2.49 ms, 512 tiles 2.87 vs 2.62 ms
-constexpr int kSmallTiles = 256;
+#ifndef ENC_SMALL_TILES
+#define ENC_SMALL_TILES 256
+#endif
+constexpr int kSmallTiles = ENC_SMALL_TILES;
 // one wave per SIMD is the plan for these kernels (a handful of waves per CU at most): tell the scheduler, or it
 // keeps register pressure low for an occupancy nobody wants and sinks the prefetches back next to their uses
 #define MIR_ONE_WAVE __attribute__((amdgpu_waves_per_eu(1, 1)))

@@ -1,11 +1,13 @@
 // Diagnostic build of the encoder's FFN kernel with in-kernel time stamps (never part of the library):
 //   hipcc -O3 -std=c++17 -ffp-contract=on -mllvm -amdgpu-mfma-vgpr-form=1 --offload-arch=gfx950 -I ai-dial-rag_amd/csrc tools/ffn_stamps.hip -o /tmp/ffn_stamps
 // Random weights / activations of a full 3072-tile pass; prints, for workgroup 0, the cycles of each stage per wave
-// (barrier exit -> end of the wave's stage work -> next barrier exit).
+// (barrier exit -> end of the wave's stage work -> next barrier exit), for the workgroup's FIRST group (the kernel is
+// persistent: 256 workgroups walk the groups).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "common.h"
 namespace mir { void set_error(const char *, ...) {} }
 #include "encoder_ffn_kernel.h"
@@ -30,7 +32,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 40; ++rep) {
         if (rep == 20) CK(hipEventRecord(e0));
-        kern<<<dim3((n_tiles + 3) / 4), dim3(512), FFN_LDS_BYTES>>>((const uint4 *)act, n_tiles, (const unsigned char *)w, (const float *)p, (uint4 *)out, st);
+        kern<<<dim3(std::min((n_tiles + 3) / 4, FFN_MAX_GRID)), dim3(512), FFN_LDS_BYTES>>>((const uint4 *)act, n_tiles, (const unsigned char *)w, (const float *)p, (uint4 *)out, st);
     }
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
