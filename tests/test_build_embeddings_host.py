@@ -83,3 +83,14 @@ def test_concurrent_documents_share_passes():
         assert sum(enc.passes) == 1200 and len(enc.passes) < 12  # 12 outer batches in fewer passes
     finally:
         emb.set_bge_embedding_impl(None)
+
+
+def test_encode_packed_checks_its_lengths_before_the_c_abi():
+    import pytest
+
+    enc = emb.BgeEncoder(None, 12, None, 0)
+    try:
+        with pytest.raises(ValueError, match="lengths"):
+            enc.encode_packed(np.zeros(3, np.int32), np.asarray([2], np.int32))
+    finally:
+        enc.close = lambda: None
