@@ -160,6 +160,38 @@ __device__ __forceinline__ void enc_glds16_s(const void *uniform_base, uint32_t 
                  : "v"(lane_byte_off), "s"(uniform_base), "s"(lds_byte_addr)
                  : "memory");
 }
+// ... non-temporal: for data that is read once (activations), so that it does not push the layer's weights - which every
+// workgroup re-reads - out of the L2s (ENC_NT = 0 switches all such hints off, for A/B runs)
+#ifndef ENC_NT
+#define ENC_NT 1
+#endif
+__device__ __forceinline__ void enc_glds16_s_nt(const void *uniform_base, uint32_t lane_byte_off, uint32_t lds_byte_addr) {
+#if ENC_NT
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_off), "s"(uniform_base), "s"(lds_byte_addr)
+                 : "memory");
+#else
+    enc_glds16_s(uniform_base, lane_byte_off, lds_byte_addr);
+#endif
+}
+__device__ __forceinline__ uint4 enc_load_nt(const uint4 *p) {
+#if ENC_NT
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void enc_store_nt(uint4 *p, uint4 v) {
+#if ENC_NT
+    const u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(p));
+#else
+    *p = v;
+#endif
+}
 __device__ __forceinline__ uint32_t enc_lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
@@ -313,7 +345,7 @@ __device__ __forceinline__ float ln_part_sq(f32x16 (&y)[NB], float mean) {
         }
     return sq;
 }
-template <int NB, bool PIN_CVT, bool PF = true>
+template <int NB, bool PIN_CVT, bool PF = true, bool NT = false>
 __device__ __forceinline__ void ln_part_store(f32x16 (&y)[NB], int fb0, float rstd, const float *__restrict__ gamma,
                                               const float *__restrict__ beta, uint4 *__restrict__ out_tile, int lane, bool store) {
     const int h = lane >> 5;
@@ -348,12 +380,19 @@ __device__ __forceinline__ void ln_part_store(f32x16 (&y)[NB], int fb0, float rs
         }
         if (store) {
             const int fb = fb0 + f;
-            out_tile[(fb * 2 + 0) * 64 + lane] =
+            const uint4 w0 =
                 PIN_CVT ? make_uint4(pack2_rn(o[0], o[1]), pack2_rn(o[2], o[3]), pack2_rn(o[4], o[5]), pack2_rn(o[6], o[7]))
                         : make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
-            out_tile[(fb * 2 + 1) * 64 + lane] =
+            const uint4 w1 =
                 PIN_CVT ? make_uint4(pack2_rn(o[8], o[9]), pack2_rn(o[10], o[11]), pack2_rn(o[12], o[13]), pack2_rn(o[14], o[15]))
                         : make_uint4(pack2(o[8], o[9]), pack2(o[10], o[11]), pack2(o[12], o[13]), pack2(o[14], o[15]));
+            if (NT) {
+                enc_store_nt(&out_tile[(fb * 2 + 0) * 64 + lane], w0);
+                enc_store_nt(&out_tile[(fb * 2 + 1) * 64 + lane], w1);
+            } else {
+                out_tile[(fb * 2 + 0) * 64 + lane] = w0;
+                out_tile[(fb * 2 + 1) * 64 + lane] = w1;
+            }
         }
     }
 }

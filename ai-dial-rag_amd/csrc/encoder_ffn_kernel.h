@@ -11,6 +11,7 @@ namespace enc {
 #ifndef FFN_RING
 #define FFN_RING 4
 #endif
+#define FFN_NT ENC_NT  // non-temporal activation loads / stores (encoder_common.h)
 // Of the six 1-KiB pieces of a W1 half that belong to token tile tl, the A wave of the tile moves the first
 // FFN_A_PIECES and its B wave the rest (plus its six pieces of the W2 half): an LDS-DMA piece costs the issuing wave
 // 75-100 cycles, so the split balances the two roles' stage times (tools/ffn_stamps.hip).
@@ -34,18 +35,36 @@ __device__ __forceinline__ void ffn_epilogue(f32x16 (&y)[NFB], const uint4 *__re
                                              bool store) {
     const int h = lane >> 5;
     constexpr int HB = NFB / 2;
+    // activations are read once and written once: non-temporal, so that they do not push the layer's weights (which every
+    // workgroup re-reads) out of the L2s
+    auto ld = [&](int i) {
+#if FFN_NT
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(resid_tile) + i * 64 + lane);
+        return make_uint4(t.x, t.y, t.z, t.w);
+#else
+        return resid_tile[i * 64 + lane];
+#endif
+    };
+    auto st4 = [&](int i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+#if FFN_NT
+        const u32x4 t = {a, b, c, d};
+        __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(out_tile) + i * 64 + lane);
+#else
+        out_tile[i * 64 + lane] = make_uint4(a, b, c, d);
+#endif
+    };
     uint4 rr[3][2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        rr[f][0] = resid_tile[(f * 2 + 0) * 64 + lane];
-        rr[f][1] = resid_tile[(f * 2 + 1) * 64 + lane];
+        rr[f][0] = ld(f * 2 + 0);
+        rr[f][1] = ld(f * 2 + 1);
     }
     float sum[2] = {0.f, 0.f};
 #pragma unroll
     for (int f = 0; f < NFB; ++f) {
         if (f + 2 < NFB) {
-            rr[(f + 2) % 3][0] = resid_tile[((f + 2) * 2 + 0) * 64 + lane];
-            rr[(f + 2) % 3][1] = resid_tile[((f + 2) * 2 + 1) * 64 + lane];
+            rr[(f + 2) % 3][0] = ld((f + 2) * 2 + 0);
+            rr[(f + 2) % 3][1] = ld((f + 2) * 2 + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -93,7 +112,7 @@ __device__ __forceinline__ void ffn_epilogue(f32x16 (&y)[NFB], const uint4 *__re
                 w[2 * gq] = pack2_rn(o0, o1);
                 w[2 * gq + 1] = pack2_rn(o2, o3);
             }
-            if (store) out_tile[(f * 2 + s2) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+            if (store) st4(f * 2 + s2, w[0], w[1], w[2], w[3]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -223,7 +242,11 @@ __global__ __launch_bounds__(512, 2) void ffn_ln_kernel(const uint4 *__restrict_
                 nxt = mfma(fr[ks % FFN_RING], x[ks], nxt);
                 if (MODE == 1) {
                     u32x4 t;
+                    #if FFN_NT
+                    asm volatile("global_load_dwordx4 %0, %1, %2 nt ; pending" : "=v"(t) : "v"(lane16), "s"(x_next + ks * 64) : "memory");
+#else
                     asm volatile("global_load_dwordx4 %0, %1, %2 ; pending" : "=v"(t) : "v"(lane16), "s"(x_next + ks * 64) : "memory");
+#endif
                     x[ks] = make_uint4(t.x, t.y, t.z, t.w);
                 }
                 if (ks < 16) {

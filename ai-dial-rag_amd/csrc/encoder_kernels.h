@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void qkv_kernel(const uint4 *__r
     for (int g = 0; g < QKV_G; ++g) {
         const uint4 *xin = act + (size_t)tt[g] * (NFB * 2 * 64) + lane;
 #pragma unroll
-        for (int ks = 0; ks < KS_H; ++ks) x[g][ks] = xin[ks * 64];
+        for (int ks = 0; ks < KS_H; ++ks) x[g][ks] = enc_load_nt(xin + ks * 64);  // read once here (the FFN's LayerNorm re-reads it as the residual much later)
     }
     // ordinary loads are complete before the first DMA: the counted waits below count DMAs and stores only
 #pragma unroll
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
         const int t = t_raw < n_tiles ? t_raw : n_tiles - 1;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(OPROJ_C_BASE + (st % 3) * OPROJ_C_SLOT + wave * 2 * 1024));
         const uint4 *src = ctx + (size_t)t * (NFB * 2 * 64) + (size_t)(OPROJ_KC * st + 2 * (wave & 1)) * 64;
-        enc_glds16_s(src, lane16, dst);
-        enc_glds16_s(src + 64, lane16, dst + 1024);
+        enc_glds16_s_nt(src, lane16, dst);  // the context is read once
+        enc_glds16_s_nt(src + 64, lane16, dst + 1024);
     };
 
     enc_stagger_start();
@@ -297,7 +297,11 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
 #pragma unroll
                 for (int i = 0; i < HB * 2; ++i) {
                     u32x4 t;
+                    #if ENC_NT
+                    asm volatile("global_load_dwordx4 %0, %1, %2 nt ; pending" : "=v"(t) : "v"(lane16), "s"(resid + (HB * hf * 2 + i) * 64) : "memory");
+#else
                     asm volatile("global_load_dwordx4 %0, %1, %2 ; pending" : "=v"(t) : "v"(lane16), "s"(resid + (HB * hf * 2 + i) * 64) : "memory");
+#endif
                     rr[i] = make_uint4(t.x, t.y, t.z, t.w);
                 }
             }
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void oproj_ln_kernel(const uint4 *__restric
         xs[(1 * 8 + wave) * 64 + lane] = pq;
         __syncthreads();
         const float rstd = rsqrtf(half_sum(xs[(1 * 8 + tl) * 64 + lane] + xs[(1 * 8 + 4 + tl) * 64 + lane]) * (1.0f / H) + LN_EPS);
-        ln_part_store<HB, false>(y, HB * hf, rstd, p_gamma, p_beta, act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
+        ln_part_store<HB, false, true, true>(y, HB * hf, rstd, p_gamma, p_beta, act_out + (size_t)tt * (NFB * 2 * 64), lane, live);
         stores_in_flight = live;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetches target this workgroup's LDS: they land before it is released
