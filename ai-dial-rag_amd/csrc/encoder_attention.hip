@@ -54,8 +54,8 @@ __device__ __forceinline__ void attn_store(AttnState &st, uint4 *__restrict__ ou
     const float inv = 1.0f / st.lsum[0];
 #pragma unroll
     for (int r = 0; r < 16; ++r) st.o[r] *= inv;
-    out[0] = acc_to_frag(st.o, 0);
-    out[64] = acc_to_frag(st.o, 1);
+    enc_store_nt(out, acc_to_frag(st.o, 0));  // the context is read once, by the output projection (measured: within noise
+    enc_store_nt(out + 64, acc_to_frag(st.o, 1));  // for this kernel, 361 vs 364 us; the projection after it 197 vs 202 us)
 }
 
 // One wave per (head, query tile): light on registers, so several waves share a SIMD and
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict_
     const TileInfo info = ti[tt];
     // Q arrives pre-multiplied by log2(e) / sqrt(32) (qkv kernels): the scores are exp2 arguments as they leave the MFMA
     const uint4 *qp = qf + ((size_t)(tt * NH + head) * 2) * 64 + lane;
-    const uint4 q0 = qp[0], q1 = qp[64];
+    const uint4 q0 = enc_load_nt(qp), q1 = enc_load_nt(qp + 64);  // Q is read once; K / V are shared by the sequence's query tiles
     const int n_kt = __builtin_amdgcn_readfirstlane(info.seq_tiles);  // a tile's bookkeeping is wave-uniform: scalar loop control
     const int seq_len = __builtin_amdgcn_readfirstlane(info.seq_len);
     const size_t kv0 = ((size_t)(__builtin_amdgcn_readfirstlane(info.seq_first_tile) * NH + head) * 2) * 64 + lane;
