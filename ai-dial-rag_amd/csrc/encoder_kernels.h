@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 constexpr int QKV_G = QKV_G_;                                 // token tiles per wave
 constexpr int QKV_WAVES = QKV_WAVES_;                         // waves per workgroup
 constexpr int QKV_PIECES = KS_H / QKV_WAVES;                  // DMA pieces per wave and stage
-constexpr int QKV_NS = 4;                                     // ring stages
+#ifndef QKV_NS_
+#define QKV_NS_ 4
+#endif
+constexpr int QKV_NS = QKV_NS_;                               // ring stages
 constexpr int QKV_STAGE_BYTES = KS_H * 1024;                  // one weight tile
 constexpr int QKV_LDS_BYTES = QKV_NS * QKV_STAGE_BYTES + 3 * H * 4;  // + the biases
 
@@ -135,8 +138,9 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void qkv_kernel(const uint4 *__r
         constexpr bool is_v = decltype(IS_V_)::value;
         for (int tile = tile_lo; tile < tile_hi; ++tile) {
             // Younger than this stage's DMA pieces, in issue order: stores(tile-3), DMA(tile+1), stores(tile-2), DMA(tile+2),
-            // stores(tile-1) = 3 * 2 QKV_G + 2 QKV_PIECES operations once the pipeline is full; the first and last stages simply drain.
-            if (tile >= 3 && tile + QKV_NS - 1 <= 36) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * 2 * QKV_G + 2 * QKV_PIECES) : "memory");
+            // stores(tile-1) (for QKV_NS = 4; in general QKV_NS - 1 store batches and QKV_NS - 2 DMA batches) once the pipeline is full;
+            // the first and last stages simply drain.
+            if (tile >= QKV_NS - 1 && tile + QKV_NS - 1 <= 36) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QKV_NS - 1) * 2 * QKV_G + (QKV_NS - 2) * QKV_PIECES) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // stage `tile` is in LDS for everyone; everyone is done with stage tile - 1
             if (tile + QKV_NS - 1 < 36) issue(tile + QKV_NS - 1);
