@@ -44,6 +44,13 @@ def timed(name, fn, reps=10):
 
 
 blob, gathered, *_ = kw._buffers(B, k)
+o_row = torch.zeros((B, k), dtype=torch.int64, device=dev); o_dist = torch.zeros((B, k), dtype=torch.float64, device=dev)
+o_cnt = torch.zeros(B, dtype=torch.int32, device=dev); o_flag = torch.zeros(B, dtype=torch.int32, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+timed("local vector search only, no sync", lambda: index.search_device(q.data_ptr(), B, k, "sqeuclidean_dist", out_row_ptr=o_row.data_ptr(), out_dist_ptr=o_dist.data_ptr(),
+                                                                          out_count_ptr=o_cnt.data_ptr(), out_flags_ptr=o_flag.data_ptr(), stream=stream))
+timed("local vector search + stream sync", lambda: (index.search_device(q.data_ptr(), B, k, "sqeuclidean_dist", out_row_ptr=o_row.data_ptr(), out_dist_ptr=o_dist.data_ptr(),
+                                                                          out_count_ptr=o_cnt.data_ptr(), out_flags_ptr=o_flag.data_ptr(), stream=stream), torch.cuda.synchronize()))
 timed("vector leg (search + gather + merge)", lambda: se.search(q, k, "sqeuclidean_dist"))
 timed("BM25 leg (search + gather + merge)", lambda: kw.search(flat, k, ptr))
 timed("all_gather_into_tensor alone", lambda: dist.all_gather_into_tensor(gathered, blob))
