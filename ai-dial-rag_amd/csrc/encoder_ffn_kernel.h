@@ -11,6 +11,11 @@ namespace enc {
 #ifndef FFN_RING
 #define FFN_RING 4
 #endif
+// residual blocks the epilogue keeps in flight ahead of the one it is adding (measured 2 / 3 / 4 / 6: 873 / 882 / 883 / 904 us
+// per 12288-tile pass - every block more costs registers the accumulators do not leave: 10 / 16 / 17 spills)
+#ifndef FFN_EPI_AHEAD
+#define FFN_EPI_AHEAD 2
+#endif
 #define FFN_NT ENC_NT  // non-temporal activation loads / stores (encoder_common.h)
 // Of the six 1-KiB pieces of a W1 half that belong to token tile tl, the A wave of the tile moves the first
 // FFN_A_PIECES and its B wave the rest (plus its six pieces of the W2 half): an LDS-DMA piece costs the issuing wave
@@ -29,7 +34,7 @@ static_assert(GELU_LUT_FLOATS * 4 <= FFN_LUT_BYTES, "GELU table");
 // wave whose registers are full: it runs INSIDE the persistent loop with all 192 accumulator registers live, and with the
 // shared helper (parameters a block ahead, residual three blocks at a time, the scheduler free to overlap blocks) hipcc
 // spilled most of y around it (180-270 registers; 17 when the same code ran once after the loop).  Here: the residual two
-// blocks ahead in a ring of three (24 registers), parameters (LDS) a float4 at a time, a scheduling fence per block.
+// blocks ahead in a ring of three (24 registers; FFN_EPI_AHEAD), parameters (LDS) a float4 at a time, a scheduling fence per block.
 __device__ __forceinline__ void ffn_epilogue(f32x16 (&y)[NFB], const uint4 *__restrict__ resid_tile, const float *bias,
                                              const float *gamma, const float *beta, uint4 *__restrict__ out_tile, int lane,
                                              bool store) {
@@ -53,24 +58,25 @@ __device__ __forceinline__ void ffn_epilogue(f32x16 (&y)[NFB], const uint4 *__re
         out_tile[i * 64 + lane] = make_uint4(a, b, c, d);
 #endif
     };
-    uint4 rr[3][2];
+    constexpr int AHEAD = FFN_EPI_AHEAD;  // residual blocks in flight ahead of the one being added (ring of AHEAD + 1)
+    uint4 rr[AHEAD + 1][2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < AHEAD; ++f) {
         rr[f][0] = ld(f * 2 + 0);
         rr[f][1] = ld(f * 2 + 1);
     }
     float sum[2] = {0.f, 0.f};
 #pragma unroll
     for (int f = 0; f < NFB; ++f) {
-        if (f + 2 < NFB) {
-            rr[(f + 2) % 3][0] = ld((f + 2) * 2 + 0);
-            rr[(f + 2) % 3][1] = ld((f + 2) * 2 + 1);
+        if (f + AHEAD < NFB) {
+            rr[(f + AHEAD) % (AHEAD + 1)][0] = ld((f + AHEAD) * 2 + 0);
+            rr[(f + AHEAD) % (AHEAD + 1)][1] = ld((f + AHEAD) * 2 + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float rv[8];
-            frag_to_floats(rr[f % 3][s2], rv);
+            frag_to_floats(rr[f % (AHEAD + 1)][s2], rv);
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 const int g = 2 * s2 + gq;
