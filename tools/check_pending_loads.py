@@ -1,7 +1,7 @@
 """Two encoder kernels request data with inline-asm `global_load_dwordx4 ... ; pending` long before they wait for it
 (`s_waitcnt ... ; release-pending`): oproj_ln_kernel its residual fragments (two stages early), ffn_ln_kernel the next
 group's activations (a stage early, across a barrier).  The compiler does not know that those registers are pending, so
-this script compiles the two translation units to ISA the way the Makefile does and checks that
+this script compiles the two translation units to ISA with the Makefile's own command line and checks that
 
   * every marked load is followed by a marked release, and NO instruction between a load and that release reads or
     writes one of the load's destination registers (a copy or a spill there would pick up stale data);
@@ -18,16 +18,18 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ai-dial-rag_amd", "csrc")
-BASE = "-O3 -std=c++17 -fPIC -ffp-contract=on --offload-arch=gfx950".split()
-UNITS = {  # translation unit -> extra flags (ai-dial-rag_amd/csrc/Makefile)
-    "encoder": [],
-    "encoder_ffn": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-}
 
 
 def compile_asm(unit: str) -> str:
+    """The ISA of <unit>.hip, compiled with EXACTLY the command the Makefile uses for build/<unit>.o (asked of `make -n`),
+    plus -save-temps, in a scratch directory."""
+    dry = subprocess.run(["make", "-C", CSRC, "-n", "-B", f"build/{unit}.o"], check=True, capture_output=True, text=True).stdout
+    line = next(l for l in dry.splitlines() if "hipcc" in l and f"{unit}.hip" in l)
+    words = line.split()
+    cut = words.index("-c")
+    flags = words[1:cut]  # everything between the compiler and `-c <source> -o <object>`
     with tempfile.TemporaryDirectory() as tmp:
-        cmd = ["/opt/rocm/bin/hipcc", *BASE, *UNITS[unit], "-I" + CSRC, "-save-temps", "-c", os.path.join(CSRC, unit + ".hip"), "-o", os.devnull]
+        cmd = [words[0], *flags, "-I" + CSRC, "-save-temps", "-c", os.path.join(CSRC, unit + ".hip"), "-o", os.devnull]
         subprocess.run(cmd, cwd=tmp, check=True, stderr=subprocess.DEVNULL)
         return open(os.path.join(tmp, unit + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 
