@@ -28,7 +28,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from .. import _native as nat
-from .sharded_index import _blob_layout
+from .sharded_index import DistCollective, _blob_layout
 
 _I64_MAX = np.iinfo(np.int64).max
 
@@ -77,6 +77,23 @@ def exchange_global_stats(local, vocab: int, group=None, device="cpu", epsilon: 
     return idf, avgdl, avg_idf, n_g
 
 
+def install_combined_stats(shards, epsilon: float = 0.25):
+    """Several document shards held by ONE process (in global document order): combine their corpus statistics the
+    way `exchange_global_stats` does across ranks - df summed, every term's first token position taken globally,
+    tokens and documents summed - and install the global idf / avgdl on each.  -> (idf, avgdl, average_idf, n_docs)."""
+    stats = [s.corpus_stats() for s in shards]
+    total, n_docs = sum(int(s[2]) for s in stats), sum(int(s[3]) for s in stats)
+    if total == 0:
+        raise ValueError("Text index is empty.")
+    df = np.sum([np.asarray(s[0], np.int64) for s in stats], axis=0)
+    offs = np.cumsum([0] + [int(s[2]) for s in stats])
+    first = np.min([np.where(np.asarray(s[1]) == _I64_MAX, _I64_MAX, np.asarray(s[1], np.int64) + o) for s, o in zip(stats, offs)], axis=0)
+    idf, avg_idf = idf_from_stats(df, first, n_docs, epsilon)
+    for s in shards:
+        s.set_global_stats(idf, total / n_docs, avg_idf)
+    return idf, total / n_docs, avg_idf, n_docs
+
+
 class ShardedBM25:
     """BM25 top-k over a corpus sharded by document across the ranks of a process group.
 
@@ -84,13 +101,12 @@ class ShardedBM25:
     `local_search` is given: a callable ``(queries: list of term-id lists, k) -> (idx[b,k] global, score[b,k],
     count[b])`` that stands in for the HIP kernels in the CPU tests."""
 
-    def __init__(self, local_model=None, group=None, device: Optional[str] = None, local_search=None):
+    def __init__(self, local_model=None, group=None, device: Optional[str] = None, local_search=None, collective=None):
         import torch
-        import torch.distributed as dist
 
-        self.torch, self.dist, self.group = torch, dist, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.torch = torch
+        self.collective = collective if collective is not None else DistCollective(group)
+        self.world, self.rank = self.collective.world, self.collective.rank
         if (local_model is None) == (local_search is None):
             raise ValueError("give exactly one of local_model / local_search")
         self.model, self.local_search = local_model, local_search
@@ -152,7 +168,7 @@ class ShardedBM25:
         if self.world == 1:
             src = blob
         else:
-            self.dist.all_gather_into_tensor(gathered, blob, group=self.group)
+            self.collective.all_gather_into_tensor(gathered, blob)
             src = gathered
         if self.on_gpu:
             base = src.data_ptr()

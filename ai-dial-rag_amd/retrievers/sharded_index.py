@@ -27,6 +27,52 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
+class DistCollective:
+    """The exchange step over ``torch.distributed`` ("nccl" = RCCL on the GPUs, "gloo" in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def all_gather_into_tensor(self, gathered, blob):
+        self.dist.all_gather_into_tensor(gathered, blob, group=self.group)
+
+
+class LoopbackCollective:
+    """`world` shards of ONE process (one thread per shard, all on the same device and stream) exchanging their blobs
+    by device-to-device copies: the layout ``all_gather_into_tensor`` produces - rank s's blob at offset s * size of
+    every rank's gathered tensor - without a process group.  It exists so that the `world > 1` branch of the sharded
+    searchers (per-shard search into a blob, gathered blobs with a non-zero shard stride, the library merge) runs on
+    the real kernels of a single GPU (tests/test_gpu_sharded_c4.py); `for_rank(r)` is what shard r's searcher gets."""
+
+    def __init__(self, world: int):
+        import threading
+
+        self.world = world
+        self._barrier = threading.Barrier(world)
+        self._blobs = [None] * world
+
+    def for_rank(self, rank: int):
+        return _LoopbackRank(self, rank)
+
+
+class _LoopbackRank:
+    def __init__(self, bus: LoopbackCollective, rank: int):
+        self.bus, self.rank, self.world = bus, rank, bus.world
+
+    def all_gather_into_tensor(self, gathered, blob):
+        bus = self.bus
+        bus._blobs[self.rank] = blob
+        bus._barrier.wait()  # every shard's search is enqueued (same stream: the copies below run behind all of them)
+        n = blob.numel()
+        for s in range(self.world):
+            gathered[s * n : (s + 1) * n].copy_(bus._blobs[s])
+        bus._barrier.wait()  # nobody reuses its blob before every rank has enqueued its copies
+
+
 def _blob_layout(b: int, k: int):
     """Byte offsets of {dist f64[b][k], row i64[b][k], count i32[b]} and the padded blob size."""
     off_row = b * k * 8
@@ -45,14 +91,12 @@ class ShardedSearcher:
     """
 
     def __init__(self, local_index=None, group=None, device: Optional[str] = None,
-                 local_search: Optional[Callable] = None):
+                 local_search: Optional[Callable] = None, collective=None):
         import torch
-        import torch.distributed as dist
 
-        self.torch, self.dist = torch, dist
-        self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.torch = torch
+        self.collective = collective if collective is not None else DistCollective(group)
+        self.world, self.rank = self.collective.world, self.collective.rank
         self.index = local_index
         self.local_search = local_search
         if (local_index is None) == (local_search is None):
@@ -113,7 +157,7 @@ class ShardedSearcher:
         if self.world == 1:
             src = blob
         else:
-            self.dist.all_gather_into_tensor(gathered, blob, group=self.group)
+            self.collective.all_gather_into_tensor(gathered, blob)
             src = gathered
         if self.on_gpu:
             base = src.data_ptr()

@@ -406,11 +406,43 @@ def build_embeddings_leg(np, torch, args, local_rank, tmpdir):
         enc.close()
 
 
-def hybrid_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher):
+def bm25_grouping_on_device(np, torch, device, indptr, toks, vocab):
+    """`oracle.bm25.group_postings` - the INTEGER bookkeeping of the CSR restatement: distinct (term, document) pairs
+    grouped by term, their term frequencies, document frequencies, first positions - with the sort done by torch on the
+    GPU (the numpy sort needs minutes at 1e9 tokens).  Checker plumbing only: every float64 operation of the oracle
+    stays in oracle/bm25.py.  Equality with the oracle's own numpy grouping: tests/test_gpu_sharded_c4.py."""
+    n = len(indptr) - 1
+    t = torch.from_numpy(np.ascontiguousarray(toks)).to(device)
+    lens = torch.from_numpy(np.diff(indptr)).to(device)
+    doc = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=device), lens)
+    key = t.to(torch.int64) * n + doc
+    del doc
+    first = torch.full((vocab,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=device)
+    first.scatter_reduce_(0, t.to(torch.int64), torch.arange(len(toks), dtype=torch.int64, device=device), reduce="amin")
+    del t
+    key, _ = torch.sort(key)
+    ukey, tf = torch.unique_consecutive(key, return_counts=True)
+    del key
+    out = ((ukey % n).cpu().numpy(), tf.cpu().numpy().astype(np.int64),
+           torch.bincount(ukey // n, minlength=vocab).cpu().numpy().astype(np.int64), first.cpu().numpy())
+    del ukey, tf
+    torch.cuda.empty_cache()
+    return out
+
+
+HYBRID_TERMS = 3   # keyword terms per hybrid query
+HYBRID_BATCHES = 32  # distinct query batches: every preconditioning and timed step gets fresh queries
+
+
+def hybrid_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher, check):
     """BASELINE config 4: hybrid semantic + BM25 + fusion, chunks sharded by row / document across the GPUs (weak
     scaling: --hybrid-docs chunks per GPU; 8 GPUs x 1.25M = the 10M chunks of C4).  A step = B queries through the
     vector leg (scan + exact re-score + all-gather + merge), the BM25 leg (per-shard scoring + top-k, all-gather,
-    merge with the reversed tie-break) and the host fusion of the two k = 7 lists (retrieval_chain.py:203-245)."""
+    merge with the reversed tie-break) and the host fusion of the two k = 7 lists (retrieval_chain.py:203-245).
+    The two legs index the SAME chunks and a query asks both about the same thing: its vector lies near a target
+    chunk's embedding and its keywords are that chunk's three rarest terms, so the legs' results overlap and the
+    fusion's score-summing / de-duplication runs.  Every step takes a fresh batch of queries.  `check` (one GPU): the
+    last batch's first queries against the unsharded oracle pipeline (oracle.find_flat + oracle.bm25 + oracle.fusion)."""
     from aidial_rag_amd.retrievers.sharded_bm25 import ShardedBM25, ShardedHybrid
 
     device = torch.device("cuda", local_rank)
@@ -423,45 +455,128 @@ def hybrid_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIn
     index = DeviceIndex.from_device_ptr(rows.data_ptr(), n_loc, d, local_rank, row_offset=lo,
                                         stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    del rows
     indptr, toks = gen_bm25_corpus(np, torch, device, n_loc, 9000 + rank)
     t0 = time.perf_counter()
     kw = ShardedBM25.build(indptr, toks, BM25_VOCAB, doc_offset=lo, device_index=local_rank)
     t_build = time.perf_counter() - t0
-    del indptr, toks
+    # ---- the query pool: every rank fills in the queries whose target chunk it owns, one all-reduce shares them ----
+    nq = HYBRID_BATCHES * B
+    targets = np.random.default_rng(4321).integers(0, n_loc * world, nq)
+    mine = np.flatnonzero((targets >= lo) & (targets < lo + n_loc))
+    g.manual_seed(977)
+    noise = torch.randn((nq, d), generator=g, dtype=torch.float32, device=device)
+    qv = torch.zeros((nq, d), dtype=torch.float64, device=device)
+    qt = torch.zeros((nq, HYBRID_TERMS), dtype=torch.int32, device=device)
+    if len(mine):
+        loc = torch.from_numpy(targets[mine] - lo).to(device)
+        at = torch.from_numpy(mine).to(device)
+        qv[at] = (rows[loc] + 0.05 * noise[at] / noise[at].norm(dim=1, keepdim=True)).double()
+        freq = np.bincount(toks, minlength=BM25_VOCAB)
+        terms = np.full((len(mine), HYBRID_TERMS), BM25_VOCAB + 7, np.int32)  # shorter chunks: padded with an unknown id (adds 0)
+        for j, t in enumerate(targets[mine] - lo):
+            u = np.unique(toks[indptr[t] : indptr[t + 1]])
+            u = u[np.argsort(freq[u], kind="stable")][:HYBRID_TERMS]
+            terms[j, : len(u)] = u
+        qt[at] = torch.from_numpy(terms).to(device)
+    if world > 1:
+        dist.all_reduce(qv)
+        dist.all_reduce(qt)
+    sample = None
+    if check:  # host copies for the oracle, before the device copies go
+        sample = (rows.cpu().numpy(), indptr, toks)
+    del rows, noise
+    if not check:
+        del indptr, toks
     hy = ShardedHybrid(ShardedSearcher(local_index=index), kw, k=k)
-    g.manual_seed(4321)
-    q = torch.randn((B, d), generator=g, dtype=torch.float32, device=device)
-    q = (q / q.norm(dim=1, keepdim=True)).double().contiguous()
-    qs = bm25_queries(np, B, 778)
-    flat = torch.tensor(np.concatenate([np.asarray(x, np.int32) for x in qs]), dtype=torch.int32, device=device)
-    ptr = torch.tensor(np.concatenate(([0], np.cumsum([len(x) for x in qs]))), dtype=torch.int32, device=device)
-    for _ in range(PRECONDITION_STEPS):
-        out = hy.search(q, args.metric, flat, ptr)
+    ptr = torch.arange(0, HYBRID_TERMS * B + 1, HYBRID_TERMS, dtype=torch.int32, device=device)
+    flats = [qt[i * B : (i + 1) * B].reshape(-1).contiguous() for i in range(HYBRID_BATCHES)]
+    qvs = [qv[i * B : (i + 1) * B].contiguous() for i in range(HYBRID_BATCHES)]
+    steps = HYBRID_BATCHES - PRECONDITION_STEPS
+
+    def step(i):
+        return hy.search(qvs[i], args.metric, flats[i], ptr)
+
+    for i in range(PRECONDITION_STEPS):
+        out = step(i)
     barrier()
-    steps = 20
     t0 = time.perf_counter()
-    for _ in range(steps):
-        out = hy.search(q, args.metric, flat, ptr)
+    overlap = []
+    for i in range(steps):
+        out = step(PRECONDITION_STEPS + i)
+        overlap.append(out)
     barrier()
     el = time.perf_counter() - t0
     tm = torch.tensor([el], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     el = float(tm.item())
-    fused_ids, _, fused_cnt, v, t = out
+    shared, fused_n = [], []
+    for fused_ids, _, fused_cnt, v, t in overlap:
+        shared += [len(set(v[0][i, : v[1][i]]) & set(t[0][i, : t[1][i]])) for i in range(B)]
+        fused_n.append(float(fused_cnt.mean()))
+    res = {"workload": f"hybrid: {n_loc} chunks per GPU x {world} GPUs = {n_loc * world} chunks; {d}-d float32 rows ({args.metric}) + "
+                       f"BM25 ({BM25_VOCAB}-term vocabulary) over the same chunks; a query = a vector near a target chunk + that chunk's "
+                       f"{HYBRID_TERMS} rarest terms; k = {k} per leg, reciprocal-rank fusion (weights 1, c = 60)",
+           "scaling": "weak", "queries_per_step": B, "steps": steps, "fresh_queries_every_step": True,
+           "ms_per_step": round(1e3 * el / steps, 4), "qps": round(B * steps / el, 1),
+           "bm25_sharded_build_s": round(t_build, 2),
+           "fused_results_per_query_mean": round(float(np.mean(fused_n)), 2),
+           "legs_overlap_in_results_mean": round(float(np.mean(shared)), 3)}
+    if check:
+        res["oracle_check"] = hybrid_oracle_check(np, torch, device, sample, qv[-B:].cpu().numpy(), qt[-B:].cpu().numpy(), overlap[-1], args.metric, k)
     index.close()
     kw.model.close()
-    return {"workload": f"hybrid: {n_loc} chunks per GPU x {world} GPUs = {n_loc * world} chunks; {d}-d float32 rows ({args.metric}) + "
-                        f"BM25 ({BM25_VOCAB}-term vocabulary); k = {k} per leg, reciprocal-rank fusion (weights 1, c = 60)",
-            "scaling": "weak", "queries_per_step": B, "ms_per_step": round(1e3 * el / steps, 4), "qps": round(B * steps / el, 1),
-            "bm25_sharded_build_s": round(t_build, 2),
-            "fused_results_per_query_mean": round(float(fused_cnt.mean()), 2),
-            "legs_overlap_in_results_mean": round(float(np.mean([len(set(v[0][i, : v[1][i]]) & set(t[0][i, : t[1][i]])) for i in range(B)])), 3)}
+    return res
+
+
+def hybrid_oracle_check(np, torch, device, sample, qvecs, qterms, got, metric, k, n_check=6):
+    """The last timed hybrid step's first queries against the unsharded oracle pipeline on the same chunks."""
+    from oracle import bm25 as ob
+    from oracle import embeddings_index as oi
+    from oracle import fusion as of
+
+    rows, indptr, toks = sample
+    t0 = time.perf_counter()
+    model = ob.BM25OkapiCSR(indptr, toks, BM25_VOCAB, grouped=bm25_grouping_on_device(np, torch, device, indptr, toks, BM25_VOCAB))
+    ids, scores, cnt, v, t = got
+    ok_v = ok_t = ok_f = True
+    for i in range(n_check):
+        sem, _ = oi.find_flat(qvecs[i], rows, metric, k)
+        top = ob.top_n_indexes(model.get_scores([int(x) for x in qterms[i]]), k)
+        lists = [[int(x) for x in sem], [int(x) for x in top]]
+        fused = of.weighted_reciprocal_rank(lists, [1.0, 1.0])
+        fs = of.rrf_scores(lists, [1.0, 1.0])
+        ok_v &= list(v[0][i, : v[1][i]]) == lists[0]
+        ok_t &= list(t[0][i, : t[1][i]]) == lists[1]
+        ok_f &= list(ids[i, : cnt[i]]) == fused and bool(np.array_equal(scores[i, : cnt[i]], np.asarray([fs[x] for x in fused])))
+    return {"queries_checked": n_check, "vector_leg_ids_identical": bool(ok_v), "bm25_leg_ids_identical": bool(ok_t),
+            "fused_ids_and_scores_identical": bool(ok_f), "oracle_s": round(time.perf_counter() - t0, 1)}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process touches no GPU, starts N ranks under
+    `torch.distributed.run` (one per GPU, RCCL over 127.0.0.1), relays their output and exits with their code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    raise SystemExit(proc.wait())
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -621,7 +736,6 @@ def main():
             # the same bytes over the whole step (prep, threshold pre-pass, scan, finalize, exact-pass gate, merge)
             "step_frac": round(bytes_launch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         },
-        "uncertain_queries": 0,  # never returned since the exact pass exists (flag bit 1)
         "exact_pass_queries": int(flags_total.item()) // 2,  # queries the filter could not prove (flag bit 2), recomputed exactly
         "preconditioning_steps": precondition,
         **({"rehearsal_one_gpu": True} if rehearsal else {}),
@@ -666,7 +780,8 @@ def main():
             with tempfile.TemporaryDirectory() as td:
                 result["index_build"]["through_build_embeddings"] = build_embeddings_leg(np, torch, args, local_rank, td)
     if args.hybrid_docs > 0:
-        result["hybrid_c4"] = hybrid_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher)
+        result["hybrid_c4"] = hybrid_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher,
+                                         check=(world == 1 and args.cpu_legs))
     bm25_state = None
     if args.bm25_docs > 0 and world == 1:
         result["bm25_c3"], bm25_dev, bm25_corpus = bm25_leg(np, torch, args, local_rank)

@@ -100,27 +100,45 @@ def build(tokenized_texts: Sequence[Sequence[Hashable]]) -> BM25Okapi:
 # Checked against the dict loop in tests/test_oracle_bm25.py.
 
 
+def group_postings(indptr: np.ndarray, term_ids: np.ndarray, vocab: int):
+    """Integer bookkeeping only (no float arithmetic): the distinct (term, doc) pairs of a token stream, grouped by
+    term with documents ascending, their term frequencies, document frequencies and the position of every term's
+    first token (= insertion order of rank-bm25's `nd` dict).  -> (t_doc i64[P], t_tf i64[P], df i64[V], first_pos i64[V]).
+    Tests at sizes where this numpy sort is too slow compute the same four arrays with a device sort and pass them as
+    `grouped=` (checked against this function at small sizes, tests/test_oracle_bm25_fusion.py)."""
+    n = len(indptr) - 1
+    doc_len = np.diff(indptr).astype(np.int64)
+    term_ids = np.asarray(term_ids)
+    key = term_ids.astype(np.int64) * np.int64(max(n, 1)) + np.repeat(np.arange(n, dtype=np.int64), doc_len)
+    key.sort()
+    if len(key):
+        flag = np.empty(len(key), dtype=bool)
+        flag[0] = True
+        np.not_equal(key[1:], key[:-1], out=flag[1:])
+        starts = np.flatnonzero(flag)
+        ukey = key[starts]
+        t_tf = np.diff(np.append(starts, len(key))).astype(np.int64)
+    else:
+        ukey, t_tf = key, np.zeros(0, np.int64)
+    t_doc = ukey % np.int64(max(n, 1))
+    df = np.bincount(ukey // np.int64(max(n, 1)), minlength=vocab).astype(np.int64)
+    first_pos = np.full(vocab, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first_pos, term_ids.astype(np.int64), np.arange(len(term_ids), dtype=np.int64))
+    return t_doc, t_tf, df, first_pos
+
+
 class BM25OkapiCSR:
-    def __init__(self, indptr: np.ndarray, term_ids: np.ndarray, vocab: int, k1=1.5, b=0.75, epsilon=0.25):
-        """`indptr[i]:indptr[i+1]` slices the TOKENS (with repeats, in text order) of doc i."""
+    def __init__(self, indptr: np.ndarray, term_ids: np.ndarray, vocab: int, k1=1.5, b=0.75, epsilon=0.25, grouped=None):
+        """`indptr[i]:indptr[i+1]` slices the TOKENS (with repeats, in text order) of doc i.  `grouped`: the result of
+        `group_postings` computed elsewhere (integer bookkeeping; every float64 operation stays below)."""
         self.k1, self.b, self.epsilon = k1, b, epsilon
         n = len(indptr) - 1
         self.corpus_size = n
         self.doc_len = np.diff(indptr).astype(np.int64)
         self.avgdl = int(self.doc_len.sum()) / n
-        doc_of_tok = np.repeat(np.arange(n, dtype=np.int64), self.doc_len)
-        # unique (doc, term) pairs with counts = term frequencies
-        key = doc_of_tok * np.int64(vocab) + term_ids.astype(np.int64)
-        order = np.argsort(key, kind="stable")
-        ukey, first, tf = np.unique(key[order], return_index=True, return_counts=True)
-        self.p_doc = (ukey // vocab).astype(np.int64)
-        self.p_term = (ukey % vocab).astype(np.int64)
-        self.p_tf = tf.astype(np.int64)
-        df = np.bincount(self.p_term, minlength=vocab).astype(np.int64)
+        self.t_doc, self.t_tf, df, first_pos = grouped if grouped is not None else group_postings(indptr, term_ids, vocab)
         # insertion order of nd = order of first appearance in the token stream
         present = np.flatnonzero(df)
-        first_pos = np.full(vocab, np.iinfo(np.int64).max, dtype=np.int64)
-        np.minimum.at(first_pos, term_ids.astype(np.int64), np.arange(len(term_ids), dtype=np.int64))
         present = present[np.argsort(first_pos[present], kind="stable")]
         idf = np.zeros(vocab, dtype=np.float64)
         idf_sum = 0.0
@@ -132,10 +150,6 @@ class BM25OkapiCSR:
         idf[(idf < 0) & (df > 0)] = self.epsilon * self.average_idf
         self.idf = idf
         self.df = df
-        # postings grouped by term for scoring
-        o2 = np.argsort(self.p_term, kind="stable")
-        self.t_doc = self.p_doc[o2]
-        self.t_tf = self.p_tf[o2]
         self.t_ptr = np.concatenate(([0], np.cumsum(df)))
 
     def get_scores(self, query: Sequence[int]) -> np.ndarray:
