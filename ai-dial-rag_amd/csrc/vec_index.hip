@@ -15,6 +15,7 @@
 #include "vec_kernels_f16.h"
 #include "vec_kernels_q16.h"
 #include "vec_kernels_h16.h"
+#include "vec_kernels_sieve.h"
 
 namespace mir {
 
@@ -255,6 +256,13 @@ struct SearchBuffers {
     uint32_t *bound_row; // [b]
     uint64_t *part_exact;  // [b][exact grid][64][2]
     uint64_t *part_sample;  // [kSampleWgs][128][klist], reused by every launch (stream-ordered)
+    // the sieve (vec_kernels_sieve.h): candidate regions of its two launches, the queries' verified lists
+    uint64_t *sv_cand;      // [2][nwg][kSieveRegion]
+    uint32_t *sv_ccount;    // [2][nwg]
+    SieveLists sv;          // dist / rv / row [b][kSieveQueryCap]; count / over [b] live in the zeroed control block
+    double *sv_kth_dist;    // [b]
+    uint32_t *sv_kth_row;   // [b]
+    uint32_t *sv_kth_valid; // [b] (control block)
     int32_t *o_doc;  // host API staging of outputs, [b][k]
     int64_t *o_chunk;
     int64_t *o_row;
@@ -272,6 +280,7 @@ struct SearchPlan {
     bool exact_only = false;
     int nwg_first = 0;        // layout16 progressive scan: workgroups (= candidate lists) and tiles of the first launch;
     uint32_t tiles_first = 0; // nwg counts the lists of BOTH launches (0 = one launch)
+    bool sieve = false;       // large layout16 shard: hi-only filter + exhaustive verification (vec_kernels_sieve.h); nwg = workgroups per launch
 };
 
 static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int ksteps, const SearchPlan &pl, bool host_api) {
@@ -283,16 +292,28 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.q_norm = c.take<double>(b);
     sb.qscale = c.take<float>((size_t)ngroups * 128);
     sb.part = c.take<uint64_t>((size_t)ngroups * nwg * qpw * klist);
+    // one zeroed control block: gthr | nflag | arrive[b] | sieve count[b] | sieve over[b] | sieve kth_valid[b]  (u32 arrays padded to u64)
     const size_t gthr_words = (size_t)ngroups * 128, arrive_words = ((size_t)b + 1) / 2;
-    sb.ctl_words = (int)(gthr_words + 1 + arrive_words);
+    sb.ctl_words = (int)(gthr_words + 1 + 4 * arrive_words);
     sb.gthr = c.take<uint64_t>((size_t)sb.ctl_words);
     sb.nflag = base ? reinterpret_cast<int32_t *>(sb.gthr + gthr_words) : nullptr;
     sb.arrive = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1) : nullptr;
+    sb.sv.count = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + arrive_words) : nullptr;
+    sb.sv.over = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + 2 * arrive_words) : nullptr;
+    sb.sv_kth_valid = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + 3 * arrive_words) : nullptr;
     sb.flagged = c.take<int32_t>(b);
     sb.bound_dist = c.take<double>(b);
     sb.bound_row = c.take<uint32_t>(b);
     sb.part_exact = c.take<uint64_t>((size_t)b * pl.exact_grid * std::min(k, kExactRound) * 2);
     sb.part_sample = c.take<uint64_t>((size_t)kSampleWgs * 128 * klist);
+    const size_t sv_q = pl.sieve ? (size_t)b * kSieveQueryCap : 0;
+    sb.sv_cand = c.take<uint64_t>(pl.sieve ? (size_t)2 * nwg * kSieveRegion : 0);
+    sb.sv_ccount = c.take<uint32_t>(pl.sieve ? (size_t)2 * nwg : 0);
+    sb.sv.dist = c.take<double>(sv_q);
+    sb.sv.rv = c.take<float>(sv_q);
+    sb.sv.row = c.take<uint32_t>(sv_q);
+    sb.sv_kth_dist = c.take<double>(pl.sieve ? b : 0);
+    sb.sv_kth_row = c.take<uint32_t>(pl.sieve ? b : 0);
     if (host_api) {
         sb.o_doc = c.take<int32_t>((size_t)b * k);
         sb.o_chunk = c.take<int64_t>((size_t)b * k);

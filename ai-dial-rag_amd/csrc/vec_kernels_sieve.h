@@ -1,0 +1,359 @@
+// The sieve: the float32 index's search on large shards (round 3).  Streams HALF the bytes of the 128-query scan of
+// vec_kernels_q16.h and is exact by construction instead of by an a-posteriori check.
+//
+// Why.  The q16 scan streams a tile's bf16 hi blocks and its lo blocks, but uses the lo blocks for ~1 % of the
+// tile halves (only where a row's hi*hi value comes within the hi*hi error bound of a threshold): half of the 15.4 GB
+// it reads per 10M x 384 pass is never looked at.  Here the scan reads ONLY the hi blocks (N*d*2 bytes) and does no
+// correction, no list and no compaction at all:
+//
+//   filter   sieve_q16_kernel: v = hi*hi value of (row, query) in the scan's ranking units.  With
+//            |true value - v| <= mg = 4e-3*|x||q| (kHiHiRelErr, worst case), a row whose true value reaches a
+//            threshold T has v >= T - mg.  Every (row, query) with !(v < T - mg) is written out as a CANDIDATE
+//            (8 bytes; ~4e-5 of the pairs with the thresholds below) - a superset of all rows at or above T.
+//   verify   sieve_verify_kernel: the reference's own float64 formula (exact_metric_wave) for every candidate,
+//            from the float32 rows; appended to the query's list.
+//   select   sieve_select_kernel: the reference's order (distance, NaN last, row) over the query's verified
+//            candidates; the first k are the result.
+//
+// Exactness.  T is a lower bound of the query's k-th best TRUE value (k rows at or above it are known), so all of
+// the true top k are at or above T, hence among the candidates, hence verified and ordered exactly.  No candidate
+// list is bounded by k: the only way to lose a row is a full buffer, which is counted; the query then takes the exact
+// pass (exact_topk_batch_kernel).  There is no "uncertain" outcome and no completeness check.
+//
+// Thresholds, progressively (as the q16 scan): a 32K-row sample gives T0 (the k-th largest of 512 per-lane lower
+// bounds v - mg over distinct rows); launch 1 sieves the first 1/16 of the tiles with T0; its verified candidates
+// give T1 = the exact k-th best true value so far; launch 2 sieves the rest with T1.  The candidates of both
+// launches are ranked together at the end.
+//
+// euclidean_dist quirk (embeddings_metrics.py:50): sqrt of a negative rounding residue is NaN and sorts LAST, so
+// a row (nearly) identical to the query has the LARGEST ranking value and the WORST rank.  T1 is taken from the k-th
+// candidate in the reference's order and only if that one is not NaN; T0's sample skips rows that could be NaN
+// (`nan_guard`): k rows at or above T that are certainly not NaN keep the argument above intact.
+#pragma once
+#include "vec_kernels_q16.h"
+
+namespace mir {
+
+constexpr int kSieveStages = 6;        // LDS-DMA ring: 6 x 24 KiB at d = 384, five stages in flight
+constexpr int kSieveRegion = 8192;     // candidates a workgroup can write per launch (64 KiB of HBM each)
+constexpr int kSieveQueryCap = 4096;   // verified candidates kept per query
+constexpr int kSieveSelectCap = 1024;  // of which the final ranking holds the ones not worse than launch 1's k-th
+constexpr int kSieveMaxK = 64;
+
+__host__ __device__ constexpr size_t sieve_lds_bytes(int ks32) { return (size_t)kSieveStages * ks32 * 2 * 1024 + 64; }
+
+template <int KS32, int KIND, bool SAMPLE>
+__global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
+                                                           const uint4 *__restrict__ qsplit, const double *__restrict__ q_norm,
+                                                           const double *__restrict__ q_sq, const float *__restrict__ max_norm,
+                                                           uint32_t n_rows, uint32_t tile0, uint32_t n_tiles, int nq, int nan_guard,
+                                                           const uint64_t *__restrict__ gthr, uint64_t *__restrict__ cand,
+                                                           uint32_t *__restrict__ ccount, float *__restrict__ part_sample) {
+    constexpr int NS = kSieveStages;
+    constexpr int SB = KS32 * 2;          // 1-KiB blocks per stage = a tile's hi blocks
+    constexpr int STAGE_U4 = SB * 64;
+    constexpr int TILE_U4 = 2 * STAGE_U4;  // layout16: a tile's hi blocks, then its lo blocks (not read here)
+    constexpr int PPW = SB / 8;           // DMA pieces per wave per stage
+    constexpr int D = NS - 1;             // stages in flight: stage g's slot is free again once stage g has been read
+    static_assert(SB % 8 == 0, "sieve: d padded to a multiple of 128");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *ring = reinterpret_cast<uint4 *>(smem);                                  // [NS][STAGE_U4]
+    uint32_t *s_count = reinterpret_cast<uint32_t *>(smem + (size_t)NS * STAGE_U4 * 16);
+
+    const int tid = threadIdx.x, lane = tid & 63, qc = lane & 15, jg = lane >> 4;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qloc = wave8 * 16 + qc;              // this lane's query in the launch
+    const bool lane_live = qloc < nq;
+    const bool active = nq > wave8 * 16;
+    const uint32_t G = gridDim.x;
+    if (tid == 0) *s_count = 0;
+
+    // the hi*hi value's margin in ranking units, and this lane's pass bound T - mg (with the float32 rounding of v itself)
+    float mg = 0.f, bound = -__builtin_inff(), guard = __builtin_inff(), best = -__builtin_inff();
+    if (lane_live) {
+        const float qn = (float)q_norm[qloc] * (1.0f + 1e-6f);
+        mg = kHiHiRelErr * qn * (KIND == SCAN_COS ? 1.0f : max_norm[0]) * (KIND == SCAN_L2 ? 2.0f : 1.0f);
+        if (!SAMPLE) {
+            const uint64_t key = gthr[qloc];
+            if (key != 0) {
+                const float t = key_value(key);
+                bound = t - mg - 2e-6f * fabsf(t);
+            }
+        } else if (nan_guard) {
+            // sq = q_sq - v < 0 is NaN under euclidean_dist: rows whose v + mg could reach q_sq do not count as known rows
+            const float qs = (float)q_sq[qloc];
+            guard = qs - 1e-5f * fabsf(qs);
+        }
+    }
+
+    bf16x8 qh[KS32];
+    {
+        const uint4 *qs = qsplit + (size_t)wave8 * KS32 * 128 + lane;
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) qh[s] = __builtin_bit_cast(bf16x8, qs[(s * 2 + 0) * 64]);
+    }
+    const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + G - 1) / G : 0;
+    const uint32_t NG = my_tiles;
+
+    auto issue = [&](uint32_t g) {
+        const uint32_t tile = tile0 + blockIdx.x + g * G;
+        const uint4 *src = docs + (size_t)tile * TILE_U4 + (wave8 * PPW) * 64 + lane;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave8 * PPW) * 64) * 16);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
+    };
+    // ordinary loads are complete before the first DMA (the counted waits below count DMAs only)
+#pragma unroll
+    for (int s = 0; s < KS32; ++s) asm volatile("" : "+v"(qh[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t g = 0; g < (uint32_t)D && g < NG; ++g) issue(g);
+
+    auto wait_stage = [&](uint32_t g) {  // stage g has landed: all but the younger stages' pieces are done
+        const uint32_t younger = (NG - 1 - g) < (uint32_t)(D - 1) ? (NG - 1 - g) : (uint32_t)(D - 1);
+        if (younger == (uint32_t)(D - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only in the last D - 1 stages of the launch
+    };
+    uint64_t *region = cand + (size_t)blockIdx.x * kSieveRegion;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (uint32_t g = 0; g < my_tiles; ++g) {
+        const uint32_t t = tile0 + blockIdx.x + g * G;
+        const uint32_t row0 = t * kTileRows + 4 * jg;  // this lane's rows: row0 + 16 rh + i
+        wait_stage(g);
+        __builtin_amdgcn_s_barrier();   // every wave's pieces of stage g are in; everybody has left stage g - 1's slot
+        if (g + D < NG) issue(g + D);
+        if (!active) continue;
+        float ax[8] = {};
+        if (KIND != SCAN_IP) q16_load_aux(aux, t, jg, ax);
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
+        uint4 f0[3], f1[3];
+        f0[0] = st[0 * 64]; f1[0] = st[1 * 64];
+        f0[1] = st[2 * 64]; f1[1] = st[3 * 64];
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) {
+            if (s + 2 < KS32) {
+                f0[(s + 2) % 3] = st[(2 * (s + 2) + 0) * 64];
+                f1[(s + 2) % 3] = st[(2 * (s + 2) + 1) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0[s % 3]), qh[s], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1[s % 3]), qh[s], c1, 0, 0, 0);
+        }
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = KIND == SCAN_IP ? c0[i] : KIND == SCAN_L2 ? fmaf(2.0f, c0[i], -ax[i]) : c0[i] * ax[i];
+            v[4 + i] = KIND == SCAN_IP ? c1[i] : KIND == SCAN_L2 ? fmaf(2.0f, c1[i], -ax[4 + i]) : c1[i] * ax[4 + i];
+        }
+        if (SAMPLE) {
+            // a LOWER bound of this lane's best true value over rows that are certainly not NaN (sample tiles are whole tiles)
+            if (lane_live) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (v[r] + mg < guard) best = fmaxf(best, v[r] - mg);
+            }
+            continue;
+        }
+        uint32_t pm = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound)) << r;  // NaN passes; no bound yet: everything passes
+        if (!lane_live) pm = 0;
+        if (!__any(pm != 0)) continue;
+        // rare (a few per cent of the wave-tiles): write the passing (query, row) pairs to this workgroup's region
+        if (t * kTileRows + kTileRows > n_rows) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (row0 + 16 * (r >> 2) + (r & 3) >= n_rows) pm &= ~(1u << r);
+        }
+        while (__any(pm != 0)) {
+            const bool has = pm != 0;
+            const int r = has ? __builtin_ctz(pm) : 0;
+            const unsigned long long bal = __ballot(has);
+            const int leader = __builtin_ctzll(bal);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(s_count, (uint32_t)__popcll(bal));
+            base = __shfl(base, leader, 64);
+            const uint32_t slot = base + (uint32_t)__popcll(bal & lt_mask);
+            if (has && slot < (uint32_t)kSieveRegion)
+                region[slot] = ((uint64_t)(uint32_t)qloc << 32) | (uint64_t)(row0 + 16 * (r >> 2) + (r & 3));
+            pm &= pm - 1;
+        }
+    }
+    if (SAMPLE) {
+        // four lanes hold a query's column: two values per query, each the maximum over distinct rows
+        const float o = __shfl_xor(best, 16, 64);
+        const float b2 = fmaxf(best, o);
+        if (lane_live && (jg == 0 || jg == 2)) part_sample[((size_t)blockIdx.x * kQ16Queries + qloc) * 2 + (jg >> 1)] = b2;
+        return;
+    }
+    __syncthreads();
+    if (tid == 0) ccount[blockIdx.x] = *s_count;  // may exceed kSieveRegion: the verify kernel then hands every query to the exact pass
+}
+
+// ---------------------------------------------------------------- verify
+// One workgroup of 16 waves per region; a wave takes candidates wave, wave + 16, ... : the reference formula in float64
+// (exact_metric_wave) and an append to the query's list.
+struct SieveLists {
+    double *dist;      // [b][kSieveQueryCap] reference distance
+    float *rv;         // [b][kSieveQueryCap] true ranking value (the scan's units), rounded to float
+    uint32_t *row;     // [b][kSieveQueryCap]
+    uint32_t *count;   // [b] appended so far (may exceed the capacity: the rest was dropped)
+    uint32_t *over;    // [b] != 0: a candidate of this query was dropped somewhere -> exact pass
+};
+
+struct SieveVerifyArgs {
+    const uint64_t *cand;   // [regions][kSieveRegion]
+    const uint32_t *ccount; // [regions]
+    const float *docs;      // f32 [n][d]
+    const float *doc_sq;
+    int d, metric, q0, nq, b;  // the launch's queries are q0 .. q0 + nq - 1 of b
+    const double *q, *q_sq, *q_norm;
+    SieveLists l;
+};
+
+__global__ __launch_bounds__(1024) void sieve_verify_kernel(SieveVerifyArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t cnt = a.ccount[blockIdx.x];
+    if (cnt > (uint32_t)kSieveRegion) {  // the region overflowed: whose candidates were lost is unknown
+        for (int i = tid; i < a.nq; i += 1024) a.l.over[a.q0 + i] = 1;
+        cnt = kSieveRegion;
+    }
+    const uint64_t *region = a.cand + (size_t)blockIdx.x * kSieveRegion;
+    for (uint32_t e = wave; e < cnt; e += 16) {
+        const uint64_t key = region[e];
+        const int qi = a.q0 + (int)(key >> 32);
+        const uint32_t row = (uint32_t)key;
+        double rv;
+        const double dist = exact_metric_wave(a.docs + (size_t)row * a.d, a.q + (size_t)qi * a.d, a.d, a.metric, a.doc_sq[row],
+                                              a.q_sq[qi], a.q_norm[qi], lane, &rv);
+        if (lane == 0) {
+            const uint32_t slot = atomicAdd(&a.l.count[qi], 1u);
+            if (slot < (uint32_t)kSieveQueryCap) {
+                a.l.dist[(size_t)qi * kSieveQueryCap + slot] = dist;
+                a.l.rv[(size_t)qi * kSieveQueryCap + slot] = (float)rv;
+                a.l.row[(size_t)qi * kSieveQueryCap + slot] = row;
+            } else {
+                a.l.over[qi] = 1;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- select
+struct SieveSelectArgs {
+    SieveLists l;
+    int q0, nq, k, metric, mode;   // mode 0: thresholds for the next launch; 1: the result
+    const double *q_norm;
+    const float *max_norm;
+    unsigned long long *gthr;      // [nq] of this launch group
+    double *kth_dist;              // [b] launch 1's k-th best (mode 0 writes, mode 1 reads)
+    uint32_t *kth_row;             // [b]
+    uint32_t *kth_valid;           // [b]
+    const int64_t *chunk_ids;
+    const int32_t *doc_ids;
+    int64_t row_offset;
+    int32_t *out_doc;
+    int64_t *out_chunk;
+    int64_t *out_row;
+    double *out_dist;
+    int32_t *out_count;
+    int32_t *out_flags;
+    int32_t *nflag;
+    int32_t *flagged;
+};
+
+// grid = nq (one block per query), block = 256.
+__global__ __launch_bounds__(256) void sieve_select_kernel(SieveSelectArgs a) {
+    __shared__ double s_d[kSieveSelectCap];
+    __shared__ uint32_t s_r[kSieveSelectCap];
+    __shared__ float s_v[kSieveSelectCap];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int qi = a.q0 + blockIdx.x;
+    const uint32_t total = a.l.count[qi];
+    const int n = (int)(total < (uint32_t)kSieveQueryCap ? total : (uint32_t)kSieveQueryCap);
+    const double *ld = a.l.dist + (size_t)qi * kSieveQueryCap;
+    const uint32_t *lr = a.l.row + (size_t)qi * kSieveQueryCap;
+    const float *lv = a.l.rv + (size_t)qi * kSieveQueryCap;
+    bool over = a.l.over[qi] != 0;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    if (over) {
+        if (a.mode == 1 && tid == 0) {
+            a.flagged[atomicAdd(a.nflag, 1)] = qi;
+            if (a.out_flags) a.out_flags[qi] = MIR_FLAG_EXACT_PASS;
+            if (a.out_count) a.out_count[qi] = 0;
+        }
+        return;  // (mode 0: the sample's threshold stays; the next launch only adds to a list that is already lost)
+    }
+    // the candidates that can still be among the first k: all of them, or (mode 1, launch 1 found k) those not worse
+    // than launch 1's k-th
+    const bool cut = a.mode == 1 && a.kth_valid[qi] != 0;
+    const double kd = cut ? a.kth_dist[qi] : 0.0;
+    const uint32_t kr = cut ? a.kth_row[qi] : 0u;
+    for (int e0 = 0; e0 < n; e0 += 256) {
+        const int e = e0 + tid;
+        bool keep = false;
+        double dd = 0.0;
+        uint32_t rr = 0;
+        float vv = 0.f;
+        if (e < n) {
+            dd = ld[e]; rr = lr[e]; vv = lv[e];
+            keep = !cut || !dist_before(kd, kr, dd, rr);
+        }
+        const unsigned long long bal = __ballot(keep);
+        int base = 0;
+        const int lane = tid & 63;
+        if (bal && lane == __builtin_ctzll(bal)) base = atomicAdd(&s_n, __popcll(bal));
+        base = __shfl(base, bal ? __builtin_ctzll(bal) : 0, 64);
+        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep && slot < kSieveSelectCap) { s_d[slot] = dd; s_r[slot] = rr; s_v[slot] = vv; }
+    }
+    __syncthreads();
+    const int m = s_n;
+    if (m > kSieveSelectCap) {  // more contenders than the ranking holds (a mass of near-ties): the exact pass orders them
+        if (a.mode == 1 && tid == 0) {
+            a.flagged[atomicAdd(a.nflag, 1)] = qi;
+            if (a.out_flags) a.out_flags[qi] = MIR_FLAG_EXACT_PASS;
+            if (a.out_count) a.out_count[qi] = 0;
+        }
+        return;
+    }
+    const int kout = a.k < m ? a.k : m;
+    for (int e = tid; e < m; e += 256) {
+        const double dd = s_d[e];
+        const uint32_t rr = s_r[e];
+        int rank = 0;
+        for (int c = 0; c < m; ++c) rank += dist_before(s_d[c], s_r[c], dd, rr) ? 1 : 0;  // (an entry is not before itself)
+        if (a.mode == 1) {
+            if (rank < a.k) {
+                const size_t o = (size_t)qi * a.k + rank;
+                if (a.out_row) a.out_row[o] = a.row_offset + (int64_t)rr;
+                if (a.out_dist) a.out_dist[o] = dd;
+                if (a.out_doc) a.out_doc[o] = a.doc_ids ? a.doc_ids[rr] : 0;
+                if (a.out_chunk) a.out_chunk[o] = a.chunk_ids ? a.chunk_ids[rr] : (int64_t)rr;
+            }
+        } else if (rank == a.k - 1 && m >= a.k) {
+            // launch 1's k-th best in the reference's order: the cut of the final ranking and, unless it is a NaN
+            // distance (whose ranking value says nothing about the rows before it), the threshold of launch 2
+            a.kth_dist[qi] = dd;
+            a.kth_row[qi] = rr;
+            a.kth_valid[qi] = 1;
+            if (dd == dd) {
+                const float t = s_v[e];
+                const float qn = (float)a.q_norm[qi] * (1.0f + 1e-6f);
+                const float slack = 2e-6f * fabsf(t) + 1e-6f * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]);
+                const float thr = t - slack;  // (float)rv rounds to nearest: the slack covers that too
+                const unsigned long long key = (unsigned long long)orderable(thr) << 32;
+                if (thr == thr && key > a.gthr[blockIdx.x]) a.gthr[blockIdx.x] = key;
+            }
+        }
+    }
+    if (a.mode == 1 && tid == 0) {
+        if (a.out_count) a.out_count[qi] = kout;
+        if (a.out_flags) a.out_flags[qi] = 0;
+    }
+}
+
+}  // namespace mir

@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--hybrid-docs", type=int, default=1_250_000,
                     help="chunks PER GPU of the hybrid leg (BASELINE config 4: 10M chunks over 8 GPUs = 1.25M each: vector "
                          "rows + BM25 documents + fusion); 0 = skip")
+    ap.add_argument("--no-variants", dest="variants", action="store_false",
+                    help="skip the clustered-corpus and near-duplicate-corpus legs of the headline search (single GPU only)")
     ap.add_argument("--no-cpu-legs", dest="cpu_legs", action="store_false",
                     help="skip the BM25 and encoder CPU baselines (the vector one is governed by --cpu-rows)")
     return ap.parse_args()
@@ -202,6 +204,123 @@ def c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex,
                      "launches": launches},
         "exact_pass_queries": flags // 2,
     }
+
+
+def gen_clustered_rows(torch, device, n, dim, centres, seed, a=0.9486833, b=0.3162278):
+    """Rows drawn from a mixture: unit centres, row = normalise(a * centre + b * unit noise) - cosine ~0.9 between two
+    rows of a cluster.  What an index of real embeddings looks like more than isotropic noise does."""
+    out = torch.empty((n, dim), dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    for c0 in range(0, n, CHUNK_ROWS):
+        g.manual_seed(seed + c0 // CHUNK_ROWS)
+        m = min(CHUNK_ROWS, n - c0)
+        cid = torch.randint(0, centres.shape[0], (m,), generator=g, device=device)
+        x = torch.randn((m, dim), generator=g, dtype=torch.float32, device=device)
+        x /= x.norm(dim=1, keepdim=True)
+        x = a * centres[cid] + b * x
+        out[c0 : c0 + m] = x / x.norm(dim=1, keepdim=True)
+        del x, cid
+    return out
+
+
+def gen_near_duplicate_rows(torch, device, n, dim, seed, frac=0.10, group=32, eps=1e-7):
+    """Isotropic unit rows of which `frac` sit in groups of `group` near-identical rows (boiler-plate pages, repeated
+    chunks): a group's rows differ from its first by `eps`-sized noise, i.e. their distances to any query agree to
+    ~1e-7 - inside every float32 filter's error band.  Returns (rows, first row of every group)."""
+    rows = gen_rows(torch, device, 0, n, dim)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n_groups = int(n * frac) // group
+    starts = torch.randperm(n // group, generator=g, device=device)[:n_groups] * group
+    for c0 in range(0, n_groups, 4096):
+        st = starts[c0 : c0 + 4096]
+        base = rows[st]
+        idx = (st[:, None] + torch.arange(group, device=device)[None, :]).reshape(-1)
+        noise = torch.randn((len(idx), dim), generator=g, dtype=torch.float32, device=device) * eps
+        x = base.repeat_interleave(group, dim=0) + noise
+        x[::group] = base
+        rows[idx] = x / x.norm(dim=1, keepdim=True)
+    return rows, starts
+
+
+def variant_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher, kind):
+    """The headline search (same N x d, k, B, metric) on a corpus that is NOT isotropic noise; single GPU.
+      clustered       4096 centres, intra-cluster cosine ~0.9, queries near centres: how much of the scan's speed
+                      comes from thresholds that isotropic data makes easy
+      near_duplicate  10 % of the rows in groups of 32 near-identical rows, half of the queries aimed at such a
+                      group: the k-th neighbour falls inside a group, which no float32 filter can order - those
+                      queries take the exact pass
+    Reports QPS, the roofline of the scan bracket, the share of queries answered by the exact pass, and - on the
+    host, with the CPU oracle over ALL rows - identity of the ids for two queries."""
+    from oracle import embeddings_index as oracle_index
+
+    device = torch.device("cuda", local_rank)
+    n, d, B, k = args.rows, args.dim, args.batch, args.k
+    g = torch.Generator(device=device)
+    g.manual_seed(31337)
+    pool = 16 * B
+    if kind == "clustered":
+        centres = torch.randn((4096, d), generator=g, dtype=torch.float32, device=device)
+        centres /= centres.norm(dim=1, keepdim=True)
+        rows = gen_clustered_rows(torch, device, n, d, centres, 777)
+        cq = centres[torch.randint(0, 4096, (pool,), generator=g, device=device)]
+        nz = torch.randn((pool, d), generator=g, dtype=torch.float32, device=device)
+        q = cq + 0.3 * nz / nz.norm(dim=1, keepdim=True)
+        aimed = pool
+    else:
+        rows, starts = gen_near_duplicate_rows(torch, device, n, d, 4141)
+        q = torch.randn((pool, d), generator=g, dtype=torch.float32, device=device)
+        pick = starts[torch.randint(0, len(starts), (pool // 2,), generator=g, device=device)]
+        nz = torch.randn((pool // 2, d), generator=g, dtype=torch.float32, device=device)
+        q[0::2] = rows[pick + 5] + 0.02 * nz / nz.norm(dim=1, keepdim=True)  # every other query: next to a group's 6th member
+        aimed = pool // 2
+    q = (q / q.norm(dim=1, keepdim=True)).double().contiguous()
+    torch.cuda.synchronize()
+    index = DeviceIndex.from_device_ptr(rows.data_ptr(), n, d, local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    searcher = ShardedSearcher(local_index=index)
+    steps = 12 if kind == "clustered" else 4
+    flags = torch.zeros((16, B), dtype=torch.int32, device=device)
+    index.profile(True)
+    for i in range(PRECONDITION_STEPS if kind == "clustered" else 2):
+        searcher.search(q[(i % 16) * B : (i % 16 + 1) * B], k, args.metric)
+    torch.cuda.synchronize()
+    index.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = searcher.search(q[i * B : (i + 1) * B], k, args.metric, out_flags=flags[i])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    index.profile(False)
+    launches, scan_ms = index.profile_read(reset=True)
+    exact = int((flags[:steps] // 2).sum().item())
+    got_rows = out[1].cpu().numpy()
+    got_cnt = out[2].cpu().numpy()
+    stats = index.scan_stats() if hasattr(index, "scan_stats") else None
+    index.close()
+    host = rows.cpu().numpy()
+    del rows
+    torch.cuda.empty_cache()
+    qh = q[(steps - 1) * B : steps * B].cpu().numpy()
+    t0 = time.perf_counter()
+    same = True
+    for i in (0, 1):  # (near_duplicate: query 0 is aimed at a group, query 1 is not)
+        want, _ = oracle_index.find_flat(qh[i], host, args.metric, k)
+        same &= bool(np.array_equal(got_rows[i, : got_cnt[i]], want))
+    t_oracle = time.perf_counter() - t0
+    del host
+    bytes_launch = n * d * 4 + (0 if args.metric == "inner_product" else 4 * n) + B * d * 4 + B * k * 12
+    avg_ms = scan_ms / max(launches, 1)
+    res = {"workload": f"{kind}: {n} x {d} float32 unit rows, {args.metric}, k={k}, {B} queries per step, {steps} steps of fresh queries",
+           "ms_per_step": round(1e3 * el / steps, 4), "qps": round(B * steps / el, 1),
+           "scan_bracket_ms": round(avg_ms, 4),
+           "roofline_frac_survey_bytes": round(bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "exact_pass_queries": exact, "exact_pass_share": round(exact / (steps * B), 4),
+           "queries_aimed_at_clusters_share": round(aimed / pool, 2),
+           "ids_identical_to_cpu_oracle_on_2_queries": same, "oracle_s": round(t_oracle, 1)}
+    if stats:
+        res["scan_stats"] = stats
+    return res
 
 
 BM25_VOCAB = 50_000
@@ -768,8 +887,10 @@ def main():
             sweep.append({"queries_per_step": Bs, "qps": round(Bs * 10 / el, 1), "ms_per_step": round(1e3 * el / 10, 4),
                           "scan_launch_ms": round(a_ms, 4), "roofline_frac": round(bytes_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         result["batch_sweep"] = sweep
-    if args.encode_chunks > 0 or args.c5_rows > 0:
-        index.close()  # release the shard before the other legs allocate theirs
+    index.close()  # release the shard before the other legs allocate theirs
+    if args.variants and world == 1:
+        for kind in ("clustered", "near_duplicate"):
+            result[kind] = variant_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher, kind)
     if args.c5_rows > 0:
         result["c5_float16_d1024"] = c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher)
     if args.encode_chunks > 0:
