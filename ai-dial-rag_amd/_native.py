@@ -69,6 +69,7 @@ def _load():
         "mir_index_search_device": ([vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp], i32),
         "mir_index_profile": ([vp, i32], i32),
         "mir_index_profile_read": ([vp, i32, vp, vp], i32),
+        "mir_index_scan_stats": ([vp, i32, vp], i32),
         "mir_index_metric_eval": ([vp, vp, i32, vp], i32),
         "mir_metric_eval": ([vp, i64, i32, i32, vp, i32, i32, vp], i32),
         "mir_topk_merge_device": ([vp, vp, vp, i32, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),

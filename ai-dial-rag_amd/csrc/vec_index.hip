@@ -98,6 +98,7 @@ struct mir_index {
     float *d_docsq = nullptr;    // padded to n_tiles*32
     float *d_invnorm = nullptr;  // padded to n_tiles*32
     float *d_maxnorm = nullptr;
+    unsigned long long *d_stats = nullptr;  // 8 counters of the sieve (mir_index_scan_stats)
     int64_t *d_chunk = nullptr;
     int32_t *d_doc = nullptr;
     int64_t hbm_bytes = 0;
@@ -147,6 +148,7 @@ static void free_index(mir_index *ix) {
     (void)hipFree(ix->d_docsq);
     (void)hipFree(ix->d_invnorm);
     (void)hipFree(ix->d_maxnorm);
+    (void)hipFree(ix->d_stats);
     (void)hipFree(ix->d_chunk);
     (void)hipFree(ix->d_doc);
     delete ix;
@@ -184,6 +186,8 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
     MIR_HIP(hipMemsetAsync(ix->d_docsq, 0, std::max<size_t>(aux_bytes, 16), stream));
     MIR_HIP(hipMemsetAsync(ix->d_invnorm, 0, std::max<size_t>(aux_bytes, 16), stream));
     MIR_HIP(hipMemsetAsync(ix->d_maxnorm, 0, 16, stream));
+    MIR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_stats), 64));
+    MIR_HIP(hipMemsetAsync(ix->d_stats, 0, 64, stream));
     if (n > 0) {
         const int64_t total_lanes = (int64_t)ix->n_tiles * ix->ksteps * 64;
         const int64_t blocks = (total_lanes + 255) / 256;
@@ -292,15 +296,16 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.q_norm = c.take<double>(b);
     sb.qscale = c.take<float>((size_t)ngroups * 128);
     sb.part = c.take<uint64_t>((size_t)ngroups * nwg * qpw * klist);
-    // one zeroed control block: gthr | nflag | arrive[b] | sieve count[b] | sieve over[b] | sieve kth_valid[b]  (u32 arrays padded to u64)
+    // one zeroed control block: gthr | nflag | arrive[b] | sieve over[b] | sieve kth_valid[b] | sieve count[b][32]  (u32 arrays padded to u64)
     const size_t gthr_words = (size_t)ngroups * 128, arrive_words = ((size_t)b + 1) / 2;
-    sb.ctl_words = (int)(gthr_words + 1 + 4 * arrive_words);
+    const size_t count_words = pl.sieve ? (size_t)b * kSieveCountStride / 2 : 0;
+    sb.ctl_words = (int)(gthr_words + 1 + 3 * arrive_words + count_words);
     sb.gthr = c.take<uint64_t>((size_t)sb.ctl_words);
     sb.nflag = base ? reinterpret_cast<int32_t *>(sb.gthr + gthr_words) : nullptr;
     sb.arrive = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1) : nullptr;
-    sb.sv.count = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + arrive_words) : nullptr;
-    sb.sv.over = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + 2 * arrive_words) : nullptr;
-    sb.sv_kth_valid = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + 3 * arrive_words) : nullptr;
+    sb.sv.over = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + arrive_words) : nullptr;
+    sb.sv_kth_valid = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + 2 * arrive_words) : nullptr;
+    sb.sv.count = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + 3 * arrive_words) : nullptr;
     sb.flagged = c.take<int32_t>(b);
     sb.bound_dist = c.take<double>(b);
     sb.bound_row = c.take<uint32_t>(b);
@@ -458,6 +463,36 @@ static int32_t launch_scan_q16(const mir_index *ix, const uint4 *qsplit_g, const
     return MIR_OK;
 }
 
+// the sieve's filter launch over tiles [tile0, tile0 + n_tiles) (vec_kernels_sieve.h); sample = the threshold pre-pass
+template <int KIND>
+static int32_t launch_sieve(const mir_index *ix, const uint4 *qsplit_g, const double *q_norm_g, const double *q_sq_g, int nq, int nwg,
+                            uint32_t tile0, uint32_t n_tiles, int nan_guard, const uint64_t *gthr_g, uint64_t *cand, uint32_t *ccount,
+                            float *part_sample, bool sample, unsigned long long *stat, hipStream_t stream) {
+    const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
+    const int ks32 = ix->ksteps / 2;
+    const size_t lds = sieve_lds_bytes(ks32);
+    const uint32_t n_rows = (uint32_t)ix->n;
+#define MIR_SIEVE_CASE(KS)                                                                                             \
+    case KS: {                                                                                                         \
+        auto kern = sample ? sieve_q16_kernel<KS, KIND, true> : sieve_q16_kernel<KS, KIND, false>;                     \
+        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, q_norm_g, q_sq_g, ix->d_maxnorm, n_rows, tile0, n_tiles, \
+                                                    nq, nan_guard, gthr_g, cand, ccount, part_sample, stat);           \
+        break;                                                                                                         \
+    }
+    switch (ks32) {
+        MIR_SIEVE_CASE(4)
+        MIR_SIEVE_CASE(8)
+        MIR_SIEVE_CASE(12)
+        default:
+            set_error("internal: the sieve has no instance for %d k-steps of 32", ks32);
+            return MIR_ERR_UNSUPPORTED;
+    }
+#undef MIR_SIEVE_CASE
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
 // float16-native scan: 128 queries per launch, 16 per wave, one float16 product per fragment (vec_kernels_h16.h)
 template <int KIND>
 static int32_t launch_scan_h16(const mir_index *ix, const uint4 *qfrag_g, const float *qscale_g, int nq, int klist, int nwg,
@@ -602,6 +637,56 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         uint64_t *pg = sb.part + (size_t)g * nwg * qpw * klist;
         const int nq = std::min(qpw, b - qpw * g);
         int32_t rc;
+        if (pl.sieve) {
+            // filter (hi blocks only) -> verify (reference formula for every candidate) -> select: exact by construction
+            uint64_t *gt = sb.gthr + (size_t)g * 128;
+            const int q0 = qpw * g;
+            const double *qn = sb.q_norm + q0, *qsq = sb.q_sq + q0;
+            const int guard = metric == MIR_METRIC_EUCLIDEAN_DIST ? 1 : 0;
+            auto sieve = [&](uint32_t t0, uint32_t nt, int wgs, uint64_t *cand, uint32_t *cc, bool smp) {
+                float *ps = reinterpret_cast<float *>(sb.part_sample);
+                unsigned long long *st = smp ? nullptr : ix->d_stats + (t0 ? 1 : 0);
+                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve<SCAN_IP>(ix, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+                if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve<SCAN_COS>(ix, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+                return launch_sieve<SCAN_L2>(ix, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+            };
+            SieveVerifyArgs va;
+            va.docs = ix->d_orig; va.doc_sq = ix->d_docsq; va.d = d; va.metric = metric; va.q0 = q0; va.nq = nq; va.b = b;
+            va.q = dq; va.q_sq = sb.q_sq; va.q_norm = sb.q_norm; va.l = sb.sv;
+            SieveSelectArgs sa;
+            sa.l = sb.sv; sa.q0 = q0; sa.nq = nq; sa.k = k; sa.metric = metric; sa.q_norm = sb.q_norm; sa.max_norm = ix->d_maxnorm;
+            sa.gthr = reinterpret_cast<unsigned long long *>(gt); sa.kth_dist = sb.sv_kth_dist; sa.kth_row = sb.sv_kth_row;
+            sa.kth_valid = sb.sv_kth_valid; sa.chunk_ids = ix->d_chunk; sa.doc_ids = ix->d_doc; sa.row_offset = ix->row_offset;
+            sa.out_doc = o_doc; sa.out_chunk = o_chunk; sa.out_row = o_row; sa.out_dist = o_dist; sa.out_count = o_count;
+            sa.out_flags = o_flags; sa.nflag = sb.nflag; sa.flagged = sb.flagged; sa.stats = ix->d_stats;
+            rc = sieve(0, (uint32_t)kSampleWgs * kSampleTilesPerWg, kSampleWgs, nullptr, nullptr, true);
+            if (rc != MIR_OK) return rc;
+            sample_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(reinterpret_cast<const float *>(sb.part_sample), kSampleWgs, qpw,
+                                                                        k, nq, reinterpret_cast<unsigned long long *>(gt));
+            MIR_HIP(hipGetLastError());
+            rc = begin_profile();
+            if (rc != MIR_OK) return rc;
+            for (int phase = 0; phase < 2 && rc == MIR_OK; ++phase) {
+                uint64_t *cand = sb.sv_cand + (size_t)phase * nwg * kSieveRegion;
+                uint32_t *cc = sb.sv_ccount + (size_t)phase * nwg;
+                rc = phase == 0 ? sieve(0, pl.tiles_first, nwg, cand, cc, false)
+                                : sieve(pl.tiles_first, ix->n_tiles - pl.tiles_first, nwg, cand, cc, false);
+                if (rc != MIR_OK) break;
+                if (phase == 1 && ev0) {  // the bracket: both filter launches and what runs between them
+                    MIR_HIP(hipEventRecord(ev1, stream));
+                    std::lock_guard<std::mutex> lk(ix->mu);
+                    ix->prof_events.emplace_back(ev0, ev1);
+                    ev1 = nullptr;
+                }
+                va.cand = cand; va.ccount = cc;
+                sieve_verify_kernel<<<dim3(nwg * kSieveVerifySplit), dim3(1024), 0, stream>>>(va);
+                sa.mode = phase;
+                sieve_select_kernel<<<dim3(nq), dim3(256), 0, stream>>>(sa);
+                MIR_HIP(hipGetLastError());
+            }
+            if (rc != MIR_OK) return rc;
+            continue;
+        }
         if (qpw != 32) {
             uint64_t *gt = sb.gthr + (size_t)g * 128;
             const float *qsc = sb.qscale + (size_t)g * qpw;
@@ -671,6 +756,11 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         }
         if (rc != MIR_OK) return rc;
     }
+    if (pl.sieve) {  // the select kernel wrote the results; queries whose buffers overflowed take the exact pass
+        exact_topk_kernel<<<dim3(pl.exact_grid), dim3(kExactThreads), 0, stream>>>(ea);
+        MIR_HIP(hipGetLastError());
+        return MIR_OK;
+    }
     FinalizeArgs fa;
     fa.part = sb.part; fa.nwg = nwg; fa.qpw = qpw; fa.klist = klist; fa.k = k; fa.b = b; fa.d = d; fa.metric = metric;
     fa.docs = ix->d_orig; fa.docs16 = ix->d_f16; fa.doc_sq = ix->d_docsq; fa.max_norm = ix->d_maxnorm;
@@ -694,6 +784,20 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
     pl->klist = std::min(k + (ix->native16 ? kH16ListMargin : kListMargin), kMaxList);
     // The reference takes any `limit` (embeddings_index.py:58,81).  Beyond what the filter's per-lane candidate
     // lists hold (LDS), an index that could actually return that many rows is searched by the exact pass alone.
+    static const bool sieve_off = getenv("MIR_NO_SIEVE") != nullptr;  // (A/B measurements against the round-2 scan)
+    if (ix->layout16 && !sieve_off && k <= kSieveMaxK) {
+        // large shards (the progressive scan's: >= 64 tiles per workgroup): filter on the hi blocks alone, verify every candidate
+        const int wgs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), (int64_t)ix->n_tiles));
+        if ((int64_t)ix->n_tiles >= 64 * (int64_t)wgs) {
+            pl->sieve = true;
+            pl->qpw = kQ16Queries;
+            pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
+            pl->nwg = wgs;
+            pl->klist = std::min(k, kMaxList);
+            pl->tiles_first = std::max<uint32_t>(ix->n_tiles / 16, std::min<uint32_t>(ix->n_tiles / 4, 4896u));
+            return MIR_OK;
+        }
+    }
     const bool wide64 = wide64_split(ix);
     const bool lists_fit = k + (ix->native16 ? kH16ListMargin : kListMargin) <= kMaxList;
     if (!lists_fit && ix->n > (int64_t)kMaxList) {  // (n <= 64: every row fits the lists)
@@ -1096,6 +1200,20 @@ int32_t mir_index_profile_read(mir_index *idx, int32_t reset, int64_t *launches,
         idx->prof_launches = 0;
         idx->prof_ms = 0.0;
     }
+    return MIR_OK;
+}
+
+// Counters of the sieve (large float32 shards, vec_kernels_sieve.h) since the last reset; synchronises the device.
+// out[0], out[1]: (row, query) candidates its first / second filter launch wrote; out[2]: queries it answered;
+// out[3]: queries it handed to the exact pass (a full buffer); out[4], out[5]: verified candidates that entered the
+// ranking after the first launch / at the end.  out[6], out[7]: reserved (0).
+int32_t mir_index_scan_stats(mir_index *idx, int32_t reset, int64_t *out8) {
+    MIR_REQUIRE(idx != nullptr && out8 != nullptr, "NULL argument");
+    int32_t rc = use_device(idx->device, nullptr);
+    if (rc != MIR_OK) return rc;
+    MIR_HIP(hipDeviceSynchronize());
+    MIR_HIP(hipMemcpy(out8, idx->d_stats, 64, hipMemcpyDeviceToHost));
+    if (reset) MIR_HIP(hipMemset(idx->d_stats, 0, 64));
     return MIR_OK;
 }
 

@@ -507,6 +507,15 @@ __device__ __forceinline__ void glds16_b128(const void *gsrc, uint32_t lds_byte_
         : "v"(gsrc), "s"(lds_byte_addr)
         : "memory");
 }
+// the same for 4 bytes per (active) lane: lane l's dword lands at lds_byte_addr + 4 l
+__device__ __forceinline__ void glds4_b32(const void *gsrc, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_byte_addr)
+        : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }

@@ -32,6 +32,10 @@
 #pragma once
 #include "vec_kernels_q16.h"
 
+#ifndef SIEVE_ABL
+#define SIEVE_ABL 0  // measurement builds only (tools/run_vec_variants.sh): 1 = half the MFMAs, 2 = half the LDS fragment reads
+#endif
+
 namespace mir {
 
 constexpr int kSieveStages = 6;        // LDS-DMA ring: 6 x 24 KiB at d = 384, five stages in flight
@@ -39,8 +43,9 @@ constexpr int kSieveRegion = 8192;     // candidates a workgroup can write per l
 constexpr int kSieveQueryCap = 4096;   // verified candidates kept per query
 constexpr int kSieveSelectCap = 1024;  // of which the final ranking holds the ones not worse than launch 1's k-th
 constexpr int kSieveMaxK = 64;
+constexpr int kSieveCountStride = 32;  // a query's append counter has a 128-byte line of its own (43K appends on 4 shared lines took 120 us)
 
-__host__ __device__ constexpr size_t sieve_lds_bytes(int ks32) { return (size_t)kSieveStages * ks32 * 2 * 1024 + 64; }
+__host__ __device__ constexpr size_t sieve_lds_bytes(int ks32) { return (size_t)kSieveStages * (ks32 * 2 * 1024 + kTileRows * 4) + 64; }
 
 template <int KS32, int KIND, bool SAMPLE>
 __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
@@ -48,17 +53,21 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
                                                            const double *__restrict__ q_sq, const float *__restrict__ max_norm,
                                                            uint32_t n_rows, uint32_t tile0, uint32_t n_tiles, int nq, int nan_guard,
                                                            const uint64_t *__restrict__ gthr, uint64_t *__restrict__ cand,
-                                                           uint32_t *__restrict__ ccount, float *__restrict__ part_sample) {
+                                                           uint32_t *__restrict__ ccount, float *__restrict__ part_sample,
+                                                           unsigned long long *__restrict__ stat) {
     constexpr int NS = kSieveStages;
     constexpr int SB = KS32 * 2;          // 1-KiB blocks per stage = a tile's hi blocks
     constexpr int STAGE_U4 = SB * 64;
     constexpr int TILE_U4 = 2 * STAGE_U4;  // layout16: a tile's hi blocks, then its lo blocks (not read here)
-    constexpr int PPW = SB / 8;           // DMA pieces per wave per stage
+    constexpr int PPW = SB / 8;           // 1-KiB DMA pieces per wave per stage
+    constexpr bool AUX = KIND != SCAN_IP; // the tile's 32 norms travel with it: 16 bytes per wave, one more DMA
+    constexpr int PW = PPW + (AUX ? 1 : 0);  // vector-memory operations per wave per stage
     constexpr int D = NS - 1;             // stages in flight: stage g's slot is free again once stage g has been read
     static_assert(SB % 8 == 0, "sieve: d padded to a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *ring = reinterpret_cast<uint4 *>(smem);                                  // [NS][STAGE_U4]
-    uint32_t *s_count = reinterpret_cast<uint32_t *>(smem + (size_t)NS * STAGE_U4 * 16);
+    float *aux_lds = reinterpret_cast<float *>(smem + (size_t)NS * STAGE_U4 * 16);   // [NS][32]
+    uint32_t *s_count = reinterpret_cast<uint32_t *>(aux_lds + NS * kTileRows);
 
     const int tid = threadIdx.x, lane = tid & 63, qc = lane & 15, jg = lane >> 4;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,6 +110,10 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave8 * PPW) * 64) * 16);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
+        if (AUX) {  // lanes 0..3 of wave w bring norms 4w .. 4w + 3 of the tile
+            const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_addr_of(aux_lds) + ((g % NS) * kTileRows + wave8 * 4) * 4);
+            if (lane < 4) glds4_b32(aux + (size_t)tile * kTileRows + wave8 * 4 + lane, adst);
+        }
     };
     // ordinary loads are complete before the first DMA (the counted waits below count DMAs only)
 #pragma unroll
@@ -108,38 +121,17 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t g = 0; g < (uint32_t)D && g < NG; ++g) issue(g);
 
-    auto wait_stage = [&](uint32_t g) {  // stage g has landed: all but the younger stages' pieces are done
+    auto wait_stage = [&](uint32_t g) {  // stage g has landed: all but the younger stages' operations are done
         const uint32_t younger = (NG - 1 - g) < (uint32_t)(D - 1) ? (NG - 1 - g) : (uint32_t)(D - 1);
-        if (younger == (uint32_t)(D - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * PPW) : "memory");
+        if (younger == (uint32_t)(D - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only in the last D - 1 stages of the launch
     };
     uint64_t *region = cand + (size_t)blockIdx.x * kSieveRegion;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    for (uint32_t g = 0; g < my_tiles; ++g) {
-        const uint32_t t = tile0 + blockIdx.x + g * G;
-        const uint32_t row0 = t * kTileRows + 4 * jg;  // this lane's rows: row0 + 16 rh + i
-        wait_stage(g);
-        __builtin_amdgcn_s_barrier();   // every wave's pieces of stage g are in; everybody has left stage g - 1's slot
-        if (g + D < NG) issue(g + D);
-        if (!active) continue;
-        float ax[8] = {};
-        if (KIND != SCAN_IP) q16_load_aux(aux, t, jg, ax);
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-        const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
-        uint4 f0[3], f1[3];
-        f0[0] = st[0 * 64]; f1[0] = st[1 * 64];
-        f0[1] = st[2 * 64]; f1[1] = st[3 * 64];
-#pragma unroll
-        for (int s = 0; s < KS32; ++s) {
-            if (s + 2 < KS32) {
-                f0[(s + 2) % 3] = st[(2 * (s + 2) + 0) * 64];
-                f1[(s + 2) % 3] = st[(2 * (s + 2) + 1) * 64];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0[s % 3]), qh[s], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1[s % 3]), qh[s], c1, 0, 0, 0);
-        }
+    // The filter of one tile: this lane's 8 values against its bound.  It runs one tile LATE, in the shadow of the
+    // next tile's MFMAs (its ~30 vector instructions after a tile's last MFMA were exposed at every barrier).
+    auto filter = [&](const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], uint32_t t) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -153,14 +145,15 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
                 for (int r = 0; r < 8; ++r)
                     if (v[r] + mg < guard) best = fmaxf(best, v[r] - mg);
             }
-            continue;
+            return;
         }
         uint32_t pm = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound)) << r;  // NaN passes; no bound yet: everything passes
         if (!lane_live) pm = 0;
-        if (!__any(pm != 0)) continue;
+        if (!__any(pm != 0)) return;
         // rare (a few per cent of the wave-tiles): write the passing (query, row) pairs to this workgroup's region
+        const uint32_t row0 = t * kTileRows + 4 * jg;  // this lane's rows: row0 + 16 rh + i
         if (t * kTileRows + kTileRows > n_rows) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)
@@ -179,7 +172,71 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
                 region[slot] = ((uint64_t)(uint32_t)qloc << 32) | (uint64_t)(row0 + 16 * (r >> 2) + (r & 3));
             pm &= pm - 1;
         }
+    };
+
+    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};  // the previous tile: accumulators, norms, index
+    float pax[8] = {};
+    uint32_t pt = 0;
+    bool have_prev = false;
+    for (uint32_t g = 0; g < my_tiles; ++g) {
+        const uint32_t t = tile0 + blockIdx.x + g * G;
+        wait_stage(g);
+        __builtin_amdgcn_s_barrier();   // every wave's pieces of stage g are in; everybody has left stage g - 1's slot
+        if (!active) {
+            if (g + D < NG) issue(g + D);
+            continue;
+        }
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
+        uint4 f0[3], f1[3];
+        f0[0] = st[0 * 64]; f1[0] = st[1 * 64];
+        f0[1] = st[2 * 64]; f1[1] = st[3 * 64];
+        float cax[8] = {};
+        if (AUX) {  // rows 16 rh + 4 jg + i of this tile
+            const float4 a0 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * kTileRows + 4 * jg);
+            const float4 a1 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * kTileRows + 16 + 4 * jg);
+            cax[0] = a0.x; cax[1] = a0.y; cax[2] = a0.z; cax[3] = a0.w;
+            cax[4] = a1.x; cax[5] = a1.y; cax[6] = a1.z; cax[7] = a1.w;
+        }
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) {
+#if SIEVE_ABL == 2  // half of the LDS reads (every fragment used twice), all MFMAs
+            if (s + 2 < KS32 && !(s & 1)) {
+                f0[(s + 2) % 3] = st[(2 * (s + 2) + 0) * 64];
+                f1[(s + 2) % 3] = st[(2 * (s + 2) + 1) * 64];
+            } else if (s + 2 < KS32) {
+                f0[(s + 2) % 3] = f0[(s + 1) % 3];
+                f1[(s + 2) % 3] = f1[(s + 1) % 3];
+            }
+#else
+            if (s + 2 < KS32) {
+                f0[(s + 2) % 3] = st[(2 * (s + 2) + 0) * 64];
+                f1[(s + 2) % 3] = st[(2 * (s + 2) + 1) * 64];
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#if SIEVE_ABL == 1  // half of the MFMAs, all LDS reads
+            if (!(s & 1)) {
+#endif
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0[s % 3]), qh[s], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1[s % 3]), qh[s], c1, 0, 0, 0);
+#if SIEVE_ABL == 1
+            }
+#endif
+            if (s == 1) {  // the next stage's DMA once the matrix pipe has work queued
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + D < NG) issue(g + D);
+            }
+            if (s == 2 && have_prev) {
+                __builtin_amdgcn_sched_barrier(0);
+                filter(p0, p1, pax, pt);
+            }
+        }
+        p0 = c0; p1 = c1; pt = t; have_prev = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pax[i] = cax[i];
     }
+    if (have_prev) filter(p0, p1, pax, pt);
     if (SAMPLE) {
         // four lanes hold a query's column: two values per query, each the maximum over distinct rows
         const float o = __shfl_xor(best, 16, 64);
@@ -188,7 +245,10 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         return;
     }
     __syncthreads();
-    if (tid == 0) ccount[blockIdx.x] = *s_count;  // may exceed kSieveRegion: the verify kernel then hands every query to the exact pass
+    if (tid == 0) {
+        ccount[blockIdx.x] = *s_count;  // may exceed kSieveRegion: the verify kernel then hands every query to the exact pass
+        if (stat && *s_count) atomicAdd(stat, (unsigned long long)*s_count);  // mir_index_scan_stats: candidates of this launch
+    }
 }
 
 // ---------------------------------------------------------------- verify
@@ -198,7 +258,7 @@ struct SieveLists {
     double *dist;      // [b][kSieveQueryCap] reference distance
     float *rv;         // [b][kSieveQueryCap] true ranking value (the scan's units), rounded to float
     uint32_t *row;     // [b][kSieveQueryCap]
-    uint32_t *count;   // [b] appended so far (may exceed the capacity: the rest was dropped)
+    uint32_t *count;   // [b][kSieveCountStride] (word 0) appended so far (may exceed the capacity: the rest was dropped)
     uint32_t *over;    // [b] != 0: a candidate of this query was dropped somewhere -> exact pass
 };
 
@@ -212,15 +272,18 @@ struct SieveVerifyArgs {
     SieveLists l;
 };
 
+constexpr int kSieveVerifySplit = 4;  // workgroups per region: a wave's candidates are a serial chain of dependent loads
 __global__ __launch_bounds__(1024) void sieve_verify_kernel(SieveVerifyArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t cnt = a.ccount[blockIdx.x];
+    const int reg = blockIdx.x / kSieveVerifySplit, part = blockIdx.x % kSieveVerifySplit;
+    uint32_t cnt = a.ccount[reg];
     if (cnt > (uint32_t)kSieveRegion) {  // the region overflowed: whose candidates were lost is unknown
-        for (int i = tid; i < a.nq; i += 1024) a.l.over[a.q0 + i] = 1;
+        if (part == 0)
+            for (int i = tid; i < a.nq; i += 1024) a.l.over[a.q0 + i] = 1;
         cnt = kSieveRegion;
     }
-    const uint64_t *region = a.cand + (size_t)blockIdx.x * kSieveRegion;
-    for (uint32_t e = wave; e < cnt; e += 16) {
+    const uint64_t *region = a.cand + (size_t)reg * kSieveRegion;
+    for (uint32_t e = part * 16 + wave; e < cnt; e += 16 * kSieveVerifySplit) {
         const uint64_t key = region[e];
         const int qi = a.q0 + (int)(key >> 32);
         const uint32_t row = (uint32_t)key;
@@ -228,7 +291,7 @@ __global__ __launch_bounds__(1024) void sieve_verify_kernel(SieveVerifyArgs a) {
         const double dist = exact_metric_wave(a.docs + (size_t)row * a.d, a.q + (size_t)qi * a.d, a.d, a.metric, a.doc_sq[row],
                                               a.q_sq[qi], a.q_norm[qi], lane, &rv);
         if (lane == 0) {
-            const uint32_t slot = atomicAdd(&a.l.count[qi], 1u);
+            const uint32_t slot = atomicAdd(&a.l.count[(size_t)qi * kSieveCountStride], 1u);
             if (slot < (uint32_t)kSieveQueryCap) {
                 a.l.dist[(size_t)qi * kSieveQueryCap + slot] = dist;
                 a.l.rv[(size_t)qi * kSieveQueryCap + slot] = (float)rv;
@@ -261,34 +324,42 @@ struct SieveSelectArgs {
     int32_t *out_flags;
     int32_t *nflag;
     int32_t *flagged;
+    unsigned long long *stats;     // mir_index_scan_stats counters (see there)
 };
 
-// grid = nq (one block per query), block = 256.
+// grid = nq (one block per query), block = 256.  The query's verified candidates (a few hundred) -> LDS; a float32
+// pre-filter (how many ranking values are greater than mine: full-rate compares, four per LDS read) leaves the ~k
+// entries that can be among the first k; only those are ranked with the reference's float64 order.
 __global__ __launch_bounds__(256) void sieve_select_kernel(SieveSelectArgs a) {
-    __shared__ double s_d[kSieveSelectCap];
-    __shared__ uint32_t s_r[kSieveSelectCap];
-    __shared__ float s_v[kSieveSelectCap];
-    __shared__ int s_n;
-    const int tid = threadIdx.x;
+    __shared__ double s_d[kSieveQueryCap];
+    __shared__ uint32_t s_r[kSieveQueryCap];
+    __shared__ __attribute__((aligned(16))) float s_v[kSieveQueryCap + 4];
+    __shared__ uint16_t s_fin[kSieveSelectCap];
+    __shared__ int s_n, s_nn, s_f;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int qi = a.q0 + blockIdx.x;
-    const uint32_t total = a.l.count[qi];
+    const uint32_t total = a.l.count[(size_t)qi * kSieveCountStride];
     const int n = (int)(total < (uint32_t)kSieveQueryCap ? total : (uint32_t)kSieveQueryCap);
     const double *ld = a.l.dist + (size_t)qi * kSieveQueryCap;
     const uint32_t *lr = a.l.row + (size_t)qi * kSieveQueryCap;
     const float *lv = a.l.rv + (size_t)qi * kSieveQueryCap;
-    bool over = a.l.over[qi] != 0;
-    if (tid == 0) s_n = 0;
+    const bool over = a.l.over[qi] != 0;
+    if (tid == 0) { s_n = 0; s_nn = 0; s_f = 0; }
     __syncthreads();
-    if (over) {
+    auto to_exact_pass = [&]() {
         if (a.mode == 1 && tid == 0) {
+            atomicAdd(a.stats + 3, 1ull);
             a.flagged[atomicAdd(a.nflag, 1)] = qi;
             if (a.out_flags) a.out_flags[qi] = MIR_FLAG_EXACT_PASS;
             if (a.out_count) a.out_count[qi] = 0;
         }
-        return;  // (mode 0: the sample's threshold stays; the next launch only adds to a list that is already lost)
+    };
+    if (over) {  // a candidate of this query was dropped somewhere (mode 0: the sample's threshold stays)
+        to_exact_pass();
+        return;
     }
-    // the candidates that can still be among the first k: all of them, or (mode 1, launch 1 found k) those not worse
-    // than launch 1's k-th
+    // ---- 0. the candidates that can still be among the first k: all of them, or (mode 1, launch 1 found k) those not
+    //         worse than launch 1's k-th.  A NaN distance ranks last whatever its ranking value: -inf for the pre-filter
     const bool cut = a.mode == 1 && a.kth_valid[qi] != 0;
     const double kd = cut ? a.kth_dist[qi] : 0.0;
     const uint32_t kr = cut ? a.kth_row[qi] : 0u;
@@ -302,30 +373,65 @@ __global__ __launch_bounds__(256) void sieve_select_kernel(SieveSelectArgs a) {
             dd = ld[e]; rr = lr[e]; vv = lv[e];
             keep = !cut || !dist_before(kd, kr, dd, rr);
         }
-        const unsigned long long bal = __ballot(keep);
+        const bool is_num = dd == dd;
+        const unsigned long long bal = __ballot(keep), nbal = __ballot(keep && is_num);
         int base = 0;
-        const int lane = tid & 63;
-        if (bal && lane == __builtin_ctzll(bal)) base = atomicAdd(&s_n, __popcll(bal));
+        if (bal && lane == __builtin_ctzll(bal)) {
+            base = atomicAdd(&s_n, __popcll(bal));
+            atomicAdd(&s_nn, __popcll(nbal));
+        }
         base = __shfl(base, bal ? __builtin_ctzll(bal) : 0, 64);
         const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (keep && slot < kSieveSelectCap) { s_d[slot] = dd; s_r[slot] = rr; s_v[slot] = vv; }
+        if (keep) { s_d[slot] = dd; s_r[slot] = rr; s_v[slot] = is_num ? vv : -__builtin_inff(); }
     }
     __syncthreads();
-    const int m = s_n;
-    if (m > kSieveSelectCap) {  // more contenders than the ranking holds (a mass of near-ties): the exact pass orders them
-        if (a.mode == 1 && tid == 0) {
-            a.flagged[atomicAdd(a.nflag, 1)] = qi;
-            if (a.out_flags) a.out_flags[qi] = MIR_FLAG_EXACT_PASS;
-            if (a.out_count) a.out_count[qi] = 0;
+    const int m = s_n, nn = s_nn;
+    if (tid < 4) s_v[m + tid] = -__builtin_inff();  // pad to a multiple of 4
+    __syncthreads();
+    // ---- 1. float32 pre-filter: an entry stays if fewer than k ranking values are strictly greater than its own (float
+    //         rounding is monotone, so every entry of the true first k stays); with fewer than k numeric distances the
+    //         NaN ones are needed too: everything stays
+    const int m4 = (m + 3) & ~3;
+    for (int e0 = 0; e0 < m; e0 += 256) {
+        const int e = e0 + tid;
+        bool fin = false;
+        if (e < m) {
+            if (nn < a.k) {
+                fin = true;
+            } else {
+                const float mine = s_v[e];
+                int gt = 0;
+                for (int u = 0; u < m4; u += 4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(s_v + u);
+                    gt += (x.x > mine) + (x.y > mine) + (x.z > mine) + (x.w > mine);
+                }
+                fin = gt < a.k && mine > -__builtin_inff();
+            }
         }
+        const unsigned long long bal = __ballot(fin);
+        int base = 0;
+        if (bal && lane == __builtin_ctzll(bal)) base = atomicAdd(&s_f, __popcll(bal));
+        base = __shfl(base, bal ? __builtin_ctzll(bal) : 0, 64);
+        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (fin && slot < kSieveSelectCap) s_fin[slot] = (uint16_t)e;
+    }
+    __syncthreads();
+    const int f = s_f;
+    if (f > kSieveSelectCap) {  // a mass of equal ranking values at the cut: the exact pass orders them
+        to_exact_pass();
         return;
     }
+    // ---- 2. the reference's order among the finalists
     const int kout = a.k < m ? a.k : m;
-    for (int e = tid; e < m; e += 256) {
+    for (int i = tid; i < f; i += 256) {
+        const int e = s_fin[i];
         const double dd = s_d[e];
         const uint32_t rr = s_r[e];
         int rank = 0;
-        for (int c = 0; c < m; ++c) rank += dist_before(s_d[c], s_r[c], dd, rr) ? 1 : 0;  // (an entry is not before itself)
+        for (int c = 0; c < f; ++c) {
+            const int o = s_fin[c];
+            rank += dist_before(s_d[o], s_r[o], dd, rr) ? 1 : 0;  // (an entry is not before itself)
+        }
         if (a.mode == 1) {
             if (rank < a.k) {
                 const size_t o = (size_t)qi * a.k + rank;
@@ -350,7 +456,9 @@ __global__ __launch_bounds__(256) void sieve_select_kernel(SieveSelectArgs a) {
             }
         }
     }
+    if (tid == 0) atomicAdd(a.stats + 4 + a.mode, (unsigned long long)m);  // entries ranked after launch 1 / at the end
     if (a.mode == 1 && tid == 0) {
+        atomicAdd(a.stats + 2, 1ull);
         if (a.out_count) a.out_count[qi] = kout;
         if (a.out_flags) a.out_flags[qi] = 0;
     }

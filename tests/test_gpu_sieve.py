@@ -1,0 +1,154 @@
+"""GPU parity of the sieve (csrc/vec_kernels_sieve.h): the search of large float32 shards (>= 64 tiles per workgroup,
+i.e. >= 524 288 rows on 256 CUs) - a filter on the bf16 hi blocks alone, the reference's float64 formula for every
+candidate, the reference's order over them.  It claims to be exact BY CONSTRUCTION, so every case here compares ids,
+their order and the distances with the oracle (embeddings_index.py:51-89 upstream), and the cases a float32 filter
+cannot order - groups of near-identical rows, exact duplicates across the cut - must come out right WITHOUT the exact
+pass (flag 0).  Buffer overflows (thousands of rows inside the filter's band) must hand the query to the exact pass."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+METRICS = ["cosine_sim", "euclidean_dist", "sqeuclidean_dist", "inner_product"]
+COS_NOISE = 2e-7
+N = 600_000  # > 64 tiles x 256 workgroups x 32 rows
+
+
+@pytest.fixture(scope="module")
+def ei():
+    from aidial_rag_amd import _native
+    from aidial_rag_amd.retrievers import embeddings_index
+
+    assert _native.device_count() >= 1
+    return embeddings_index
+
+
+def check(metric, q, docs, got, k, msg):
+    from oracle import embeddings_index as oi
+    from oracle import embeddings_metrics as om
+
+    doc, chunk, row, dist, cnt, flags = got
+    with np.errstate(invalid="ignore"):
+        alld = om.ENUM_TO_METRIC[om.Metric(metric)](q, docs)
+    want = np.argsort(alld, kind="stable")[:k]
+    assert cnt == len(want), msg
+    g = row[:cnt]
+    if metric != "cosine_sim":
+        np.testing.assert_array_equal(g, want, err_msg=msg)
+    else:
+        for a, b in zip(g, want):
+            assert a == b or abs(alld[a] - alld[b]) <= COS_NOISE, f"{msg}: {a} vs {b}"
+    np.testing.assert_allclose(dist[:cnt], alld[g], rtol=0, atol=5e-7 if metric == "cosine_sim" else 1e-9, equal_nan=True, err_msg=msg)
+
+
+@pytest.fixture(scope="module")
+def corpus():
+    rng = np.random.default_rng(77)
+    docs = rng.standard_normal((N, 384)).astype(np.float32)
+    docs /= np.linalg.norm(docs, axis=1, keepdims=True)
+    # a group of 40 near-identical rows (within 1e-7) scattered over both launches' tiles, and exact duplicates
+    centre = docs[123].copy()
+    group = np.sort(rng.choice(N, 40, replace=False))
+    for p in group:
+        docs[p] = centre + 1e-7 * rng.standard_normal(384).astype(np.float32)
+    dup_src = 555_001
+    dups = [17, 40_000, 300_000, 599_999]
+    for p in dups:
+        docs[p] = docs[dup_src]
+    docs[777] = 0.0            # a zero row (cosine: clamped norm)
+    docs[100_000, 5] = np.nan  # a NaN row: distance NaN, sorts last
+    qs = rng.standard_normal((12, 384))
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    off = rng.standard_normal(384)
+    qs[0] = centre.astype(np.float64) + 0.3 * off / np.linalg.norm(off)  # the group is its top 40: the cut at k falls inside it
+    qs[1] = docs[dup_src].astype(np.float64)                             # five bit-identical rows first; euclidean_dist: NaN quirk
+    qs[2] = docs[dups[1]].astype(np.float64) * 3.0
+    qs[3] = 0.0                                                          # zero query
+    return docs, qs, group, dups + [dup_src]
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_sieve_equals_oracle(ei, corpus, metric):
+    docs, qs, group, dups = corpus
+    ix = ei.DeviceIndex.from_host(docs)
+    for k in (10, 1, 64):
+        with np.errstate(invalid="ignore"):
+            out = ix.search(qs, k, metric)
+        # (query 3 is all zeros: every row ties with every other under the dot-product metrics - a legitimate overflow)
+        assert int(np.delete(out[5], 3).sum()) == 0, f"{metric} k={k}: the sieve needed the exact pass: {out[5]}"
+        for i in range(len(qs)):
+            check(metric, qs[i], docs, tuple(o[i] for o in out), k, f"{metric} k={k} q={i}")
+    if metric == "sqeuclidean_dist":
+        rows = ix.search(qs[:2], 10, metric)[2]
+        assert set(rows[0]) <= set(group.tolist())                       # decided inside the near-identical group
+        assert list(rows[1][:5]) == sorted(dups)                         # exact ties: ascending row
+    ix.close()
+
+
+def test_batch_sizes_groups_and_row_offset(ei, corpus):
+    docs, qs, _, _ = corpus
+    rng = np.random.default_rng(5)
+    big = rng.standard_normal((200, 384))
+    big[:12] = qs
+    ix = ei.DeviceIndex.from_host(docs, row_offset=10_000_000_000)
+    one = ix.search(big[:1], 10, "sqeuclidean_dist")
+    full = ix.search(big[:128], 10, "sqeuclidean_dist")
+    two_groups = ix.search(big, 10, "sqeuclidean_dist")   # 200 queries: two launches groups of 128 and 72
+    for a, b in zip(one, full):
+        np.testing.assert_array_equal(a[0], b[0])
+    for a, b in zip(full, two_groups):
+        np.testing.assert_array_equal(a, b[:128])
+    assert int(np.delete(two_groups[5], 3).sum()) == 0  # (query 3 is all zeros)
+    for i in (0, 5, 130, 199):
+        got = [o[i] for o in two_groups]
+        got[2] = got[2] - 10_000_000_000
+        check("sqeuclidean_dist", big[i], docs, tuple(got), 10, f"q={i}")
+    ix.close()
+
+
+@pytest.mark.parametrize("d", [128, 200, 72])
+def test_other_dimensions_and_unnormalised_rows(ei, d):
+    """d padded to 128 / 256; rows with very different norms (the filter's margin uses the index's largest norm)."""
+    rng = np.random.default_rng(d)
+    docs = (rng.standard_normal((N, d)) * rng.uniform(0.2, 4.0, (N, 1))).astype(np.float32)
+    docs[4000] = docs[9]
+    qs = rng.standard_normal((5, d)) * 2.0
+    qs[0] = docs[9].astype(np.float64)
+    ix = ei.DeviceIndex.from_host(docs)
+    for metric in METRICS:
+        with np.errstate(invalid="ignore"):
+            out = ix.search(qs, 7, metric)
+        for i in range(len(qs)):
+            check(metric, qs[i], docs, tuple(o[i] for o in out), 7, f"d={d} {metric} q={i}")
+    ix.close()
+
+
+def test_overflowing_buffers_take_the_exact_pass(ei):
+    """6 000 bit-identical rows next to the query: more candidates than a query's list holds - the query is flagged and
+    the exact pass returns the reference's answer (the lowest rows); the other queries of the batch are untouched.
+    Then a corpus that is ONE row 600 000 times: every workgroup's region overflows, every query takes the exact pass."""
+    rng = np.random.default_rng(9)
+    d = 128
+    docs = rng.standard_normal((N, d)).astype(np.float32)
+    docs /= np.linalg.norm(docs, axis=1, keepdims=True)
+    same = np.sort(rng.choice(N, 6000, replace=False))
+    docs[same] = docs[same[0]]
+    qs = rng.standard_normal((6, d))
+    qs[2] = docs[same[0]].astype(np.float64) + 0.01 * rng.standard_normal(d)
+    ix = ei.DeviceIndex.from_host(docs)
+    out = ix.search(qs, 10, "sqeuclidean_dist")
+    assert list(out[5]) == [0, 0, 2, 0, 0, 0]
+    assert list(out[2][2]) == list(same[:10])  # bit-identical rows: one distance, ascending row
+    assert len(set(out[3][2])) == 1
+    for i in (0, 1, 3, 4, 5):  # (numpy's own gemv gives bit-identical rows distances that differ in the last bit, by
+        check("sqeuclidean_dist", qs[i], docs, tuple(o[i] for o in out), 10, f"q={i}")  # position: no order to compare for query 2)
+    ix.close()
+    docs[:] = docs[0]
+    ix = ei.DeviceIndex.from_host(docs)
+    q16 = rng.standard_normal((16, d))  # 16 x 600 000 candidates over 256 regions of 8192: the regions overflow too
+    out = ix.search(q16, 5, "inner_product")
+    assert list(out[5]) == [2] * 16
+    for i in range(16):
+        assert list(out[2][i]) == [0, 1, 2, 3, 4]
+    ix.close()

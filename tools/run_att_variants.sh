@@ -1,6 +1,8 @@
 #!/bin/bash
 # builds encoder_attention.o with -DATT_VARIANT=n (ENC_EXTRA) for each argument and times the encoder kernels
 R=${GRAFT_REPO_ROOT:-$PWD}
+# whatever happens, the tree ends with the DEFAULT build (a later `make` would otherwise keep shipping an experiment)
+trap 'make -C $R/ai-dial-rag_amd/csrc -B build/encoder.o build/encoder_attention.o build/encoder_ffn.o ENC_EXTRA= -j8 > /dev/null 2>&1; make -C $R/ai-dial-rag_amd/csrc > /dev/null 2>&1' EXIT
 for v in "$@"; do
   make -C $R/ai-dial-rag_amd/csrc -B build/encoder_attention.o ENC_EXTRA="$v" > /tmp/att_build.log 2>&1 && make -C $R/ai-dial-rag_amd/csrc >> /tmp/att_build.log 2>&1 || { tail -5 /tmp/att_build.log; exit 1; }
   echo "### $v"

@@ -1,6 +1,8 @@
 #!/bin/bash
 # rebuilds the three encoder objects with each argument as ENC_EXTRA and times the encoder kernels (tools/encoder_throughput.py)
 R=${GRAFT_REPO_ROOT:-$PWD}
+# whatever happens, the tree ends with the DEFAULT build (a later `make` would otherwise keep shipping an experiment)
+trap 'make -C $R/ai-dial-rag_amd/csrc -B build/encoder.o build/encoder_attention.o build/encoder_ffn.o ENC_EXTRA= -j8 > /dev/null 2>&1; make -C $R/ai-dial-rag_amd/csrc > /dev/null 2>&1' EXIT
 for v in "$@"; do
   make -C $R/ai-dial-rag_amd/csrc -B build/encoder.o build/encoder_attention.o build/encoder_ffn.o ENC_EXTRA="$v" -j8 > /tmp/enc_build.log 2>&1 && make -C $R/ai-dial-rag_amd/csrc >> /tmp/enc_build.log 2>&1 || { tail -5 /tmp/enc_build.log; exit 1; }
   echo "### $v"
