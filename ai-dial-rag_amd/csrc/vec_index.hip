@@ -16,6 +16,7 @@
 #include "vec_kernels_q16.h"
 #include "vec_kernels_h16.h"
 #include "vec_kernels_sieve.h"
+#include "vec_kernels_exact.h"
 
 namespace mir {
 
@@ -97,6 +98,7 @@ struct mir_index {
     uint4 *d_split = nullptr;    // bf16 hi/lo fragments, or the float16 fragments of a native16 index
     float *d_docsq = nullptr;    // padded to n_tiles*32
     float *d_invnorm = nullptr;  // padded to n_tiles*32
+    float *d_dnorm = nullptr;    // max((float)|row|, 1e-8), exact_metric_wave's summation order: cosine_sim of the batched exact pass
     float *d_maxnorm = nullptr;
     unsigned long long *d_stats = nullptr;  // 8 counters of the sieve (mir_index_scan_stats)
     int64_t *d_chunk = nullptr;
@@ -147,6 +149,7 @@ static void free_index(mir_index *ix) {
     (void)hipFree(ix->d_split);
     (void)hipFree(ix->d_docsq);
     (void)hipFree(ix->d_invnorm);
+    (void)hipFree(ix->d_dnorm);
     (void)hipFree(ix->d_maxnorm);
     (void)hipFree(ix->d_stats);
     (void)hipFree(ix->d_chunk);
@@ -182,7 +185,8 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
     MIR_HIP(hipMalloc(&ix->d_docsq, std::max<size_t>(aux_bytes, 16)));
     MIR_HIP(hipMalloc(&ix->d_invnorm, std::max<size_t>(aux_bytes, 16)));
     MIR_HIP(hipMalloc(&ix->d_maxnorm, 16));
-    ix->hbm_bytes += split_bytes + 2 * aux_bytes + 16;
+    MIR_HIP(hipMalloc(&ix->d_dnorm, std::max<size_t>((size_t)n * 4, 16)));
+    ix->hbm_bytes += split_bytes + 2 * aux_bytes + 16 + (size_t)n * 4;
     MIR_HIP(hipMemsetAsync(ix->d_docsq, 0, std::max<size_t>(aux_bytes, 16), stream));
     MIR_HIP(hipMemsetAsync(ix->d_invnorm, 0, std::max<size_t>(aux_bytes, 16), stream));
     MIR_HIP(hipMemsetAsync(ix->d_maxnorm, 0, 16, stream));
@@ -209,6 +213,9 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
             MIR_HIP(hipGetLastError());
             launch_row_norms(ix->d_orig, n, d, ix, stream);
         }
+        MIR_HIP(hipGetLastError());
+        if (ix->native16) row_dnorm_kernel<_Float16><<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream>>>(ix->d_f16, n, d, ix->d_dnorm);
+        else row_dnorm_kernel<float><<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->d_dnorm);
         MIR_HIP(hipGetLastError());
     }
     return MIR_OK;
@@ -259,6 +266,7 @@ struct SearchBuffers {
     double *bound_dist;  // [b] exact pass, k > 64: last result of the previous round
     uint32_t *bound_row; // [b]
     uint64_t *part_exact;  // [b][exact grid][64][2]
+    double *qt;            // [ceil(b / 32)][d padded to 256][32]: the flagged queries, transposed, for the batched exact pass
     uint64_t *part_sample;  // [kSampleWgs][128][klist], reused by every launch (stream-ordered)
     // the sieve (vec_kernels_sieve.h): candidate regions of its two launches, the queries' verified lists
     uint64_t *sv_cand;      // [2][nwg][kSieveRegion]
@@ -310,6 +318,7 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.bound_dist = c.take<double>(b);
     sb.bound_row = c.take<uint32_t>(b);
     sb.part_exact = c.take<uint64_t>((size_t)b * pl.exact_grid * std::min(k, kExactRound) * 2);
+    sb.qt = c.take<double>((size_t)((b + kXbQ - 1) / kXbQ) * xb_dpad(d) * kXbQ);
     sb.part_sample = c.take<uint64_t>((size_t)kSampleWgs * 128 * klist);
     const size_t sv_q = pl.sieve ? (size_t)b * kSieveQueryCap : 0;
     sb.sv_cand = c.take<uint64_t>(pl.sieve ? (size_t)2 * nwg * kSieveRegion : 0);
@@ -581,9 +590,16 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     const int gwords = sb.ctl_words;
     // (blocks past the fragment and per-query blocks only zero their 64 words and return)
     const int prep_blocks = std::max(ntiles32 * ix->ksteps + b, (gwords + 63) / 64);
-    ExactArgs ea;
-    ea.docs = ix->d_orig; ea.docs16 = ix->d_f16; ea.doc_sq = ix->d_docsq; ea.n_rows = (uint32_t)ix->n; ea.d = d;
-    ea.metric = metric; ea.q = dq; ea.q_sq = sb.q_sq; ea.q_norm = sb.q_norm; ea.nflag = sb.nflag; ea.flagged = sb.flagged;
+    ExactBatchArgs ea;
+    ea.docs = ix->d_orig; ea.docs16 = ix->d_f16; ea.doc_sq = ix->d_docsq; ea.dnorm = ix->d_dnorm; ea.n_rows = (uint32_t)ix->n; ea.d = d;
+    ea.metric = metric; ea.qt = sb.qt; ea.q_sq = sb.q_sq; ea.nflag = sb.nflag; ea.flagged = sb.flagged;
+    auto exact_pass = [&]() {  // device-gated: exits at once when no query was flagged
+        const bool cosine = metric == MIR_METRIC_COSINE_SIM;
+        if (ix->native16 && cosine) exact_topk_batch_kernel<_Float16, true><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea);
+        else if (ix->native16) exact_topk_batch_kernel<_Float16, false><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea);
+        else if (cosine) exact_topk_batch_kernel<float, true><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea);
+        else exact_topk_batch_kernel<float, false><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea);
+    };
     ea.k = k; ea.round = 0; ea.list_stride = std::min(k, kExactRound); ea.part = sb.part_exact; ea.arrive = sb.arrive;
     ea.bound_dist = sb.bound_dist; ea.bound_row = sb.bound_row; ea.chunk_ids = ix->d_chunk; ea.doc_ids = ix->d_doc;
     ea.row_offset = ix->row_offset; ea.out_doc = o_doc; ea.out_chunk = o_chunk; ea.out_row = o_row; ea.out_dist = o_dist;
@@ -592,13 +608,13 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         // k beyond the filter's candidate lists: no scan; every query is the reference's own computation.
         // ceil(min(k, n) / 64) rounds, each one pass over the rows per query.
         prep_queries_kernel<<<dim3(std::max(b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(dq, b, d, ix->ksteps, 0, nullptr, sb.q_sq, sb.q_norm, gz, gwords);
-        flag_all_kernel<<<dim3((b + 255) / 256), dim3(256), 0, stream>>>(b, sb.nflag, sb.flagged);
+        flag_all_kernel<<<dim3(b), dim3(256), 0, stream>>>(b, sb.nflag, sb.flagged, dq, d, metric, sb.q_norm, sb.qt);
         MIR_HIP(hipGetLastError());
         const int64_t found = std::min<int64_t>(k, ix->n);
         const int rounds = (int)std::max<int64_t>(1, (found + kExactRound - 1) / kExactRound);
         for (int r = 0; r < rounds; ++r) {
             ea.round = r;
-            exact_topk_kernel<<<dim3(pl.exact_grid), dim3(kExactThreads), 0, stream>>>(ea);
+            exact_pass();
             MIR_HIP(hipGetLastError());
         }
         return MIR_OK;
@@ -659,14 +675,16 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             sa.kth_valid = sb.sv_kth_valid; sa.chunk_ids = ix->d_chunk; sa.doc_ids = ix->d_doc; sa.row_offset = ix->row_offset;
             sa.out_doc = o_doc; sa.out_chunk = o_chunk; sa.out_row = o_row; sa.out_dist = o_dist; sa.out_count = o_count;
             sa.out_flags = o_flags; sa.nflag = sb.nflag; sa.flagged = sb.flagged; sa.stats = ix->d_stats;
-            rc = sieve(0, (uint32_t)kSampleWgs * kSampleTilesPerWg, kSampleWgs, nullptr, nullptr, true);
+            sa.q = dq; sa.qt = sb.qt; sa.d = d;
+            const uint32_t tpw = std::min<uint32_t>(kSampleTilesPerWg, ix->n_tiles / (4u * kSampleWgs));  // (>= 1: plan())
+            rc = sieve(0, (uint32_t)kSampleWgs * tpw, kSampleWgs, nullptr, nullptr, true);
             if (rc != MIR_OK) return rc;
             sample_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(reinterpret_cast<const float *>(sb.part_sample), kSampleWgs, qpw,
                                                                         k, nq, reinterpret_cast<unsigned long long *>(gt));
             MIR_HIP(hipGetLastError());
             rc = begin_profile();
             if (rc != MIR_OK) return rc;
-            for (int phase = 0; phase < 2 && rc == MIR_OK; ++phase) {
+            for (int phase = pl.tiles_first ? 0 : 1; phase < 2 && rc == MIR_OK; ++phase) {  // (one launch: the final phase alone)
                 uint64_t *cand = sb.sv_cand + (size_t)phase * nwg * kSieveRegion;
                 uint32_t *cc = sb.sv_ccount + (size_t)phase * nwg;
                 rc = phase == 0 ? sieve(0, pl.tiles_first, nwg, cand, cc, false)
@@ -681,7 +699,9 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                 va.cand = cand; va.ccount = cc;
                 sieve_verify_kernel<<<dim3(nwg * kSieveVerifySplit), dim3(1024), 0, stream>>>(va);
                 sa.mode = phase;
-                sieve_select_kernel<<<dim3(nq), dim3(256), 0, stream>>>(sa);
+                MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sieve_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)sieve_select_lds_bytes()));
+                sieve_select_kernel<<<dim3(nq), dim3(256), sieve_select_lds_bytes(), stream>>>(sa);
                 MIR_HIP(hipGetLastError());
             }
             if (rc != MIR_OK) return rc;
@@ -757,7 +777,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         if (rc != MIR_OK) return rc;
     }
     if (pl.sieve) {  // the select kernel wrote the results; queries whose buffers overflowed take the exact pass
-        exact_topk_kernel<<<dim3(pl.exact_grid), dim3(kExactThreads), 0, stream>>>(ea);
+        exact_pass();
         MIR_HIP(hipGetLastError());
         return MIR_OK;
     }
@@ -768,19 +788,24 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     fa.q = dq; fa.q_sq = sb.q_sq; fa.q_norm = sb.q_norm;
     fa.chunk_ids = ix->d_chunk; fa.doc_ids = ix->d_doc; fa.row_offset = ix->row_offset;
     fa.out_doc = o_doc; fa.out_chunk = o_chunk; fa.out_row = o_row; fa.out_dist = o_dist;
-    fa.out_count = o_count; fa.out_flags = o_flags; fa.nflag = sb.nflag; fa.flagged = sb.flagged;
+    fa.out_count = o_count; fa.out_flags = o_flags; fa.nflag = sb.nflag; fa.flagged = sb.flagged; fa.qt = sb.qt;
     finalize_kernel<<<dim3(b), dim3(256), 0, stream>>>(fa);
     MIR_HIP(hipGetLastError());
     // queries whose candidate set finalize could not prove complete: exact pass, gated on the device (it exits at
     // once when there are none)
-    exact_topk_kernel<<<dim3(pl.exact_grid), dim3(kExactThreads), 0, stream>>>(ea);
+    exact_pass();
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }
 
 static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
-    // one exact-pass workgroup per CU, fewer on small shards (a workgroup's 16 waves take a row each)
-    pl->exact_grid = (int)std::max<int64_t>(1, std::min<int64_t>(ix->num_cus, (ix->n + kExactWaves - 1) / kExactWaves));
+    // the exact pass: two workgroups per CU (one stages rows while the other computes), one per 64-row block on small
+    // shards; its per-workgroup lists are b x grid x min(k, 64) x 16 bytes of workspace - fewer workgroups for huge batches
+    {
+        const int64_t per_wg = (int64_t)b * std::min(k, kExactRound) * 16;
+        const int64_t by_mem = std::max<int64_t>(64, ((int64_t)256 << 20) / std::max<int64_t>(per_wg, 1));
+        pl->exact_grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(2 * ix->num_cus, by_mem), (ix->n + kXbRows - 1) / kXbRows));
+    }
     pl->klist = std::min(k + (ix->native16 ? kH16ListMargin : kListMargin), kMaxList);
     // The reference takes any `limit` (embeddings_index.py:58,81).  Beyond what the filter's per-lane candidate
     // lists hold (LDS), an index that could actually return that many rows is searched by the exact pass alone.
@@ -788,13 +813,16 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
     if (ix->layout16 && !sieve_off && k <= kSieveMaxK) {
         // large shards (the progressive scan's: >= 64 tiles per workgroup): filter on the hi blocks alone, verify every candidate
         const int wgs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), (int64_t)ix->n_tiles));
-        if ((int64_t)ix->n_tiles >= 64 * (int64_t)wgs) {
+        if (ix->n_tiles >= 4u * kSampleWgs) {  // from 32K rows: there is a sample to take the first threshold from
             pl->sieve = true;
             pl->qpw = kQ16Queries;
             pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
             pl->nwg = wgs;
             pl->klist = std::min(k, kMaxList);
-            pl->tiles_first = std::max<uint32_t>(ix->n_tiles / 16, std::min<uint32_t>(ix->n_tiles / 4, 4896u));
+            // shards of >= 64 tiles per workgroup in two filter launches (1/16 of the tiles, but not fewer than ~157K rows
+            // nor more than 1/4, then the rest with the exact k-th best so far as the threshold); smaller ones in one
+            pl->tiles_first = (int64_t)ix->n_tiles >= 64 * (int64_t)wgs
+                                  ? std::max<uint32_t>(ix->n_tiles / 16, std::min<uint32_t>(ix->n_tiles / 4, 4896u)) : 0;
             return MIR_OK;
         }
     }

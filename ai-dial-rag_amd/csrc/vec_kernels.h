@@ -812,6 +812,24 @@ __device__ inline void merge_sorted_lists(const uint64_t *__restrict__ lists, si
     __syncthreads();
 }
 
+// ---- hand-over to the exact pass (vec_kernels_exact.h): the flagging kernels write the query's column of the transposed
+// copy Qt[pass][column][32 queries] that the batched pass reads through the scalar cache
+constexpr int kXbCols = 128;     // columns staged per slice of the exact pass
+constexpr int kXbQ = 32;         // queries per pass of the exact pass
+__host__ __device__ constexpr int xb_dpad(int d) { return (d + kXbCols - 1) / kXbCols * kXbCols; }
+// whole block (`nthreads` threads), f = the query's position in the flagged list; cosine_sim stores q / max(|q|, 1e-8)
+__device__ __forceinline__ void exact_publish_query(double *__restrict__ qt, int f, const double *__restrict__ q, int d, int metric,
+                                                    double q_norm, int tid, int nthreads) {
+    const int dpad = xb_dpad(d);
+    const double qn = fmax(q_norm, 1e-8);
+    double *dst = qt + ((size_t)(f / kXbQ) * dpad) * kXbQ + (f % kXbQ);
+    for (int j = tid; j < dpad; j += nthreads) {
+        double x = j < d ? q[j] : 0.0;
+        if (metric == MIR_METRIC_COSINE_SIM) x = x / qn;
+        dst[(size_t)j * kXbQ] = x;
+    }
+}
+
 struct FinalizeArgs {
     const uint64_t *part;   // [launch][nwg][qpw][klist]
     int nwg;                // workgroups of the scan
@@ -840,6 +858,7 @@ struct FinalizeArgs {
     int32_t *out_flags;
     int32_t *nflag;         // number of queries handed to the exact pass (zeroed by the prep kernel)
     int32_t *flagged;       // [b] their indices, in arrival order
+    double *qt;             // the exact pass's transposed copy of the flagged queries
 };
 
 // grid = b (one block per query), block = 256, static LDS 64 KiB + small.
@@ -853,6 +872,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     __shared__ double c_rank[kMaxList];
     __shared__ uint32_t c_row[kMaxList];
     __shared__ double s_vk;
+    __shared__ int s_f;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = blockIdx.x;
@@ -919,9 +939,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
         }
         // An unproven query is handed to exact_topk_kernel (enqueued right behind this kernel), which
         // overwrites its outputs and flag; the reference is always exact (embeddings_index.py:51-60).
-        if (flag) a.flagged[atomicAdd(a.nflag, 1)] = qi;
+        s_f = -1;
+        if (flag) {
+            s_f = atomicAdd(a.nflag, 1);
+            a.flagged[s_f] = qi;
+        }
         if (a.out_flags) a.out_flags[qi] = flag;
     }
+    __syncthreads();
+    if (s_f >= 0) exact_publish_query(a.qt, s_f, q, a.d, a.metric, a.q_norm[qi], tid, 256);
 }
 
 // ---------------------------------------------------------------- exact pass
@@ -1097,10 +1123,16 @@ __global__ __launch_bounds__(kExactThreads) void exact_topk_kernel(ExactArgs a) 
 }
 
 // every query takes the exact pass (k beyond the scan's candidate lists)
-__global__ __launch_bounds__(256) void flag_all_kernel(int b, int32_t *__restrict__ nflag, int32_t *__restrict__ flagged) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < b) flagged[i] = i;
-    if (i == 0) *nflag = b;
+// grid = b: block i hands query i over (position i of the flagged list)
+__global__ __launch_bounds__(256) void flag_all_kernel(int b, int32_t *__restrict__ nflag, int32_t *__restrict__ flagged,
+                                                       const double *__restrict__ q, int d, int metric, const double *__restrict__ q_norm,
+                                                       double *__restrict__ qt) {
+    const int i = blockIdx.x;
+    if (threadIdx.x == 0) {
+        flagged[i] = i;
+        if (i == 0) *nflag = b;
+    }
+    exact_publish_query(qt, i, q + (size_t)i * d, d, metric, q_norm[i], threadIdx.x, 256);
 }
 
 // ---------------------------------------------------------------- sample thresholds

@@ -40,7 +40,7 @@ namespace mir {
 
 constexpr int kSieveStages = 6;        // LDS-DMA ring: 6 x 24 KiB at d = 384, five stages in flight
 constexpr int kSieveRegion = 8192;     // candidates a workgroup can write per launch (64 KiB of HBM each)
-constexpr int kSieveQueryCap = 4096;   // verified candidates kept per query
+constexpr int kSieveQueryCap = 8192;   // verified candidates kept per query (~55 k of them arrive on a 10M-row shard)
 constexpr int kSieveSelectCap = 1024;  // of which the final ranking holds the ones not worse than launch 1's k-th
 constexpr int kSieveMaxK = 64;
 constexpr int kSieveCountStride = 32;  // a query's append counter has a 128-byte line of its own (43K appends on 4 shared lines took 120 us)
@@ -325,17 +325,22 @@ struct SieveSelectArgs {
     int32_t *nflag;
     int32_t *flagged;
     unsigned long long *stats;     // mir_index_scan_stats counters (see there)
+    const double *q;               // [b][d]: a query handed to the exact pass is published to
+    double *qt;                    // the pass's transposed copy
+    int d;
 };
 
 // grid = nq (one block per query), block = 256.  The query's verified candidates (a few hundred) -> LDS; a float32
 // pre-filter (how many ranking values are greater than mine: full-rate compares, four per LDS read) leaves the ~k
 // entries that can be among the first k; only those are ranked with the reference's float64 order.
+__host__ __device__ constexpr size_t sieve_select_lds_bytes() { return (size_t)kSieveQueryCap * 16 + 16 + (size_t)kSieveSelectCap * 2; }
 __global__ __launch_bounds__(256) void sieve_select_kernel(SieveSelectArgs a) {
-    __shared__ double s_d[kSieveQueryCap];
-    __shared__ uint32_t s_r[kSieveQueryCap];
-    __shared__ __attribute__((aligned(16))) float s_v[kSieveQueryCap + 4];
-    __shared__ uint16_t s_fin[kSieveSelectCap];
-    __shared__ int s_n, s_nn, s_f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sel_lds[];
+    double *s_d = reinterpret_cast<double *>(sel_lds);                                      // [kSieveQueryCap]
+    float *s_v = reinterpret_cast<float *>(sel_lds + (size_t)kSieveQueryCap * 8);            // [kSieveQueryCap + 4]
+    uint32_t *s_r = reinterpret_cast<uint32_t *>(sel_lds + (size_t)kSieveQueryCap * 12 + 16);  // [kSieveQueryCap]
+    uint16_t *s_fin = reinterpret_cast<uint16_t *>(sel_lds + (size_t)kSieveQueryCap * 16 + 16);  // [kSieveSelectCap]
+    __shared__ int s_n, s_nn, s_f, s_slot;
     const int tid = threadIdx.x, lane = tid & 63;
     const int qi = a.q0 + blockIdx.x;
     const uint32_t total = a.l.count[(size_t)qi * kSieveCountStride];
@@ -346,13 +351,17 @@ __global__ __launch_bounds__(256) void sieve_select_kernel(SieveSelectArgs a) {
     const bool over = a.l.over[qi] != 0;
     if (tid == 0) { s_n = 0; s_nn = 0; s_f = 0; }
     __syncthreads();
-    auto to_exact_pass = [&]() {
-        if (a.mode == 1 && tid == 0) {
+    auto to_exact_pass = [&]() {  // (whole block)
+        if (a.mode != 1) return;
+        if (tid == 0) {
             atomicAdd(a.stats + 3, 1ull);
-            a.flagged[atomicAdd(a.nflag, 1)] = qi;
+            s_slot = atomicAdd(a.nflag, 1);
+            a.flagged[s_slot] = qi;
             if (a.out_flags) a.out_flags[qi] = MIR_FLAG_EXACT_PASS;
             if (a.out_count) a.out_count[qi] = 0;
         }
+        __syncthreads();
+        exact_publish_query(a.qt, s_slot, a.q + (size_t)qi * a.d, a.d, a.metric, a.q_norm[qi], tid, 256);
     };
     if (over) {  // a candidate of this query was dropped somewhere (mode 0: the sample's threshold stays)
         to_exact_pass();

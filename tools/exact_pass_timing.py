@@ -15,12 +15,12 @@ for n, d, f16 in ((10_000_000, 384, False), (6_250_000, 1024, True)):
     ix = DeviceIndex.from_device_ptr(x.data_ptr(), n, d, 0, stream=torch.cuda.current_stream().cuda_stream, float16=f16)
     torch.cuda.synchronize(); del x
     se = ShardedSearcher(local_index=ix)
-    q = torch.randn((4, d), generator=g, device=dev, dtype=torch.float64)
+    q = torch.randn((128, d), generator=g, device=dev, dtype=torch.float64)
     for metric in ("sqeuclidean_dist", "cosine_sim"):
-        for B in (1, 4):
-            for _ in range(2): se.search(q[:B], 64, metric)
+        for B in (1, 4, 32, 128):
+            for _ in range(2): se.search(q[:B], 65, metric)
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            for _ in range(3): out = se.search(q[:B], 64, metric)
+            for _ in range(3): out = se.search(q[:B], 65, metric)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-            print(f"n={n} d={d} f16={f16} {metric} B={B} k=64: {dt*1e3:.2f} ms per search ({dt*1e3/B:.2f} per query), flags {out[3].tolist()}", flush=True)
+            print(f"n={n} d={d} f16={f16} {metric} B={B} k=65: {dt*1e3:.2f} ms per search ({dt*1e3/B:.2f} per query), flags {sorted(set(out[3].tolist()))}", flush=True)
     ix.close(); torch.cuda.empty_cache()
