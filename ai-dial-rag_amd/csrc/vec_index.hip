@@ -593,12 +593,19 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     ExactBatchArgs ea;
     ea.docs = ix->d_orig; ea.docs16 = ix->d_f16; ea.doc_sq = ix->d_docsq; ea.dnorm = ix->d_dnorm; ea.n_rows = (uint32_t)ix->n; ea.d = d;
     ea.metric = metric; ea.qt = sb.qt; ea.q_sq = sb.q_sq; ea.nflag = sb.nflag; ea.flagged = sb.flagged;
+    ExactArgs es;  // the serial pass's view of the same buffers (one or two flagged queries)
+    es.docs = ix->d_orig; es.docs16 = ix->d_f16; es.doc_sq = ix->d_docsq; es.n_rows = (uint32_t)ix->n; es.d = d; es.metric = metric;
+    es.q = dq; es.q_sq = sb.q_sq; es.q_norm = sb.q_norm; es.nflag = sb.nflag; es.flagged = sb.flagged;
     auto exact_pass = [&]() {  // device-gated: exits at once when no query was flagged
+        es.k = ea.k; es.round = ea.round; es.list_stride = ea.list_stride; es.part = ea.part; es.arrive = ea.arrive;
+        es.bound_dist = ea.bound_dist; es.bound_row = ea.bound_row; es.chunk_ids = ea.chunk_ids; es.doc_ids = ea.doc_ids;
+        es.row_offset = ea.row_offset; es.out_doc = ea.out_doc; es.out_chunk = ea.out_chunk; es.out_row = ea.out_row;
+        es.out_dist = ea.out_dist; es.out_count = ea.out_count; es.out_flags = ea.out_flags;
         const bool cosine = metric == MIR_METRIC_COSINE_SIM;
-        if (ix->native16 && cosine) exact_topk_batch_kernel<_Float16, true><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea);
-        else if (ix->native16) exact_topk_batch_kernel<_Float16, false><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea);
-        else if (cosine) exact_topk_batch_kernel<float, true><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea);
-        else exact_topk_batch_kernel<float, false><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea);
+        if (ix->native16 && cosine) exact_pass_kernel<_Float16, true><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea, es);
+        else if (ix->native16) exact_pass_kernel<_Float16, false><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea, es);
+        else if (cosine) exact_pass_kernel<float, true><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea, es);
+        else exact_pass_kernel<float, false><<<dim3(pl.exact_grid), dim3(kXbThreads), 0, stream>>>(ea, es);
     };
     ea.k = k; ea.round = 0; ea.list_stride = std::min(k, kExactRound); ea.part = sb.part_exact; ea.arrive = sb.arrive;
     ea.bound_dist = sb.bound_dist; ea.bound_row = sb.bound_row; ea.chunk_ids = ix->d_chunk; ea.doc_ids = ix->d_doc;
@@ -799,12 +806,12 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
 }
 
 static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
-    // the exact pass: two workgroups per CU (one stages rows while the other computes), one per 64-row block on small
-    // shards; its per-workgroup lists are b x grid x min(k, 64) x 16 bytes of workspace - fewer workgroups for huge batches
+    // the exact pass: one workgroup of 16 waves per CU, one per 64-row block on small shards; its per-workgroup lists are
+    // b x grid x min(k, 64) x 16 bytes of workspace - fewer workgroups for huge batches
     {
         const int64_t per_wg = (int64_t)b * std::min(k, kExactRound) * 16;
         const int64_t by_mem = std::max<int64_t>(64, ((int64_t)256 << 20) / std::max<int64_t>(per_wg, 1));
-        pl->exact_grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(2 * ix->num_cus, by_mem), (ix->n + kXbRows - 1) / kXbRows));
+        pl->exact_grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ix->num_cus, by_mem), (ix->n + kXbRows - 1) / kXbRows));
     }
     pl->klist = std::min(k + (ix->native16 ? kH16ListMargin : kListMargin), kMaxList);
     // The reference takes any `limit` (embeddings_index.py:58,81).  Beyond what the filter's per-lane candidate

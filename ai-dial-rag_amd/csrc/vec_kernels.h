@@ -814,8 +814,8 @@ __device__ inline void merge_sorted_lists(const uint64_t *__restrict__ lists, si
 
 // ---- hand-over to the exact pass (vec_kernels_exact.h): the flagging kernels write the query's column of the transposed
 // copy Qt[pass][column][32 queries] that the batched pass reads through the scalar cache
-constexpr int kXbCols = 128;     // columns staged per slice of the exact pass
-constexpr int kXbQ = 32;         // queries per pass of the exact pass
+constexpr int kXbCols = 192;     // columns staged per slice of the exact pass
+constexpr int kXbQ = 128;        // queries per pass of the exact pass
 __host__ __device__ constexpr int xb_dpad(int d) { return (d + kXbCols - 1) / kXbCols * kXbCols; }
 // whole block (`nthreads` threads), f = the query's position in the flagged list; cosine_sim stores q / max(|q|, 1e-8)
 __device__ __forceinline__ void exact_publish_query(double *__restrict__ qt, int f, const double *__restrict__ q, int d, int metric,
@@ -1038,13 +1038,13 @@ __device__ __forceinline__ int exact_block_rank(double my_d, uint32_t my_r, int 
     return valid ? rank : -1;
 }
 
-__global__ __launch_bounds__(kExactThreads) void exact_topk_kernel(ExactArgs a) {
+// (round 3: a device function - exact_pass_kernel of vec_kernels_exact.h runs it when ONE or TWO queries were handed over,
+// the batched pass otherwise)
+__device__ __forceinline__ void exact_topk_serial(const ExactArgs &a, const int nf) {
     __shared__ double s_d[kExactThreads];
     __shared__ uint32_t s_r[kExactThreads];
     __shared__ int s_cnt[kExactWaves];
     __shared__ int s_last;
-    const int nf = *a.nflag;
-    if (nf == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kk = min(kExactRound, a.k - kExactRound * a.round);
     const uint32_t G = gridDim.x;

@@ -4,15 +4,15 @@
 //
 // Round 2's exact_topk_kernel walked the flagged queries one after the other, each a private pass over all rows with a
 // wave per row (lane-strided partial sums, a 6-step wave reduction per row and query): 8.4 ms per query at 10M x 384,
-// 128 flagged queries = 1.1 s.  Here every row is read ONCE for up to 32 flagged queries:
-//   * ROWS ON LANES.  A workgroup stages 64 rows x 128 columns in LDS (row stride 129 floats: conflict-free column
-//     walks); lane l then owns row l and accumulates its dot products sequentially over the columns - no cross-lane
-//     reduction at all.  The query values are the same for every lane: they come through the scalar cache
-//     (s_load) from a transposed copy Qt[pass][column][32 queries] that the flagging kernels write, and enter
-//     v_fma_f64 as the scalar operand.  Wave w of the workgroup's four takes queries 8w .. 8w + 7 of the pass: per
-//     staged element one LDS read, one conversion and eight float64 FMAs, four columns (4 x 8 query values = 64 SGPRs)
-//     per scalar-memory wait; three workgroups per CU (33 KiB of LDS each) so that two waves of a SIMD compute while
-//     one waits.
+// 128 flagged queries = 1.1 s.  Here every row is read ONCE for up to 128 flagged queries:
+//   * ROWS ON LANES.  One workgroup of 16 waves per CU stages 64 rows x 192 columns in LDS (row stride 193 floats:
+//     conflict-free column walks); lane l then owns row l and accumulates its dot products sequentially over the
+//     columns - no cross-lane reduction at all.  The query values are the same for every lane: they come through the
+//     scalar cache (s_load) from a transposed copy Qt[pass][column][128 queries] that the flagging kernels write, and
+//     enter v_fma_f64 as the scalar operand.  Wave w takes queries 8w .. 8w + 7 of the pass: per staged element one LDS
+//     read, one conversion and eight float64 FMAs, four columns (4 x 8 query values = 64 SGPRs) per scalar-memory
+//     wait; the other three waves of its SIMD compute meanwhile.  The next slice is fetched into registers (48 bytes
+//     per thread) before the current one is computed on.
 //   * a wave keeps its 8 queries' best `kk` <= 64 entries in registers, one entry per lane, sorted (exact_wave_insert);
 //     a block of 64 rows costs one vote per query unless a row actually enters a list.
 //   * per pass the workgroups' lists meet in HBM and the last workgroup to arrive merges them (as round 2's kernel).
@@ -27,8 +27,8 @@
 
 namespace mir {
 
-constexpr int kXbThreads = 256;
-constexpr int kXbWaves = 4;
+constexpr int kXbThreads = 1024;
+constexpr int kXbWaves = 16;
 constexpr int kXbRows = 64;      // rows per block = lanes
 constexpr int kXbStride = kXbCols + 1;
 constexpr int kXbQW = 8;         // queries per wave and pass
@@ -111,14 +111,12 @@ __device__ __forceinline__ int xb_block_rank(double my_d, uint32_t my_r, int cnt
 }
 
 template <typename T, bool COS>
-__global__ __launch_bounds__(kXbThreads, 3) void exact_topk_batch_kernel(ExactBatchArgs a) {
-    __shared__ float tile[kXbRows * kXbStride];  // 33 024 B: three workgroups per CU (at four, 128 registers per lane spill)
+__device__ __forceinline__ void exact_topk_batch(const ExactBatchArgs &a, const int nf) {
+    __shared__ float tile[kXbRows * kXbStride];  // 49 408 B
     __shared__ double s_d[kXbThreads];
     __shared__ uint32_t s_r[kXbThreads];
     __shared__ int s_cnt[kXbWaves];
     __shared__ int s_last[kXbQ];
-    const int nf = *a.nflag;
-    if (nf == 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = min(kExactRound, a.k - kExactRound * a.round);
@@ -135,8 +133,8 @@ __global__ __launch_bounds__(kXbThreads, 3) void exact_topk_batch_kernel(ExactBa
         typedef const __attribute__((address_space(4))) double cdouble;
         cdouble *qt = (cdouble *)(a.qt + (size_t)(p0 / kXbQ) * dpad * kXbQ + wave * kXbQW);
         // this wave's queries: slots wave * 8 + i
-        double my_d[kXbQW], b_d[kXbQW], qsq[kXbQW];
-        uint32_t my_r[kXbQW], b_r[kXbQW];
+        double my_d[kXbQW], qsq[kXbQW];
+        uint32_t my_r[kXbQW];
         int cnt[kXbQW];
         bool live[kXbQW];
 #pragma unroll
@@ -146,11 +144,51 @@ __global__ __launch_bounds__(kXbThreads, 3) void exact_topk_batch_kernel(ExactBa
             const int qi = live[i] ? a.flagged[p0 + c] : 0;
             my_d[i] = 0.0; my_r[i] = 0; cnt[i] = 0;
             qsq[i] = live[i] ? a.q_sq[qi] : 0.0;
-            b_d[i] = (bounded && live[i]) ? a.bound_dist[qi] : 0.0;
-            b_r[i] = (bounded && live[i]) ? a.bound_row[qi] : 0u;
         }
         const bool wave_live = wave * kXbQW < np;
 
+        // A slice = 64 rows x 192 columns = 3072 pieces of 16 bytes, three per thread.  The NEXT slice is fetched into
+        // registers before this one is computed on, and stored to LDS after it.
+        constexpr int kIts = kXbRows * (kXbCols / 4) / kXbThreads;
+        static_assert(kIts * kXbThreads == kXbRows * (kXbCols / 4), "slice pieces per thread");
+        float nx[kIts][4];
+        auto fetch = [&](uint32_t blk, int s) {
+#pragma unroll
+            for (int it = 0; it < kIts; ++it) {
+                const int idx = it * kXbThreads + tid;
+                const int r = idx / (kXbCols / 4), c4 = idx % (kXbCols / 4);
+                const int col = s * kXbCols + c4 * 4;
+                const uint32_t gr = blk * kXbRows + r;
+                nx[it][0] = 0.f; nx[it][1] = 0.f; nx[it][2] = 0.f; nx[it][3] = 0.f;
+                if (blk < nblocks && gr < a.n_rows) {
+                    const T *src = docs + (size_t)gr * d + col;
+                    if (vec_ok && col + 3 < d) {
+                        if (sizeof(T) == 4) {
+                            const float4 v = *reinterpret_cast<const float4 *>(src);
+                            nx[it][0] = v.x; nx[it][1] = v.y; nx[it][2] = v.z; nx[it][3] = v.w;
+                        } else {
+                            const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                            const _Float16 *h = reinterpret_cast<const _Float16 *>(&v);
+                            nx[it][0] = (float)h[0]; nx[it][1] = (float)h[1]; nx[it][2] = (float)h[2]; nx[it][3] = (float)h[3];
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (col + u < d) nx[it][u] = (float)src[u];
+                    }
+                }
+            }
+        };
+        auto stash = [&]() {
+#pragma unroll
+            for (int it = 0; it < kIts; ++it) {
+                const int idx = it * kXbThreads + tid;
+                const int r = idx / (kXbCols / 4), c4 = idx % (kXbCols / 4);
+                float *dst = tile + r * kXbStride + c4 * 4;
+                dst[0] = nx[it][0]; dst[1] = nx[it][1]; dst[2] = nx[it][2]; dst[3] = nx[it][3];
+            }
+        };
+        fetch(blockIdx.x, 0);
         for (uint32_t blk = blockIdx.x; blk < nblocks; blk += G) {
             const uint32_t row0 = blk * kXbRows;
             const uint32_t row = row0 + lane;
@@ -161,36 +199,10 @@ __global__ __launch_bounds__(kXbThreads, 3) void exact_topk_batch_kernel(ExactBa
             const float dn = (COS && row_ok) ? a.dnorm[row] : 1.0f;
             for (int s = 0; s < nslices; ++s) {
                 __syncthreads();  // the previous slice has been consumed
-                // ---- stage 64 rows x 128 columns: a row's slice is 512 B contiguous, eight rows per 256-thread load
-                {
-                    const int c4 = lane & 31, col = s * kXbCols + c4 * 4;
-#pragma unroll 4
-                    for (int it = 0; it < kXbRows / (2 * kXbWaves); ++it) {
-                        const int r = (it * kXbWaves + wave) * 2 + (lane >> 5);
-                        const uint32_t gr = row0 + r;
-                        float x[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (gr < a.n_rows) {
-                            const T *src = docs + (size_t)gr * d + col;
-                            if (vec_ok && col + 3 < d) {
-                                if (sizeof(T) == 4) {
-                                    const float4 v = *reinterpret_cast<const float4 *>(src);
-                                    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-                                } else {
-                                    const uint2 v = *reinterpret_cast<const uint2 *>(src);
-                                    const _Float16 *h = reinterpret_cast<const _Float16 *>(&v);
-                                    x[0] = (float)h[0]; x[1] = (float)h[1]; x[2] = (float)h[2]; x[3] = (float)h[3];
-                                }
-                            } else {
-#pragma unroll
-                                for (int u = 0; u < 4; ++u)
-                                    if (col + u < d) x[u] = (float)src[u];
-                            }
-                        }
-                        float *dst = tile + r * kXbStride + c4 * 4;
-                        dst[0] = x[0]; dst[1] = x[1]; dst[2] = x[2]; dst[3] = x[3];
-                    }
-                }
+                stash();
                 __syncthreads();
+                if (s + 1 < nslices) fetch(blk, s + 1);
+                else fetch(blk + G, 0);
                 if (!wave_live) continue;
                 // ---- lane = row: sequential float64 dot products with this wave's 8 queries
                 const float *mine = tile + lane * kXbStride;
@@ -233,7 +245,10 @@ __global__ __launch_bounds__(kXbThreads, 3) void exact_topk_batch_kernel(ExactBa
                 const double worst_d = __shfl(my_d[i], kk - 1, 64);
                 const uint32_t worst_r = __shfl(my_r[i], kk - 1, 64);
                 bool ok = row_ok && (cnt[i] < kk || dist_before(dist, row, worst_d, worst_r));
-                if (bounded) ok = ok && dist_before(b_d[i], b_r[i], dist, row);
+                if (bounded) {  // rounds after the first (k > 64): only rows strictly after the previous round's last result
+                    const int qi = a.flagged[p0 + wave * kXbQW + i];
+                    ok = ok && dist_before(a.bound_dist[qi], a.bound_row[qi], dist, row);
+                }
                 unsigned long long m = __ballot(ok);
                 while (m) {
                     const int l = __builtin_ctzll(m);
@@ -304,6 +319,19 @@ __global__ __launch_bounds__(kXbThreads, 3) void exact_topk_batch_kernel(ExactBa
             __syncthreads();
         }
     }
+}
+
+// One dispatch behind every search: nothing flagged -> exits at once; one or two flagged queries -> round 2's serial
+// pass (a wave per row: 8.4 ms per query at 10M x 384, where the batched pass's sweep costs ~15 ms whatever the count:
+// its scalar query loads are latency-bound with a single wave at work); more -> the batched pass.
+constexpr int kXbSerialMax = 2;
+static_assert(kXbThreads == kExactThreads, "one block size for both passes");
+template <typename T, bool COS>
+__global__ __launch_bounds__(kXbThreads) void exact_pass_kernel(ExactBatchArgs b, ExactArgs s) {
+    const int nf = *b.nflag;
+    if (nf == 0) return;
+    if (nf <= kXbSerialMax) exact_topk_serial(s, nf);
+    else exact_topk_batch<T, COS>(b, nf);
 }
 
 }  // namespace mir

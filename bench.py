@@ -318,6 +318,8 @@ def variant_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher, kind)
            "exact_pass_queries": exact, "exact_pass_share": round(exact / (steps * B), 4),
            "queries_aimed_at_clusters_share": round(aimed / pool, 2),
            "ids_identical_to_cpu_oracle_on_2_queries": same, "oracle_s": round(t_oracle, 1)}
+    res["roofline_frac_streamed_bytes"] = round((n * ((d + 127) // 128 * 128) * 2 + (0 if args.metric == "inner_product" else 4 * n))
+                                                / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if stats:
         res["scan_stats"] = stats
     return res
@@ -776,6 +778,7 @@ def main():
         out = step(i)  # exactly the timed loop's body
     barrier()
     index.profile_read(reset=True)
+    index.scan_stats(reset=True)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -785,6 +788,7 @@ def main():
     flags_total = flags_all[n_warm:].sum(dtype=torch.int64).reshape(())
     index.profile(False)
     launches, scan_ms = index.profile_read(reset=True)
+    sieve_stats = index.scan_stats(reset=True)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -793,17 +797,20 @@ def main():
     elapsed = float(tmax.item())
     qps = B * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (scan), per launch ----
-    # algorithmic bytes per launch: shard rows * d * 4 (the bf16 hi+lo image is
-    # the same 4 B/element) + 4 B/row norm column (sqeuclid/cosine) + the query tile + its results.
-    # One pass of scan_topk_q16_kernel over the shard serves up to 128 queries (every batch size at d <= 384, k <= 52;
-    # the 32-query register-ring kernel only for other shapes).
+    # ---- roofline of the dominant kernel, per shard pass ----
+    # SURVEY.md 8(d)'s algorithmic bytes: shard rows * d * 4 + 4 B/row norm column (sqeuclid/cosine) + the query tile + its
+    # results.  Since round 3 a float32 shard of >= 32K rows at d <= 384 is searched by the sieve (csrc/vec_kernels_sieve.h),
+    # which streams only the bf16 hi blocks of the index image - HALF of those bytes: `achieved` / `frac` price the bytes
+    # the kernel actually moves (what the PMC counters see), `frac_survey_bytes` the survey's figure, side by side.
     n_loc = hi - lo
     aux = 0 if args.metric == "inner_product" else 4 * n_loc
     wide = d <= 384 and d > 64 and k <= 52
-    qpl = 128 if wide else 32
+    sieve = d <= 384 and d > 64 and k <= 64 and n_loc >= 32768 and os.environ.get("MIR_NO_SIEVE") is None
+    qpl = 128 if (wide or sieve) else 32
     q_launch = min(B, qpl)  # queries actually riding one launch
-    bytes_launch = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
+    survey_bytes = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
+    d_pad = (d + 127) // 128 * 128
+    bytes_launch = (n_loc * d_pad * 2 + aux + q_launch * d * 4 + q_launch * k * 12) if sieve else survey_bytes
     avg_ms = scan_ms / max(launches, 1)
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
     # HBM traffic per launch comes from PMC counters, which cannot be collected inside this run (rocprofv3 --pmc
@@ -813,9 +820,16 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("rows_per_launch") == n_loc and tj.get("dim") == d:
+        if tj.get("rows_per_launch") == n_loc and tj.get("dim") == d and bool(tj.get("sieve")) == sieve:
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run): " + str(tj.get("command", ""))
+    if sieve:
+        kernel_name = ("sieve_q16_kernel: two filter launches over the bf16 hi blocks (first 1/16 of the tiles, then the rest) with "
+                       "sieve_verify_kernel + sieve_select_kernel between them (the exact k-th best so far = the second launch's threshold)")
+    elif wide:
+        kernel_name = "scan_topk_q16_kernel (2 launches per shard + list_threshold_kernel)"
+    else:
+        kernel_name = "scan_topk_kernel"
 
     result = {
         "metric": "retrieval_qps_10Mx384",
@@ -828,7 +842,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32 (bf16x3 MFMA scan, f64 re-score)",
+        "dtype": "f32 (bf16 MFMA filter with a worst-case error margin, every candidate re-scored in f64 with the reference formula)",
         "data": "synthetic",
         "config": {
             "workload": f"brute-force top-k over {n}x{d} float32 unit-norm rows, {args.metric}, k={k}",
@@ -838,10 +852,10 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            # the full shard is streamed by TWO launches of the kernel (first 1/16 of the tiles, then the rest with the
-            # thresholds the first found, list_threshold_kernel in between); the HIP events bracket all three.  The
-            # 32K-row sample launch before them (13 us) is outside the bracket and inside `step_frac`.
-            "kernel": "scan_topk_q16_kernel (2 launches per shard + list_threshold_kernel)" if wide else "scan_topk_kernel",
+            # HIP events on the launch stream bracket the shard pass: both filter launches and what runs between them.  The
+            # 32K-row sample launch before them and the verify / select kernels after the second launch are outside the
+            # bracket and inside `step_frac`.
+            "kernel": kernel_name,
             "queries_per_launch": qpl,
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
@@ -850,11 +864,16 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_source,
             "bytes_per_launch": bytes_launch,
+            "bytes_per_launch_is": ("bytes the sieve streams: rows * d_pad * 2 (bf16 hi blocks) + norm column + queries + results" if sieve
+                                    else "SURVEY.md 8(d) algorithmic bytes"),
+            "survey_bytes_per_launch": survey_bytes,
+            "frac_survey_bytes": round(survey_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "avg_launch_ms": round(avg_ms, 4),
             "launches": launches,
-            # the same bytes over the whole step (prep, threshold pre-pass, scan, finalize, exact-pass gate, merge)
+            # the same bytes over the whole step (prep, threshold pre-pass, filter, verify, select, exact-pass gate, merge)
             "step_frac": round(bytes_launch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         },
+        "sieve": sieve_stats if sieve else None,  # candidates per query and filter launch, queries handed to the exact pass (rank 0's shard)
         "exact_pass_queries": int(flags_total.item()) // 2,  # queries the filter could not prove (flag bit 2), recomputed exactly
         "preconditioning_steps": precondition,
         **({"rehearsal_one_gpu": True} if rehearsal else {}),
@@ -885,7 +904,8 @@ def main():
             el = float(tm.item())
             a_ms = ms / max(ln, 1)
             sweep.append({"queries_per_step": Bs, "qps": round(Bs * 10 / el, 1), "ms_per_step": round(1e3 * el / 10, 4),
-                          "scan_launch_ms": round(a_ms, 4), "roofline_frac": round(bytes_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+                          "scan_launch_ms": round(a_ms, 4), "roofline_frac": round(bytes_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "frac_survey_bytes": round(survey_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         result["batch_sweep"] = sweep
     index.close()  # release the shard before the other legs allocate theirs
     if args.variants and world == 1:
