@@ -361,6 +361,26 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(Bm25Dev m, const int32_t
     }
 }
 
+// ---- routing between the two fast passes (bm25_wave_kernel below, one wave per (tile, query); this tile kernel for the
+// queries that do not fit it)
+constexpr int kWvPerLane = 12;
+constexpr int kWvPost = 64 * kWvPerLane;   // postings of a pair held in registers per round
+constexpr int kWvSlots = 768;              // distinct touched documents of a pair
+constexpr int kWvHeavy = 256;              // a query averaging more postings per tile than this goes to the tile kernel
+constexpr int kWvWaves = 4;                // waves per workgroup
+struct __align__(16) WaveLds {
+    double sc[kWvSlots];
+    uint32_t bm[kBm25Tile / 32];
+    uint16_t pre[kBm25Tile / 32];
+};
+
+// (whole wave; lanes = terms) sum of the document frequencies of the query's known terms vs the budget
+__device__ __forceinline__ bool query_is_heavy(int len, long long df_lane, int ntiles) {
+    long long s = df_lane;
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    return len > kBm25Chunk || s > (long long)kWvHeavy * ntiles;
+}
+
 // Fast pass.  grid = (ntiles, ceil(b / qc)), block = 256: a workgroup owns one tile and walks `qc`
 // queries through it, software-pipelined - while query q is accumulated and ranked in LDS, the
 // postings of q+1, the term metadata of q+2 and the term ids of q+3 are in flight, so the
@@ -382,6 +402,7 @@ __global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32
     __shared__ double tb_idf[2][kBm25Chunk];
     __shared__ int tb_off[2][kBm25Chunk + 1];
     __shared__ int tb_cnt[2];
+    __shared__ int tb_mine[2];  // the query is this kernel's (heavy); the others are bm25_wave_kernel's
     __shared__ int s_qptr[kBm25QcMax + 1];
     __shared__ uint32_t touched[kBm25Tile / 32];
     __shared__ uint16_t cand[kBm25Cand];
@@ -402,29 +423,38 @@ __global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32
     __syncthreads();
 
     // --- wave 0: one query term per lane -------------------------------------------------
-    int t_reg = -1;                       // term id (hop 1)
+    int t_reg = -1, t_len = 0;            // term id, query length (hop 1)
     bool m_ok = false;                    // metadata registers hold a real term (hop 2)
-    double r_idf = 0.0; uint32_t r_a = 0, r_b = 0; int64_t r_tp = 0;
+    int m_len = 0;
+    double r_idf = 0.0; uint32_t r_a = 0, r_b = 0; int64_t r_tp = 0; long long r_df = 0;
     auto load_term = [&](int qi) {
         t_reg = -1;
+        t_len = 0;
         if (tid < 64 && qi < nq) {
             const int qb = s_qptr[qi], len = s_qptr[qi + 1] - qb;
+            t_len = len;
             if (len <= kBm25Chunk && tid < len) t_reg = q_terms[qb + tid];  // longer queries: nothing here, dense pass
         }
     };
     auto load_meta = [&]() {
         m_ok = false;
+        m_len = t_len;
+        r_df = 0;
         if (tid < 64 && t_reg >= 0 && t_reg < m.vocab) {
             const uint32_t *to = m.t_tile + (size_t)t_reg * (m.ntiles + 1) + tile;
             r_idf = m.idf[t_reg];
             r_a = to[0];
             r_b = to[1];
             r_tp = m.t_ptr[t_reg];
+            r_df = m.t_ptr[t_reg + 1] - r_tp;
             m_ok = true;
         }
     };
     auto build_table = [&](int buf) {
         if (tid < 64) {
+            const bool mine = query_is_heavy(m_len, r_df, m.ntiles);  // (whole wave 0)
+            if (!mine) m_ok = false;                                   // a light query: an empty table, nothing emitted
+            if (tid == 0) tb_mine[buf] = mine ? 1 : 0;
             const int n = m_ok ? (int)(r_b - r_a) : 0;
             const bool valid = m_ok && r_idf != 0.0 && n > 0;
             const unsigned long long mask = __ballot(valid);
@@ -520,7 +550,11 @@ __global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32
         load_postings(cur ^ 1);
         load_meta();
         load_term(qi + 3);
-        // ---- top-k of query qi among the touched positives ----
+        // ---- top-k of query qi among the touched positives (a light query: the wave kernel's, nothing to do) ----
+        if (!tb_mine[cur]) {
+            __syncthreads();  // (everybody has read tb_mine[cur] before the next iteration's build_table rewrites it)
+            continue;
+        }
         const int q = q0 + qi;
         const size_t pb = ((size_t)q * m.ntiles + tile) * k;
         const int nc = ncand;
@@ -574,6 +608,221 @@ __global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fast pass at the right grain (round 3).  A (tile, query) pair of the SURVEY 8(d) workload touches ~143 postings on
+// average; a 256-thread workgroup with a barrier per query term was parked at s_barrier / s_waitcnt 70 % of its cycles
+// (profiles/r02_bm25_pmc.md).  Here ONE WAVE owns a pair and nothing in its way is a barrier:
+//   1. lanes = query terms: term id, then idf / posting range of the tile / document frequency, then a wave scan;
+//   2. the pair's postings into registers (up to 12 per lane), every load in flight at once;
+//   3. the touched documents as an 8192-bit map in LDS (atomic OR), popcount prefix per word: a document's SLOT is its
+//      rank among the touched documents - slots ascend with the document index, no hashing, no collisions;
+//   4. float64 scores per slot, the query's terms applied ONE AFTER THE OTHER in query order (a document occurs once per
+//      term, so a term's adds never meet; LDS operations of one wave execute in order): rank-bm25's own summation order,
+//      bit for bit;
+//   5. the positive slots' top k by k rounds of a wave arg-max on (score, slot) - the reference's (score, index) order.
+// Queries that do not fit (more than 64 terms, or more postings than kWvHeavy per tile on average) are left to
+// bm25_sparse_kernel, which skips all others; both use the same predicate (query_is_heavy).  A pair whose touched
+// documents outnumber the slots marks its query for the exact dense pass (count -1).
+__global__ __launch_bounds__(64 * kWvWaves) void bm25_wave_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms,
+                                                                  const int32_t *__restrict__ q_ptr, int b, int k,
+                                                                  double *__restrict__ part_score, int32_t *__restrict__ part_idx,
+                                                                  int32_t *__restrict__ part_cnt) {
+    __shared__ WaveLds lds[kWvWaves];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    WaveLds &L = lds[wave];
+    for (int i = lane; i < kBm25Tile / 32; i += 64) L.bm[i] = 0;
+    for (int i = lane; i < kWvSlots; i += 64) L.sc[i] = 0.0;
+    const long long npairs = (long long)b * m.ntiles;
+    const long long stride = (long long)gridDim.x * kWvWaves;
+    const double NEG = -__builtin_inf();
+    for (long long p = (long long)blockIdx.x * kWvWaves + wave; p < npairs; p += stride) {
+        const int q = (int)(p / m.ntiles), tile = (int)(p - (long long)q * m.ntiles);
+        const int base = tile * kBm25Tile;
+        const int qb = q_ptr[q], len = q_ptr[q + 1] - qb;
+        // ---- 1. lanes = terms
+        int t = -1;
+        if (lane < len && len <= kBm25Chunk) t = q_terms[qb + lane];
+        const bool known = t >= 0 && t < m.vocab;
+        double idf = 0.0;
+        int64_t lo = 0;
+        int n = 0;
+        long long df = 0;
+        if (known) {
+            const uint32_t *to = m.t_tile + (size_t)t * (m.ntiles + 1) + tile;
+            const int64_t tp = m.t_ptr[t];
+            df = m.t_ptr[t + 1] - tp;
+            idf = m.idf[t];
+            const uint32_t a = to[0], e = to[1];
+            lo = tp + a;
+            n = (int)(e - a);
+        }
+        if (query_is_heavy(len, df, m.ntiles)) continue;  // bm25_sparse_kernel's
+        const bool valid = known && idf != 0.0 && n > 0;   // `(self.idf.get(q) or 0)`: adds +-0
+        const unsigned long long vmask = __ballot(valid);
+        const int nt = __popcll(vmask);
+        const size_t pb = ((size_t)q * m.ntiles + tile) * k;
+        int32_t *my_cnt = part_cnt + (size_t)q * m.ntiles + tile;
+        if (nt == 0) {
+            if (lane == 0) *my_cnt = 0;
+            continue;
+        }
+        // compact the valid terms to lanes 0 .. nt-1, in query order (a forward permutation: valid lane -> its rank among the
+        // valid ones, the others behind them), with the exclusive prefix of their posting counts
+        const int pos = __popcll(vmask & ((1ull << lane) - 1ull));
+        int incl = valid ? n : 0;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __shfl(incl, 63, 64);
+        const int tgt = (valid ? pos : nt + (lane - pos)) * 4;
+        auto push = [&](int x) { return __builtin_amdgcn_ds_permute(tgt, x); };
+        const double c_idf = __hiloint2double(push(__double2hiint(idf)), push(__double2loint(idf)));
+        const int c_lo_hi = push((int)(lo >> 32)), c_lo_lo = push((int)(uint32_t)lo);
+        const int c_off = push(incl - (valid ? n : 0));  // lane j < nt: offset of term j's first posting among the pair's
+        // term of posting e_i = r0 + 64 i + lane: the last term whose offset is <= e_i.  Offsets come through v_readlane
+        // (u is wave-uniform), one compare per posting and term.
+        auto load_round = [&](int r0, bool want_w, int (&dl)[kWvPerLane], int (&tj)[kWvPerLane], double (&w)[kWvPerLane]) {
+#pragma unroll
+            for (int i = 0; i < kWvPerLane; ++i) tj[i] = 0;
+            for (int u = 1; u < nt; ++u) {
+                const int off_u = __builtin_amdgcn_readlane(c_off, u);
+#pragma unroll
+                for (int i = 0; i < kWvPerLane; ++i) tj[i] += (r0 + i * 64 + lane >= off_u) ? 1 : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < kWvPerLane; ++i) {
+                const int e = r0 + i * 64 + lane;
+                const int j = tj[i];
+                const int64_t lo_j = ((int64_t)__shfl(c_lo_hi, j, 64) << 32) | (uint32_t)__shfl(c_lo_lo, j, 64);
+                const int off_j = __shfl(c_off, j, 64);
+                dl[i] = 0; w[i] = 0.0;
+                if (e < total) {
+                    const int64_t pp = lo_j + (e - off_j);
+                    dl[i] = m.p_doc[pp] - base;
+                    if (want_w) w[i] = m.p_w[pp];
+                } else {
+                    tj[i] = -1;
+                }
+            }
+        };
+        int dl[kWvPerLane], tj[kWvPerLane];
+        double w[kWvPerLane];
+        const bool one_round = total <= kWvPost;  // (nearly always: the postings stay in registers for both phases)
+        // ---- 2./3. the touched documents
+        for (int r0 = 0; r0 < total; r0 += kWvPost) {
+            load_round(r0, one_round, dl, tj, w);
+#pragma unroll
+            for (int i = 0; i < kWvPerLane; ++i)
+                if (tj[i] >= 0) atomicOr(&L.bm[dl[i] >> 5], 1u << (dl[i] & 31));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations execute in order; this pins the compiler's)
+        // slots: popcount prefix over the 256 map words (4 per lane)
+        int ndist;
+        {
+            uint32_t w4[4];
+            int c = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { w4[u] = L.bm[4 * lane + u]; c += __popc(w4[u]); }
+            int inc = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            ndist = __shfl(inc, 63, 64);
+            int run = inc - c;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { L.pre[4 * lane + u] = (uint16_t)run; run += __popc(w4[u]); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ndist > kWvSlots) {  // (skewed tile: more touched documents than slots) -> the exact dense pass takes the query
+            if (lane == 0) *my_cnt = -1;  // bm25_merge_kernel: a negative count hands the query to the dense pass
+            for (int i = lane; i < kBm25Tile / 32; i += 64) L.bm[i] = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
+        // ---- 4. scores: terms in query order
+        for (int r0 = 0; r0 < total; r0 += kWvPost) {
+            if (!one_round) load_round(r0, true, dl, tj, w);
+            const int jmin = __builtin_amdgcn_readfirstlane(tj[0]);  // lane 0's first posting of the round: the round's first term
+            int jmx = -1;
+#pragma unroll
+            for (int i = 0; i < kWvPerLane; ++i) jmx = tj[i] > jmx ? tj[i] : jmx;
+            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(jmx, off, 64); jmx = o > jmx ? o : jmx; }
+            for (int j = jmin; j <= jmx; ++j) {
+                const double idf_j = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c_idf), j), __builtin_amdgcn_readlane(__double2loint(c_idf), j));
+#pragma unroll
+                for (int i = 0; i < kWvPerLane; ++i) {
+                    if (tj[i] == j) {
+                        const int wd = dl[i] >> 5;
+                        const int slot = (int)L.pre[wd] + __popc(L.bm[wd] & ((1u << (dl[i] & 31)) - 1u));
+                        L.sc[slot] = L.sc[slot] + idf_j * w[i];  // product rounded, then the sum: rank-bm25's order
+                    }
+                }
+                asm volatile("" ::: "memory");  // term j's adds are issued before term j + 1 reads the same slots
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- 5. top k of the positive slots: (score desc, slot desc) = (score desc, index desc)
+        double v[kWvPerLane];
+        double bs = NEG;
+        int bi = -1;
+#pragma unroll
+        for (int i = 0; i < kWvPerLane; ++i) {
+            const int sl = i * 64 + lane;
+            double x = NEG;
+            if (sl < ndist) { const double y = L.sc[sl]; x = y > 0.0 ? y : NEG; }
+            v[i] = x;
+            if (x != NEG && (bi < 0 || x > bs || (x == bs && sl > bi))) { bs = x; bi = sl; }
+        }
+        int got = 0;
+        for (int r = 0; r < k; ++r) {
+            double ws = bs;
+            int wi = bi;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double os = __shfl_xor(ws, off, 64);
+                const int oi = __shfl_xor(wi, off, 64);
+                if (oi >= 0 && (wi < 0 || os > ws || (os == ws && oi > wi))) { ws = os; wi = oi; }
+            }
+            if (wi < 0) break;  // fewer positives than k (uniform)
+            // the winner's document: the (wi - pre[w])-th set bit of its map word; its owner lane = wi & 63
+            {
+                // word of slot wi: each lane looks at its 4 words
+                int hit = -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int wd = 4 * lane + u;
+                    const int p0 = L.pre[wd], c = __popc(L.bm[wd]);
+                    if (wi >= p0 && wi < p0 + c) hit = wd;
+                }
+                if (hit >= 0) {
+                    uint32_t bits = L.bm[hit];
+                    for (int s2 = wi - (int)L.pre[hit]; s2 > 0; --s2) bits &= bits - 1;
+                    part_score[pb + r] = ws;
+                    part_idx[pb + r] = base + hit * 32 + __builtin_ctz(bits);
+                }
+            }
+            ++got;
+            if ((wi & 63) == lane) {  // consume it and rescan my own values
+                const int mine = wi >> 6;
+                bs = NEG; bi = -1;
+#pragma unroll
+                for (int i = 0; i < kWvPerLane; ++i) {
+                    if (i == mine) v[i] = NEG;
+                    const int sl = i * 64 + lane;
+                    if (v[i] != NEG && (bi < 0 || v[i] > bs || (v[i] == bs && sl > bi))) { bs = v[i]; bi = sl; }
+                }
+            }
+        }
+        if (lane == 0) *my_cnt = got;
+        // ---- reset what the pair touched
+        for (int i = lane; i < ndist; i += 64) L.sc[i] = 0.0;
+        for (int i = lane; i < kBm25Tile / 32; i += 64) L.bm[i] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // grid = b, block = 256: merge the tiles' candidates of one query.
 // mode 0: merge the sparse pass and flag the queries that came up short (need_dense[q] = 1);
 // mode 1: merge the dense pass, for the flagged queries only.
@@ -597,13 +846,15 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(double *__restrict__ pa
     const int32_t *pc = part_cnt + (size_t)q * ntiles;
     const double NEG = -__builtin_inf();
     int mine = 0;
+    bool overflow = false;  // (mode 0) a tile whose touched documents outnumbered the wave kernel's slots: count -1
     for (int e = tid; e < ntiles * k; e += 256) {
         const int tile = e / k, p = e - tile * k;
+        if (pc[tile] < 0) overflow = true;
         if (p >= pc[tile]) ps[e] = NEG; else ++mine;
     }
     for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
     if ((tid & 63) == 0) red_p[tid >> 6] = mine;
-    __syncthreads();
+    const int any_overflow = __syncthreads_or(overflow ? 1 : 0);
     if (tid == 0) s_total = red_p[0] + red_p[1] + red_p[2] + red_p[3];
     __syncthreads();
     const int kout = k < s_total ? k : s_total;
@@ -623,7 +874,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(double *__restrict__ pa
         L);
     if (tid == 0) {
         out_count[q] = kout;
-        if (mode == 0) need_dense[q] = (kout < k && (int64_t)kout < n_docs) ? 1 : 0;
+        if (mode == 0) need_dense[q] = ((kout < k && (int64_t)kout < n_docs) || any_overflow) ? 1 : 0;
     }
 }
 
@@ -633,6 +884,7 @@ using namespace mir;
 
 struct mir_bm25 {
     int device = 0;
+    int num_cus = 256;
     int64_t n_docs = 0;
     int vocab = 0;
     int64_t n_postings = 0;
@@ -749,11 +1001,13 @@ int32_t mir_bm25_create(const int64_t *indptr, const int32_t *term_ids, int64_t 
     MIR_REQUIRE(total == 0 || term_ids != nullptr, "term_ids is NULL");
     for (int64_t i = 0; i < n_docs; ++i)
         MIR_REQUIRE(indptr[i + 1] >= indptr[i], "indptr is not monotone at %lld", (long long)i);
-    int32_t rc = use_device(device, nullptr);
+    int cus = 0;
+    int32_t rc = use_device(device, &cus);
     if (rc != MIR_OK) return rc;
 
     mir_bm25 *h = new (std::nothrow) mir_bm25();
     MIR_REQUIRE(h != nullptr, "out of host memory");
+    h->num_cus = cus;
     h->device = device; h->n_docs = n_docs; h->vocab = vocab; h->doc_offset = doc_offset;
     h->avgdl = idf_override ? avgdl_override : (double)total / (double)n_docs;
 
@@ -910,6 +1164,12 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     int qc = (int)((int64_t)b * T / 2048);
     qc = qc < 1 ? 1 : (qc > kBm25QcMax ? kBm25QcMax : qc);
     if (h->qc_pin > 0) qc = h->qc_pin;  // tests pin the pipeline depth (short pipelines x long query queues)
+    {   // one wave per (tile, query) for the queries that fit it; the tile kernel below takes the others
+        const long long npairs = (long long)b * T;
+        const int wgs = (int)std::max<long long>(1, std::min<long long>((npairs + kWvWaves - 1) / kWvWaves, (long long)h->num_cus * 5));
+        bm25_wave_kernel<<<dim3(wgs), dim3(64 * kWvWaves), 0, s>>>(dev_view(h), d_terms, d_ptr, b, k, part_score, part_idx, part_cnt);
+        MIR_HIP(hipGetLastError());
+    }
     bm25_sparse_kernel<<<dim3(T, (b + qc - 1) / qc), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, b, qc, k, part_score,
                                                                         part_idx, part_cnt);
     MIR_HIP(hipGetLastError());
