@@ -363,22 +363,80 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(Bm25Dev m, const int32_t
 
 // ---- routing between the two fast passes (bm25_wave_kernel below, one wave per (tile, query); this tile kernel for the
 // queries that do not fit it)
-constexpr int kWvPerLane = 12;
-constexpr int kWvPost = 64 * kWvPerLane;   // postings of a pair held in registers per round
-constexpr int kWvSlots = 768;              // distinct touched documents of a pair
-constexpr int kWvHeavy = 256;              // a query averaging more postings per tile than this goes to the tile kernel
+constexpr int kWvSlots = 768;              // distinct touched documents of a (tile, query) pair
+constexpr int kWvHeavy = 512;              // a query averaging more postings per tile than this goes to the tile kernel
 constexpr int kWvWaves = 4;                // waves per workgroup
+constexpr int kWvCountStride = 32;         // a query's candidate counter has a 128-byte line of its own
 struct __align__(16) WaveLds {
     double sc[kWvSlots];
     uint32_t bm[kBm25Tile / 32];
     uint16_t pre[kBm25Tile / 32];
 };
+// the light queries' candidates (every touched document with its score, all tiles): a query's postings bound them, so
+// bm25_plan_kernel gives each light query exactly that many entries of one pool - and calls a query heavy once the pool is full
+struct WavePool {
+    double *score;     // [capacity]
+    int32_t *doc;      // [capacity] local document index
+    uint32_t *count;   // [b][kWvCountStride] candidates written so far (bit 31: a tile overflowed its slots)
+    int32_t *light;    // [b] 1: the query is the wave kernel's
+    uint32_t *off;     // [b] its first pool entry
+    int32_t *hlist;    // [b] the heavy queries, for bm25_sparse_kernel; hlist[b] = their number
+    long long capacity;
+};
+__host__ __device__ inline long long wave_pool_capacity(int b, int ntiles) {
+    const long long one = (long long)kWvHeavy * ntiles;  // the largest light query
+    const long long per = one < 16384 ? one : 16384;
+    const long long c = (long long)b * per;
+    return c > one ? c : one;
+}
 
-// (whole wave; lanes = terms) sum of the document frequencies of the query's known terms vs the budget
-__device__ __forceinline__ bool query_is_heavy(int len, long long df_lane, int ntiles) {
-    long long s = df_lane;
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    return len > kBm25Chunk || s > (long long)kWvHeavy * ntiles;
+// One block of 1024 threads: which queries are light (at most 64 terms, at most kWvHeavy postings per tile on average, and
+// room left in the candidate pool - in query order), where their candidates go, and their counters zeroed.
+__global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms, const int32_t *__restrict__ q_ptr,
+                                                         int b, WavePool pool) {
+    __shared__ long long s_scan[1024];
+    __shared__ long long s_base;
+    __shared__ int s_nheavy;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_base = 0; s_nheavy = 0; }
+    __syncthreads();
+    for (int q0 = 0; q0 < b; q0 += 1024) {
+        const int q = q0 + tid;
+        long long need = 0;
+        bool fits = false;
+        if (q < b) {
+            const int qb = q_ptr[q], len = q_ptr[q + 1] - qb;
+            if (len <= kBm25Chunk) {
+                long long sdf = 0;
+                for (int j = 0; j < len; ++j) {
+                    const int t = q_terms[qb + j];
+                    if (t >= 0 && t < m.vocab) sdf += m.t_ptr[t + 1] - m.t_ptr[t];
+                }
+                if (sdf <= (long long)kWvHeavy * m.ntiles) { need = sdf; fits = true; }
+            }
+        }
+        // inclusive scan of `need` over the 1024 queries of this round
+        s_scan[tid] = need;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const long long o = tid >= off ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += o;
+            __syncthreads();
+        }
+        const long long at = s_base + s_scan[tid] - need;
+        const bool light = fits && at + need <= pool.capacity;  // (a query that does not fit leaves a hole: harmless)
+        if (q < b) {
+            pool.light[q] = light ? 1 : 0;
+            pool.off[q] = light ? (uint32_t)at : 0u;
+            pool.count[(size_t)q * kWvCountStride] = 0;
+            if (!light) pool.hlist[atomicAdd(&s_nheavy, 1)] = q;  // (any order: a heavy query's tiles are merged by bm25_merge_kernel)
+        }
+        __syncthreads();
+        if (tid == 1023) s_base += s_scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) pool.hlist[b] = s_nheavy;
 }
 
 // Fast pass.  grid = (ntiles, ceil(b / qc)), block = 256: a workgroup owns one tile and walks `qc`
@@ -391,6 +449,7 @@ constexpr int kBm25QcMax = 64;
 
 __global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms,
                                                           const int32_t *__restrict__ q_ptr, int b, int qc, int k,
+                                                          const int32_t *__restrict__ hlist,
                                                           double *__restrict__ part_score,
                                                           int32_t *__restrict__ part_idx,
                                                           int32_t *__restrict__ part_cnt) {
@@ -403,7 +462,7 @@ __global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32
     __shared__ int tb_off[2][kBm25Chunk + 1];
     __shared__ int tb_cnt[2];
     __shared__ int tb_mine[2];  // the query is this kernel's (heavy); the others are bm25_wave_kernel's
-    __shared__ int s_qptr[kBm25QcMax + 1];
+    __shared__ int s_qptr[kBm25QcMax + 1], s_qlen[kBm25QcMax], s_qid[kBm25QcMax];
     __shared__ uint32_t touched[kBm25Tile / 32];
     __shared__ uint16_t cand[kBm25Cand];
     __shared__ int ncand;
@@ -411,50 +470,54 @@ __global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32
     __shared__ int s_cnt;
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
+    // this workgroup walks heavy queries hlist[q0 .. q0 + nq) (bm25_plan_kernel; the light ones are bm25_wave_kernel's)
+    const int nheavy = hlist[b];
     const int q0 = blockIdx.y * qc;
-    const int nq = (b - q0) < qc ? (b - q0) : qc;
+    if (q0 >= nheavy) return;
+    const int nq = (nheavy - q0) < qc ? (nheavy - q0) : qc;
     const int base = tile * kBm25Tile;
     const int cnt = (int)((m.n_docs - base) < kBm25Tile ? (m.n_docs - base) : kBm25Tile);
     const double NEG = -__builtin_inf();
     for (int i = tid; i < kBm25Tile; i += 256) sc[i] = 0.0;
     touched[tid] = 0;
     if (tid == 0) ncand = 0;
-    if (tid <= nq) s_qptr[tid] = q_ptr[q0 + tid];
+    if (tid < nq) {
+        const int qid = hlist[q0 + tid];
+        s_qid[tid] = qid;
+        s_qptr[tid] = q_ptr[qid];
+        s_qlen[tid] = q_ptr[qid + 1] - q_ptr[qid];
+    }
     __syncthreads();
 
     // --- wave 0: one query term per lane -------------------------------------------------
     int t_reg = -1, t_len = 0;            // term id, query length (hop 1)
     bool m_ok = false;                    // metadata registers hold a real term (hop 2)
     int m_len = 0;
-    double r_idf = 0.0; uint32_t r_a = 0, r_b = 0; int64_t r_tp = 0; long long r_df = 0;
+    double r_idf = 0.0; uint32_t r_a = 0, r_b = 0; int64_t r_tp = 0;
     auto load_term = [&](int qi) {
         t_reg = -1;
-        t_len = 0;
+        t_len = 0;  // (1 = the query is this kernel's)
         if (tid < 64 && qi < nq) {
-            const int qb = s_qptr[qi], len = s_qptr[qi + 1] - qb;
-            t_len = len;
+            const int qb = s_qptr[qi], len = s_qlen[qi];
+            t_len = 1;
             if (len <= kBm25Chunk && tid < len) t_reg = q_terms[qb + tid];  // longer queries: nothing here, dense pass
         }
     };
     auto load_meta = [&]() {
         m_ok = false;
         m_len = t_len;
-        r_df = 0;
         if (tid < 64 && t_reg >= 0 && t_reg < m.vocab) {
             const uint32_t *to = m.t_tile + (size_t)t_reg * (m.ntiles + 1) + tile;
             r_idf = m.idf[t_reg];
             r_a = to[0];
             r_b = to[1];
             r_tp = m.t_ptr[t_reg];
-            r_df = m.t_ptr[t_reg + 1] - r_tp;
             m_ok = true;
         }
     };
     auto build_table = [&](int buf) {
         if (tid < 64) {
-            const bool mine = query_is_heavy(m_len, r_df, m.ntiles);  // (whole wave 0)
-            if (!mine) m_ok = false;                                   // a light query: an empty table, nothing emitted
-            if (tid == 0) tb_mine[buf] = mine ? 1 : 0;
+            if (tid == 0) tb_mine[buf] = m_len;
             const int n = m_ok ? (int)(r_b - r_a) : 0;
             const bool valid = m_ok && r_idf != 0.0 && n > 0;
             const unsigned long long mask = __ballot(valid);
@@ -555,7 +618,7 @@ __global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32
             __syncthreads();  // (everybody has read tb_mine[cur] before the next iteration's build_table rewrites it)
             continue;
         }
-        const int q = q0 + qi;
+        const int q = s_qid[qi];
         const size_t pb = ((size_t)q * m.ntiles + tile) * k;
         const int nc = ncand;
         auto emit = [&](int r, double v, int64_t i) {
@@ -609,33 +672,147 @@ __global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Fast pass at the right grain (round 3).  A (tile, query) pair of the SURVEY 8(d) workload touches ~143 postings on
-// average; a 256-thread workgroup with a barrier per query term was parked at s_barrier / s_waitcnt 70 % of its cycles
-// (profiles/r02_bm25_pmc.md).  Here ONE WAVE owns a pair and nothing in its way is a barrier:
+// Fast pass at the right grain (round 3).  A (tile, query) pair of the SURVEY 8(d) workload touches 53 postings at the
+// median and 143 on average; a 256-thread workgroup with a barrier per query term was parked at s_barrier / s_waitcnt
+// 70 % of its cycles (profiles/r02_bm25_pmc.md).  Here ONE WAVE owns a pair and nothing in its way is a barrier:
 //   1. lanes = query terms: term id, then idf / posting range of the tile / document frequency, then a wave scan;
-//   2. the pair's postings into registers (up to 12 per lane), every load in flight at once;
+//   2. the pair's postings into registers (PL per lane: 2 for the small pairs, 12 otherwise), every load in flight at once;
 //   3. the touched documents as an 8192-bit map in LDS (atomic OR), popcount prefix per word: a document's SLOT is its
 //      rank among the touched documents - slots ascend with the document index, no hashing, no collisions;
 //   4. float64 scores per slot, the query's terms applied ONE AFTER THE OTHER in query order (a document occurs once per
 //      term, so a term's adds never meet; LDS operations of one wave execute in order): rank-bm25's own summation order,
 //      bit for bit;
-//   5. the positive slots' top k by k rounds of a wave arg-max on (score, slot) - the reference's (score, index) order.
+//   5. every touched document with its score goes to the QUERY's candidate array (one atomic per pair reserves the
+//      range); bm25_select_kernel then takes the query's top k over all tiles at once.  (A top-k per pair - ten wave
+//      arg-max rounds - was two thirds of a pair's instructions, repeated 123 times per query.)
 // Queries that do not fit (more than 64 terms, or more postings than kWvHeavy per tile on average) are left to
-// bm25_sparse_kernel, which skips all others; both use the same predicate (query_is_heavy).  A pair whose touched
-// documents outnumber the slots marks its query for the exact dense pass (count -1).
+// bm25_sparse_kernel + bm25_merge_kernel, which skip all others (bm25_plan_kernel decides).  A pair
+// whose touched documents outnumber the slots marks its query for the exact dense pass (its count word gets bit 31).
+template <int PL>
+__device__ __forceinline__ void wave_pair(const Bm25Dev &m, WaveLds &L, int lane, int nt, int total, int base, double c_idf, int c_lo_hi,
+                                          int c_lo_lo, int c_off, const WavePool &pool, int q) {
+    // term of posting e_i = r0 + 64 i + lane: the last term whose offset is <= e_i.  Offsets come through v_readlane
+    // (u is wave-uniform), one compare per posting and term.
+    int dl[PL], tj[PL];
+    double w[PL];
+    auto load_round = [&](int r0, bool want_w) {
+#pragma unroll
+        for (int i = 0; i < PL; ++i) tj[i] = 0;
+        for (int u = 1; u < nt; ++u) {
+            const int off_u = __builtin_amdgcn_readlane(c_off, u);
+#pragma unroll
+            for (int i = 0; i < PL; ++i) tj[i] += (r0 + i * 64 + lane >= off_u) ? 1 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            const int e = r0 + i * 64 + lane;
+            const int j = tj[i];
+            const int64_t lo_j = ((int64_t)__shfl(c_lo_hi, j, 64) << 32) | (uint32_t)__shfl(c_lo_lo, j, 64);
+            const int off_j = __shfl(c_off, j, 64);
+            dl[i] = 0; w[i] = 0.0;
+            if (e < total) {
+                const int64_t pp = lo_j + (e - off_j);
+                dl[i] = m.p_doc[pp] - base;
+                if (want_w) w[i] = m.p_w[pp];
+            } else {
+                tj[i] = -1;
+            }
+        }
+    };
+    const bool one_round = total <= 64 * PL;  // (nearly always: the postings stay in registers for both phases)
+    // ---- 2./3. the touched documents
+    for (int r0 = 0; r0 < total; r0 += 64 * PL) {
+        load_round(r0, one_round);
+#pragma unroll
+        for (int i = 0; i < PL; ++i)
+            if (tj[i] >= 0) atomicOr(&L.bm[dl[i] >> 5], 1u << (dl[i] & 31));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations execute in order; this pins the compiler's)
+    // slots: popcount prefix over the 256 map words (4 per lane)
+    uint32_t w4[4];
+    int ndist, run0;
+    {
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { w4[u] = L.bm[4 * lane + u]; c += __popc(w4[u]); }
+        int inc = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        ndist = __shfl(inc, 63, 64);
+        run0 = inc - c;
+        int run = run0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { L.pre[4 * lane + u] = (uint16_t)run; run += __popc(w4[u]); }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t *cnt = pool.count + (size_t)q * kWvCountStride;
+    if (ndist > kWvSlots) {  // (skewed tile: more touched documents than slots) -> the exact dense pass takes the query
+        if (lane == 0) atomicOr(cnt, 0x80000000u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) L.bm[4 * lane + u] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return;
+    }
+    // ---- 4. scores: terms in query order
+    for (int r0 = 0; r0 < total; r0 += 64 * PL) {
+        if (!one_round) load_round(r0, true);
+        const int jmin = __builtin_amdgcn_readfirstlane(tj[0]);  // lane 0's first posting of the round: the round's first term
+        int jmx = -1;
+#pragma unroll
+        for (int i = 0; i < PL; ++i) jmx = tj[i] > jmx ? tj[i] : jmx;
+        for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(jmx, off, 64); jmx = o > jmx ? o : jmx; }
+        for (int j = jmin; j <= jmx; ++j) {
+            const double idf_j = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c_idf), j), __builtin_amdgcn_readlane(__double2loint(c_idf), j));
+#pragma unroll
+            for (int i = 0; i < PL; ++i) {
+                if (tj[i] == j) {
+                    const int wd = dl[i] >> 5;
+                    const int slot = (int)L.pre[wd] + __popc(L.bm[wd] & ((1u << (dl[i] & 31)) - 1u));
+                    L.sc[slot] = L.sc[slot] + idf_j * w[i];  // product rounded, then the sum: rank-bm25's order
+                }
+            }
+            asm volatile("" ::: "memory");  // term j's adds are issued before term j + 1 reads the same slots
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- 5. every touched document and its score -> the query's candidates (slot order = document order)
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(cnt, (uint32_t)ndist) & 0x7fffffffu;
+    at = __builtin_amdgcn_readfirstlane(at);
+    double *cs = pool.score + (size_t)pool.off[q] + at;
+    int32_t *cd = pool.doc + (size_t)pool.off[q] + at;
+    {
+        int slot = run0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t bits = w4[u];
+            while (bits) {
+                const int bit = __builtin_ctz(bits);
+                bits &= bits - 1;
+                cs[slot] = L.sc[slot];
+                cd[slot] = base + (4 * lane + u) * 32 + bit;
+                L.sc[slot] = 0.0;  // (reset as we go)
+                ++slot;
+            }
+            L.bm[4 * lane + u] = 0;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 __global__ __launch_bounds__(64 * kWvWaves) void bm25_wave_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms,
-                                                                  const int32_t *__restrict__ q_ptr, int b, int k,
-                                                                  double *__restrict__ part_score, int32_t *__restrict__ part_idx,
-                                                                  int32_t *__restrict__ part_cnt) {
+                                                                  const int32_t *__restrict__ q_ptr, int b, WavePool pool) {
     __shared__ WaveLds lds[kWvWaves];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     WaveLds &L = lds[wave];
     for (int i = lane; i < kBm25Tile / 32; i += 64) L.bm[i] = 0;
     for (int i = lane; i < kWvSlots; i += 64) L.sc[i] = 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const long long npairs = (long long)b * m.ntiles;
     const long long stride = (long long)gridDim.x * kWvWaves;
-    const double NEG = -__builtin_inf();
     for (long long p = (long long)blockIdx.x * kWvWaves + wave; p < npairs; p += stride) {
         const int q = (int)(p / m.ntiles), tile = (int)(p - (long long)q * m.ntiles);
         const int base = tile * kBm25Tile;
@@ -647,26 +824,19 @@ __global__ __launch_bounds__(64 * kWvWaves) void bm25_wave_kernel(Bm25Dev m, con
         double idf = 0.0;
         int64_t lo = 0;
         int n = 0;
-        long long df = 0;
         if (known) {
             const uint32_t *to = m.t_tile + (size_t)t * (m.ntiles + 1) + tile;
             const int64_t tp = m.t_ptr[t];
-            df = m.t_ptr[t + 1] - tp;
             idf = m.idf[t];
             const uint32_t a = to[0], e = to[1];
             lo = tp + a;
             n = (int)(e - a);
         }
-        if (query_is_heavy(len, df, m.ntiles)) continue;  // bm25_sparse_kernel's
+        if (!pool.light[q]) continue;  // bm25_sparse_kernel's (bm25_plan_kernel decided)
         const bool valid = known && idf != 0.0 && n > 0;   // `(self.idf.get(q) or 0)`: adds +-0
         const unsigned long long vmask = __ballot(valid);
         const int nt = __popcll(vmask);
-        const size_t pb = ((size_t)q * m.ntiles + tile) * k;
-        int32_t *my_cnt = part_cnt + (size_t)q * m.ntiles + tile;
-        if (nt == 0) {
-            if (lane == 0) *my_cnt = 0;
-            continue;
-        }
+        if (nt == 0) continue;
         // compact the valid terms to lanes 0 .. nt-1, in query order (a forward permutation: valid lane -> its rank among the
         // valid ones, the others behind them), with the exclusive prefix of their posting counts
         const int pos = __popcll(vmask & ((1ull << lane) - 1ull));
@@ -681,145 +851,116 @@ __global__ __launch_bounds__(64 * kWvWaves) void bm25_wave_kernel(Bm25Dev m, con
         const double c_idf = __hiloint2double(push(__double2hiint(idf)), push(__double2loint(idf)));
         const int c_lo_hi = push((int)(lo >> 32)), c_lo_lo = push((int)(uint32_t)lo);
         const int c_off = push(incl - (valid ? n : 0));  // lane j < nt: offset of term j's first posting among the pair's
-        // term of posting e_i = r0 + 64 i + lane: the last term whose offset is <= e_i.  Offsets come through v_readlane
-        // (u is wave-uniform), one compare per posting and term.
-        auto load_round = [&](int r0, bool want_w, int (&dl)[kWvPerLane], int (&tj)[kWvPerLane], double (&w)[kWvPerLane]) {
+        if (total <= 128) wave_pair<2>(m, L, lane, nt, total, base, c_idf, c_lo_hi, c_lo_lo, c_off, pool, q);
+        else wave_pair<12>(m, L, lane, nt, total, base, c_idf, c_lo_hi, c_lo_lo, c_off, pool, q);
+    }
+}
+
+constexpr int kSelList = 2048;
+// grid = b, block = 256: a light query's top k over the candidates of all its tiles (bm25_wave_kernel); flags it for the
+// dense pass when fewer than k documents are positive or a tile overflowed.  Heavy queries: bm25_merge_kernel's.
+__global__ __launch_bounds__(256) void bm25_select_kernel(WavePool pool, int k, int64_t doc_offset, int64_t n_docs,
+                                                          int32_t *__restrict__ need_dense, int64_t *__restrict__ out_idx,
+                                                          double *__restrict__ out_score, int32_t *__restrict__ out_count) {
+    __shared__ double red_s[4];
+    __shared__ int64_t red_i[4];
+    __shared__ int red_p[4];
+    __shared__ int s_cnt, s_m;
+    __shared__ float s_thr;
+    __shared__ __attribute__((aligned(16))) float s_key[1024];
+    __shared__ double l_s[kSelList];
+    __shared__ int l_i[kSelList];
+    __shared__ TopkLds L;
+    const int tid = threadIdx.x, q = blockIdx.x;
+    if (!pool.light[q]) return;
+    const uint32_t word = pool.count[(size_t)q * kWvCountStride];
+    const bool overflow = (word >> 31) != 0;
+    const int n = (int)(word & 0x7fffffffu);
+    double *cs = pool.score + (size_t)pool.off[q];
+    const int32_t *cd = pool.doc + (size_t)pool.off[q];
+    const double NEG = -__builtin_inf();
+    auto emit = [&](int r, double sc, int64_t i) {
+        out_score[(size_t)q * k + r] = sc;
+        out_idx[(size_t)q * k + r] = doc_offset + i;
+    };
+    auto pos = [&](int i) { const double v = cs[i]; return v > 0.0 ? v : NEG; };
+    auto whole = [&]() {  // block_topk over all n candidates: one dependent load per thread and 256 candidates
+        return block_topk(
+            n, k, tid, pos, [&](int i) { return (int64_t)cd[i]; }, emit,
+            [&]() {
+                if (tid == 0) s_cnt = 0;
+                block_select(
+                    n, k < n ? k : n, tid, pos, [&](int i) { return (int64_t)cd[i]; }, [&](int i) { cs[i] = NEG; },
+                    [&](int r, double v, int64_t i) { emit(r, v, i); s_cnt = r + 1; }, red_s, red_i, red_p);
+                __syncthreads();
+                return s_cnt;
+            },
+            L);
+    };
+    int got;
+    if (n <= 1024) {
+        got = whole();
+    } else {
+        // more than a thousand candidates: first cut them down with EIGHT loads in flight per thread.  The k-th best float key
+        // of 1024 candidates sampled across the array bounds the answer from below (~k n / 1024 candidates reach it); those go
+        // to an LDS list, and block_topk runs on the list
+        float key4[4];
 #pragma unroll
-            for (int i = 0; i < kWvPerLane; ++i) tj[i] = 0;
-            for (int u = 1; u < nt; ++u) {
-                const int off_u = __builtin_amdgcn_readlane(c_off, u);
-#pragma unroll
-                for (int i = 0; i < kWvPerLane; ++i) tj[i] += (r0 + i * 64 + lane >= off_u) ? 1 : 0;
-            }
-#pragma unroll
-            for (int i = 0; i < kWvPerLane; ++i) {
-                const int e = r0 + i * 64 + lane;
-                const int j = tj[i];
-                const int64_t lo_j = ((int64_t)__shfl(c_lo_hi, j, 64) << 32) | (uint32_t)__shfl(c_lo_lo, j, 64);
-                const int off_j = __shfl(c_off, j, 64);
-                dl[i] = 0; w[i] = 0.0;
-                if (e < total) {
-                    const int64_t pp = lo_j + (e - off_j);
-                    dl[i] = m.p_doc[pp] - base;
-                    if (want_w) w[i] = m.p_w[pp];
-                } else {
-                    tj[i] = -1;
-                }
-            }
-        };
-        int dl[kWvPerLane], tj[kWvPerLane];
-        double w[kWvPerLane];
-        const bool one_round = total <= kWvPost;  // (nearly always: the postings stay in registers for both phases)
-        // ---- 2./3. the touched documents
-        for (int r0 = 0; r0 < total; r0 += kWvPost) {
-            load_round(r0, one_round, dl, tj, w);
-#pragma unroll
-            for (int i = 0; i < kWvPerLane; ++i)
-                if (tj[i] >= 0) atomicOr(&L.bm[dl[i] >> 5], 1u << (dl[i] & 31));
+        for (int u = 0; u < 4; ++u) {
+            const int i = (int)(((long long)(tid + 256 * u) * n) >> 10);
+            key4[u] = (float)pos(i);
+            s_key[tid + 256 * u] = key4[u];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations execute in order; this pins the compiler's)
-        // slots: popcount prefix over the 256 map words (4 per lane)
-        int ndist;
-        {
-            uint32_t w4[4];
-            int c = 0;
+        if (tid == 0) { s_thr = -__builtin_inff(); s_m = 0; }
+        __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { w4[u] = L.bm[4 * lane + u]; c += __popc(w4[u]); }
-            int inc = c;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += o;
-            }
-            ndist = __shfl(inc, 63, 64);
-            int run = inc - c;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { L.pre[4 * lane + u] = (uint16_t)run; run += __popc(w4[u]); }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (ndist > kWvSlots) {  // (skewed tile: more touched documents than slots) -> the exact dense pass takes the query
-            if (lane == 0) *my_cnt = -1;  // bm25_merge_kernel: a negative count hands the query to the dense pass
-            for (int i = lane; i < kBm25Tile / 32; i += 64) L.bm[i] = 0;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            continue;
-        }
-        // ---- 4. scores: terms in query order
-        for (int r0 = 0; r0 < total; r0 += kWvPost) {
-            if (!one_round) load_round(r0, true, dl, tj, w);
-            const int jmin = __builtin_amdgcn_readfirstlane(tj[0]);  // lane 0's first posting of the round: the round's first term
-            int jmx = -1;
-#pragma unroll
-            for (int i = 0; i < kWvPerLane; ++i) jmx = tj[i] > jmx ? tj[i] : jmx;
-            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(jmx, off, 64); jmx = o > jmx ? o : jmx; }
-            for (int j = jmin; j <= jmx; ++j) {
-                const double idf_j = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c_idf), j), __builtin_amdgcn_readlane(__double2loint(c_idf), j));
-#pragma unroll
-                for (int i = 0; i < kWvPerLane; ++i) {
-                    if (tj[i] == j) {
-                        const int wd = dl[i] >> 5;
-                        const int slot = (int)L.pre[wd] + __popc(L.bm[wd] & ((1u << (dl[i] & 31)) - 1u));
-                        L.sc[slot] = L.sc[slot] + idf_j * w[i];  // product rounded, then the sum: rank-bm25's order
-                    }
-                }
-                asm volatile("" ::: "memory");  // term j's adds are issued before term j + 1 reads the same slots
+        for (int u = 0; u < 4; ++u) {
+            if (key4[u] > -__builtin_inff()) {
+                int gt, ge;
+                count_keys(s_key, 1024, key4[u], gt, ge);
+                if (gt < k && k <= ge) s_thr = key4[u];
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // ---- 5. top k of the positive slots: (score desc, slot desc) = (score desc, index desc)
-        double v[kWvPerLane];
-        double bs = NEG;
-        int bi = -1;
+        __syncthreads();
+        const float thr = s_thr;
+        for (int i0 = 0; i0 < n; i0 += 256 * 8) {
+            double v[8];
+            int ix[8];
 #pragma unroll
-        for (int i = 0; i < kWvPerLane; ++i) {
-            const int sl = i * 64 + lane;
-            double x = NEG;
-            if (sl < ndist) { const double y = L.sc[sl]; x = y > 0.0 ? y : NEG; }
-            v[i] = x;
-            if (x != NEG && (bi < 0 || x > bs || (x == bs && sl > bi))) { bs = x; bi = sl; }
-        }
-        int got = 0;
-        for (int r = 0; r < k; ++r) {
-            double ws = bs;
-            int wi = bi;
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double os = __shfl_xor(ws, off, 64);
-                const int oi = __shfl_xor(wi, off, 64);
-                if (oi >= 0 && (wi < 0 || os > ws || (os == ws && oi > wi))) { ws = os; wi = oi; }
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256 + tid;
+                v[u] = NEG; ix[u] = 0;
+                if (i < n) { v[u] = cs[i]; ix[u] = cd[i]; }
             }
-            if (wi < 0) break;  // fewer positives than k (uniform)
-            // the winner's document: the (wi - pre[w])-th set bit of its map word; its owner lane = wi & 63
-            {
-                // word of slot wi: each lane looks at its 4 words
-                int hit = -1;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int wd = 4 * lane + u;
-                    const int p0 = L.pre[wd], c = __popc(L.bm[wd]);
-                    if (wi >= p0 && wi < p0 + c) hit = wd;
-                }
-                if (hit >= 0) {
-                    uint32_t bits = L.bm[hit];
-                    for (int s2 = wi - (int)L.pre[hit]; s2 > 0; --s2) bits &= bits - 1;
-                    part_score[pb + r] = ws;
-                    part_idx[pb + r] = base + hit * 32 + __builtin_ctz(bits);
-                }
-            }
-            ++got;
-            if ((wi & 63) == lane) {  // consume it and rescan my own values
-                const int mine = wi >> 6;
-                bs = NEG; bi = -1;
-#pragma unroll
-                for (int i = 0; i < kWvPerLane; ++i) {
-                    if (i == mine) v[i] = NEG;
-                    const int sl = i * 64 + lane;
-                    if (v[i] != NEG && (bi < 0 || v[i] > bs || (v[i] == bs && sl > bi))) { bs = v[i]; bi = sl; }
-                }
+            for (int u = 0; u < 8; ++u) {
+                const bool want = v[u] > 0.0 && (float)v[u] >= thr;
+                const int slot = wave_append(want, &s_m);
+                if (want && slot < kSelList) { l_s[slot] = v[u]; l_i[slot] = ix[u]; }
             }
         }
-        if (lane == 0) *my_cnt = got;
-        // ---- reset what the pair touched
-        for (int i = lane; i < ndist; i += 64) L.sc[i] = 0.0;
-        for (int i = lane; i < kBm25Tile / 32; i += 64) L.bm[i] = 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int mlist = s_m;
+        __syncthreads();
+        if (mlist > kSelList) {
+            got = whole();  // (adversarial order or a mass of equal scores: the slow exact way)
+        } else {
+            got = block_topk(
+                mlist, k, tid, [&](int i) { return l_s[i]; }, [&](int i) { return (int64_t)l_i[i]; }, emit,
+                [&]() {
+                    if (tid == 0) s_cnt = 0;
+                    block_select(
+                        mlist, k < mlist ? k : mlist, tid, [&](int i) { return l_s[i]; }, [&](int i) { return (int64_t)l_i[i]; },
+                        [&](int i) { l_s[i] = NEG; }, [&](int r, double v2, int64_t i) { emit(r, v2, i); s_cnt = r + 1; }, red_s, red_i, red_p);
+                    __syncthreads();
+                    return s_cnt;
+                },
+                L);
+        }
+    }
+    if (tid == 0) {
+        out_count[q] = got;
+        need_dense[q] = ((got < k && (int64_t)got < n_docs) || overflow) ? 1 : 0;
     }
 }
 
@@ -830,7 +971,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(double *__restrict__ pa
                                                          const int32_t *__restrict__ part_idx,
                                                          const int32_t *__restrict__ part_cnt, int ntiles, int k,
                                                          int64_t doc_offset, int64_t n_docs, int mode,
-                                                         int32_t *__restrict__ need_dense,
+                                                         const int32_t *__restrict__ light, int32_t *__restrict__ need_dense,
                                                          int64_t *__restrict__ out_idx,
                                                          double *__restrict__ out_score,
                                                          int32_t *__restrict__ out_count) {
@@ -841,20 +982,19 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(double *__restrict__ pa
     __shared__ TopkLds L;
     const int tid = threadIdx.x, q = blockIdx.x;
     if (mode == 1 && !need_dense[q]) return;
+    if (mode == 0 && light[q]) return;  // bm25_select_kernel's
     double *ps = part_score + (size_t)q * ntiles * k;
     const int32_t *pi = part_idx + (size_t)q * ntiles * k;
     const int32_t *pc = part_cnt + (size_t)q * ntiles;
     const double NEG = -__builtin_inf();
     int mine = 0;
-    bool overflow = false;  // (mode 0) a tile whose touched documents outnumbered the wave kernel's slots: count -1
     for (int e = tid; e < ntiles * k; e += 256) {
         const int tile = e / k, p = e - tile * k;
-        if (pc[tile] < 0) overflow = true;
         if (p >= pc[tile]) ps[e] = NEG; else ++mine;
     }
     for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
     if ((tid & 63) == 0) red_p[tid >> 6] = mine;
-    const int any_overflow = __syncthreads_or(overflow ? 1 : 0);
+    __syncthreads();
     if (tid == 0) s_total = red_p[0] + red_p[1] + red_p[2] + red_p[3];
     __syncthreads();
     const int kout = k < s_total ? k : s_total;
@@ -874,7 +1014,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(double *__restrict__ pa
         L);
     if (tid == 0) {
         out_count[q] = kout;
-        if (mode == 0) need_dense[q] = ((kout < k && (int64_t)kout < n_docs) || any_overflow) ? 1 : 0;
+        if (mode == 0) need_dense[q] = (kout < k && (int64_t)kout < n_docs) ? 1 : 0;
     }
 }
 
@@ -1159,35 +1299,57 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     int32_t *part_idx = reinterpret_cast<int32_t *>(p + (size_t)b * T * k * 8);
     int32_t *part_cnt = reinterpret_cast<int32_t *>(p + (size_t)b * T * k * 12);
     int32_t *need = part_cnt + (size_t)b * T;
-    // 1. fast pass: positives among touched documents
-    //    queries per workgroup: as many as still leave ~8 workgroups per CU of parallelism
+    WavePool pool;
+    pool.capacity = wave_pool_capacity(b, T);
+    pool.light = need + b;
+    pool.off = reinterpret_cast<uint32_t *>(pool.light + b);
+    pool.hlist = reinterpret_cast<int32_t *>(pool.off + b);
+    pool.count = reinterpret_cast<uint32_t *>(pool.hlist + b + 1);
+    {
+        size_t o = (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 16 + 4 + (size_t)b * kWvCountStride * 4;
+        o = (o + 255) & ~(size_t)255;
+        pool.score = reinterpret_cast<double *>(p + o);
+        pool.doc = reinterpret_cast<int32_t *>(p + o + (size_t)pool.capacity * 8);
+    }
+    // 1. fast passes: positives among touched documents.  Light queries (bm25_plan_kernel) one wave per (tile, query) and one
+    //    selection per query; the others on the tile kernel + merge
+    bm25_plan_kernel<<<dim3(1), dim3(1024), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
+    MIR_HIP(hipGetLastError());
+    {
+        const long long npairs = (long long)b * T;
+        const int wgs = (int)std::max<long long>(1, std::min<long long>((npairs + kWvWaves - 1) / kWvWaves, (long long)h->num_cus * 5));
+        bm25_wave_kernel<<<dim3(wgs), dim3(64 * kWvWaves), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
+        MIR_HIP(hipGetLastError());
+    }
+    //    tile kernel: queries per workgroup: as many as still leave ~8 workgroups per CU of parallelism
     int qc = (int)((int64_t)b * T / 2048);
     qc = qc < 1 ? 1 : (qc > kBm25QcMax ? kBm25QcMax : qc);
     if (h->qc_pin > 0) qc = h->qc_pin;  // tests pin the pipeline depth (short pipelines x long query queues)
-    {   // one wave per (tile, query) for the queries that fit it; the tile kernel below takes the others
-        const long long npairs = (long long)b * T;
-        const int wgs = (int)std::max<long long>(1, std::min<long long>((npairs + kWvWaves - 1) / kWvWaves, (long long)h->num_cus * 5));
-        bm25_wave_kernel<<<dim3(wgs), dim3(64 * kWvWaves), 0, s>>>(dev_view(h), d_terms, d_ptr, b, k, part_score, part_idx, part_cnt);
-        MIR_HIP(hipGetLastError());
-    }
-    bm25_sparse_kernel<<<dim3(T, (b + qc - 1) / qc), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, b, qc, k, part_score,
+    bm25_sparse_kernel<<<dim3(T, (b + qc - 1) / qc), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, b, qc, k, pool.hlist, part_score,
                                                                         part_idx, part_cnt);
     MIR_HIP(hipGetLastError());
-    bm25_merge_kernel<<<dim3(b), dim3(256), 0, s>>>(part_score, part_idx, part_cnt, T, k, h->doc_offset, h->n_docs, 0, need,
+    bm25_merge_kernel<<<dim3(b), dim3(256), 0, s>>>(part_score, part_idx, part_cnt, T, k, h->doc_offset, h->n_docs, 0, pool.light, need,
                                                     d_out_idx, d_out_score, d_out_count);
+    MIR_HIP(hipGetLastError());
+    bm25_select_kernel<<<dim3(b), dim3(256), 0, s>>>(pool, k, h->doc_offset, h->n_docs, need, d_out_idx, d_out_score, d_out_count);
     MIR_HIP(hipGetLastError());
     // 2. exact dense pass for the queries with fewer than k positive documents (workgroups of
     //    the other queries exit at once; usually that is all of them)
     bm25_tile_kernel<<<dim3(T, b), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, k, need, nullptr, part_score,
                                                              part_idx, part_cnt);
     MIR_HIP(hipGetLastError());
-    bm25_merge_kernel<<<dim3(b), dim3(256), 0, s>>>(part_score, part_idx, part_cnt, T, k, h->doc_offset, h->n_docs, 1, need,
+    bm25_merge_kernel<<<dim3(b), dim3(256), 0, s>>>(part_score, part_idx, part_cnt, T, k, h->doc_offset, h->n_docs, 1, pool.light, need,
                                                     d_out_idx, d_out_score, d_out_count);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }
 
-static size_t part_bytes(int b, int T, int k) { return (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 4 + 64; }
+// [part_score | part_idx | part_cnt | need, light, off (b each), hlist (b + 1) | count (b x 32) | pool scores | pool documents]
+static size_t part_bytes(int b, int T, int k) {
+    size_t o = (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 16 + 4 + (size_t)b * kWvCountStride * 4;
+    o = (o + 255) & ~(size_t)255;
+    return o + (size_t)wave_pool_capacity(b, T) * 12 + 64;
+}
 
 // BM25Okapi.get_scores(query) -> float64[n_docs] (bm25_retriever.py:83)
 int32_t mir_bm25_scores(mir_bm25 *h, const int32_t *q_terms_host, int32_t nq, double *out_scores_host) {
