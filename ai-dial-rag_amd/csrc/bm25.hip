@@ -1018,6 +1018,78 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(double *__restrict__ pa
     }
 }
 
+// ---- any n (bm25_retriever.py:81-84 takes any n): beyond the 64 results the selection kernels hold, the dense score
+// vectors (bm25_tile_kernel's get_scores form) are ranked in rounds of 64: round r admits only documents strictly after
+// round r - 1's last result in the reference's order (score descending, then index DESCENDING).  One block of 16 waves per
+// query; a wave walks documents wave, wave + 16, ... and keeps its best 64 in registers, one per lane, sorted.
+constexpr int kDkThreads = 1024, kDkWaves = 16, kDkRound = 64;
+__device__ __forceinline__ void bm25_wave_insert(double ns, int64_t ni, int kk, int lane, double &my_s, int64_t &my_i, int &cnt) {
+    const unsigned long long before = __ballot(lane < cnt && bm25_before(my_s, my_i, ns, ni));
+    const int pos = __popcll(before);
+    if (pos >= kk) return;
+    const double up_s = __shfl_up(my_s, 1, 64);
+    const int64_t up_i = ((int64_t)__shfl_up((int)(my_i >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)my_i, 1, 64);
+    if (lane > pos) { my_s = up_s; my_i = up_i; }
+    else if (lane == pos) { my_s = ns; my_i = ni; }
+    cnt = cnt < kk ? cnt + 1 : kk;
+}
+__global__ __launch_bounds__(kDkThreads) void bm25_dense_topk_kernel(const double *__restrict__ scores, int64_t n_docs, int k, int round,
+                                                                     int64_t doc_offset, int q0, double *__restrict__ bound_s,
+                                                                     int64_t *__restrict__ bound_i, int64_t *__restrict__ out_idx,
+                                                                     double *__restrict__ out_score, int32_t *__restrict__ out_count) {
+    __shared__ double s_s[kDkThreads];
+    __shared__ int64_t s_i[kDkThreads];
+    __shared__ int s_c[kDkWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = blockIdx.x, q = q0 + ql;
+    const double *sc = scores + (size_t)ql * n_docs;
+    const int64_t found = k < n_docs ? k : n_docs;
+    const int kk = (int)((found - (int64_t)kDkRound * round) < kDkRound ? (found - (int64_t)kDkRound * round) : kDkRound);
+    if (kk <= 0) return;
+    const bool bounded = round > 0;
+    const double b_s = bounded ? bound_s[ql] : 0.0;
+    const int64_t b_i = bounded ? bound_i[ql] : 0;
+    double my_s = 0.0;
+    int64_t my_i = 0;
+    int cnt = 0;
+    // 64 documents per wave step, one per lane; a step costs one vote unless a document enters the list
+    for (int64_t d0 = (int64_t)wave * 64; d0 < n_docs; d0 += (int64_t)kDkWaves * 64) {
+        const int64_t d = d0 + lane;
+        const double x = d < n_docs ? sc[d] : 0.0;
+        const double worst_s = __shfl(my_s, kk - 1, 64);
+        const int64_t worst_i = ((int64_t)__shfl((int)(my_i >> 32), kk - 1, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)my_i, kk - 1, 64);
+        bool ok = d < n_docs && (cnt < kk || bm25_before(x, d, worst_s, worst_i));
+        if (bounded) ok = ok && bm25_before(b_s, b_i, x, d);
+        unsigned long long mm = __ballot(ok);
+        while (mm) {
+            const int l = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            bm25_wave_insert(__shfl(x, l, 64), d0 + l, kk, lane, my_s, my_i, cnt);
+        }
+    }
+    // the 16 wave lists -> ranks
+    s_s[tid] = my_s;
+    s_i[tid] = my_i;
+    if (lane == 0) s_c[wave] = cnt;
+    __syncthreads();
+    int total = 0, rank = 0;
+    const bool valid = lane < cnt;
+    for (int w = 0; w < kDkWaves; ++w) {
+        const int c = s_c[w];
+        total += c;
+        if (valid)
+            for (int l = 0; l < c; ++l) rank += bm25_before(s_s[w * 64 + l], s_i[w * 64 + l], my_s, my_i) ? 1 : 0;
+    }
+    const int kout = total < kk ? total : kk;
+    if (valid && rank < kout) {
+        const size_t o = (size_t)q * k + (size_t)kDkRound * round + rank;
+        out_score[o] = my_s;
+        out_idx[o] = doc_offset + my_i;
+        if (rank == kout - 1) { bound_s[ql] = my_s; bound_i[ql] = my_i; }
+    }
+    if (tid == 0 && round == 0) out_count[q] = (int)found;
+}
+
 }  // namespace mir
 
 using namespace mir;
@@ -1283,6 +1355,9 @@ int32_t mir_bm25_idf(const mir_bm25 *h, double *out_idf_host) {
     return MIR_OK;
 }
 
+static int32_t bm25_run_large_k(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_ptr, int b, int k, int64_t *d_out_idx,
+                                double *d_out_score, int32_t *d_out_count, void *ws, hipStream_t s);
+
 // Shared implementation: queries already on the device (q_terms[nt], q_ptr[b+1]).
 // part = [part_score f64 | part_idx i32 | part_cnt i32 | need_dense i32]
 static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_ptr, int b, int k, double *d_scores,
@@ -1294,6 +1369,7 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
         MIR_HIP(hipGetLastError());
         return MIR_OK;
     }
+    if (k > kBm25MaxK) return bm25_run_large_k(h, d_terms, d_ptr, b, k, d_out_idx, d_out_score, d_out_count, part, s);
     char *p = static_cast<char *>(part);
     double *part_score = reinterpret_cast<double *>(p);
     int32_t *part_idx = reinterpret_cast<int32_t *>(p + (size_t)b * T * k * 8);
@@ -1351,6 +1427,37 @@ static size_t part_bytes(int b, int T, int k) {
     return o + (size_t)wave_pool_capacity(b, T) * 12 + 64;
 }
 
+// n > 64: dense scores for chunks of queries, then rounds of 64.  Workspace: [scores chunk x n_docs f64 | bound_s | bound_i]
+static int large_k_chunk(const mir_bm25 *h, int b) {
+    const int64_t per = std::max<int64_t>(h->n_docs, 1) * 8;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, ((int64_t)1 << 30) / per));
+}
+static size_t large_k_bytes(const mir_bm25 *h, int b) {
+    const int c = large_k_chunk(h, b);
+    return (size_t)c * (size_t)std::max<int64_t>(h->n_docs, 1) * 8 + (size_t)c * 16 + 256;
+}
+static int32_t bm25_run_large_k(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_ptr, int b, int k, int64_t *d_out_idx,
+                                double *d_out_score, int32_t *d_out_count, void *ws, hipStream_t s) {
+    const int chunk = large_k_chunk(h, b);
+    double *scores = static_cast<double *>(ws);
+    double *bound_s = scores + (size_t)chunk * std::max<int64_t>(h->n_docs, 1);
+    int64_t *bound_i = reinterpret_cast<int64_t *>(bound_s + chunk);
+    const int64_t found = std::min<int64_t>(k, h->n_docs);
+    const int rounds = (int)std::max<int64_t>(1, (found + kDkRound - 1) / kDkRound);
+    for (int q0 = 0; q0 < b; q0 += chunk) {
+        const int nq = std::min(chunk, b - q0);
+        // (the tile kernel reads q_ptr[q], q_ptr[q + 1] of query q = blockIdx.y: offset the ptr array, scores land at [0, nq))
+        bm25_tile_kernel<<<dim3(h->ntiles, nq), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr + q0, 0, nullptr, scores, nullptr, nullptr, nullptr);
+        MIR_HIP(hipGetLastError());
+        for (int r = 0; r < rounds; ++r) {
+            bm25_dense_topk_kernel<<<dim3(nq), dim3(kDkThreads), 0, s>>>(scores, h->n_docs, k, r, h->doc_offset, q0, bound_s, bound_i, d_out_idx,
+                                                                        d_out_score, d_out_count);
+            MIR_HIP(hipGetLastError());
+        }
+    }
+    return MIR_OK;
+}
+
 // BM25Okapi.get_scores(query) -> float64[n_docs] (bm25_retriever.py:83)
 int32_t mir_bm25_scores(mir_bm25 *h, const int32_t *q_terms_host, int32_t nq, double *out_scores_host) {
     MIR_REQUIRE(h != nullptr, "handle is NULL");
@@ -1384,10 +1491,6 @@ int32_t mir_bm25_search(mir_bm25 *h, const int32_t *q_terms_host, const int32_t 
     MIR_REQUIRE(b >= 0 && k >= 1, "bad shape b=%d k=%d", b, k);
     if (b == 0) return MIR_OK;
     MIR_REQUIRE(q_ptr_host && out_idx && out_score && out_count, "NULL buffer");
-    if (k > kBm25MaxK) {
-        set_error("k=%d exceeds this build's BM25 top-k limit %d", k, kBm25MaxK);
-        return MIR_ERR_UNSUPPORTED;
-    }
     const int nt = q_ptr_host[b];
     MIR_REQUIRE(q_ptr_host[0] == 0 && nt >= 0 && (nt == 0 || q_terms_host), "bad q_ptr");
     for (int i = 0; i < b; ++i) MIR_REQUIRE(q_ptr_host[i + 1] >= q_ptr_host[i], "q_ptr not monotone");
@@ -1398,7 +1501,7 @@ int32_t mir_bm25_search(mir_bm25 *h, const int32_t *q_terms_host, const int32_t 
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_terms = take((size_t)nt * 4 + 4), o_ptr = take((size_t)(b + 1) * 4);
     const size_t o_idx = take((size_t)b * k * 8), o_sc = take((size_t)b * k * 8), o_cnt = take((size_t)b * 4);
-    const size_t o_part = take(part_bytes(b, h->ntiles, k));
+    const size_t o_part = take(k > kBm25MaxK ? large_k_bytes(h, b) : part_bytes(b, h->ntiles, k));
     rc = ensure_scratch(h, off);
     if (rc != MIR_OK) return rc;
     char *base = static_cast<char *>(h->scratch);
@@ -1434,7 +1537,7 @@ int32_t mir_bm25_search(mir_bm25 *h, const int32_t *q_terms_host, const int32_t 
 // mir_bm25_workspace_bytes(h, b, k) bytes and stay untouched until the stream has passed.
 int64_t mir_bm25_workspace_bytes(const mir_bm25 *h, int32_t b, int32_t k) {
     if (!h || b < 0 || k < 1) return -1;
-    return (int64_t)part_bytes(b, h->ntiles, k);
+    return (int64_t)(k > kBm25MaxK ? large_k_bytes(h, b) : part_bytes(b, h->ntiles, k));
 }
 
 int32_t mir_bm25_search_device(mir_bm25 *h, const int32_t *q_terms_device, const int32_t *q_ptr_device, int32_t b,
@@ -1444,10 +1547,6 @@ int32_t mir_bm25_search_device(mir_bm25 *h, const int32_t *q_terms_device, const
     MIR_REQUIRE(b >= 0 && k >= 1, "bad shape b=%d k=%d", b, k);
     if (b == 0) return MIR_OK;
     MIR_REQUIRE(q_ptr_device && out_idx && out_score && out_count && workspace, "NULL buffer");
-    if (k > kBm25MaxK) {
-        set_error("k=%d exceeds this build's BM25 top-k limit %d", k, kBm25MaxK);
-        return MIR_ERR_UNSUPPORTED;
-    }
     int32_t rc = use_device(h->device, nullptr);
     if (rc != MIR_OK) return rc;
     return bm25_run(h, q_terms_device, q_ptr_device, b, k, nullptr, out_idx, out_score, out_count, workspace,

@@ -115,8 +115,16 @@ def test_synthetic_vs_oracle_bit_exact(br, n, vocab):
     small = br.DeviceBM25.from_token_ids(indptr[:8], toks[: indptr[7]], vocab)
     i2, s2, c2 = small.search([qs[0]], 64)
     assert c2[0] == 7
-    with pytest.raises(NotImplementedError):
-        dev.search(qs[:1], 65)
+    # any n (bm25_retriever.py:81-84): beyond 64 the dense scores are ranked in rounds of 64; the zero tail and its
+    # reversed tie-break included
+    for kk in (65, 200, n + 10):
+        ib, sb, cb = dev.search(qs[:5] + [[], [vocab + 3]], kk)
+        for i, q in enumerate(qs[:5] + [[], [vocab + 3]]):
+            want = o.get_scores(q)
+            top = ob.top_n_indexes(want, kk)
+            assert cb[i] == len(top) == min(kk, n)
+            np.testing.assert_array_equal(ib[i, : cb[i]], top, err_msg=f"k={kk} query {i}")
+            np.testing.assert_array_equal(sb[i, : cb[i]], want[top])
 
 
 def _check_batch(dev, o, qs, k=10):
