@@ -87,6 +87,17 @@ void wordpiece_word(const mir_wordpiece &t, const uint32_t *w, int n, std::vecto
 bool encode_text(const mir_wordpiece &t, const unsigned char *s, int64_t n, std::vector<int32_t> &out,
                  std::vector<uint32_t> &norm, std::vector<uint8_t> &ncls, std::string &buf, std::vector<int> &off) {
     norm.clear(); ncls.clear();
+    // A literal special token in the text ("[SEP]", "[CLS]", "[MASK]", "[PAD]", "[UNK]"): BertTokenizerFast cuts those out of
+    // the RAW text before normalisation and emits their ids; here '[', 'sep', ']' would come out.  Such a text (a page about
+    // tokenizers, say) is handed back to the caller's tokenizer.
+    for (int64_t i = 0; i + 5 <= n; ++i) {
+        if (s[i] != '[') continue;
+        static const char *const kSpecial[] = {"[SEP]", "[CLS]", "[MASK]", "[PAD]", "[UNK]"};
+        for (const char *sp : kSpecial) {
+            const size_t L = std::strlen(sp);
+            if ((size_t)(n - i) >= L && std::memcmp(s + i, sp, L) == 0) return false;
+        }
+    }
     for (int64_t i = 0; i < n;) {
         uint32_t c = s[i];
         int len = 1;

@@ -26,11 +26,14 @@ never need any of this.
 """
 
 import ctypes as C
+import logging
 from functools import lru_cache
 from typing import List, Sequence
 
 LANG = "english"
 _SEP = "\x00"
+
+logger = logging.getLogger(__name__)
 
 
 def stem_tokens(tokens: Sequence[str]) -> List[str]:
@@ -138,18 +141,49 @@ should've now d ll m o re ve y ain aren aren't couldn couldn't didn didn't doesn
 mightn mightn't mustn mustn't needn needn't shan shan't shouldn shouldn't wasn wasn't weren weren't won won't wouldn wouldn't""".split())
 
 
+FRONT_END = None  # "nltk" | "restated" once _front_end() has chosen (front_end_info() reports it)
+_warned_multi_sentence = False
+
+
 @lru_cache(maxsize=1)
 def _front_end():
-    """(stopwords, word_tokenize): NLTK's own when it is installed WITH its data, else the restatements above."""
+    """(stopwords, word_tokenize): NLTK's own when it is installed WITH its data, else the restatements above - and then
+    it SAYS so, once: the restated sentence splitter approximates Punkt (a trained model) and the stopword list is restated
+    from memory, both unpinned, so tokens can differ from the reference's `tokenized_text`."""
+    global FRONT_END
     try:
         from nltk.corpus import stopwords
         from nltk.tokenize import word_tokenize
 
         stop = frozenset(stopwords.words(LANG))
         word_tokenize("probe the tokenizer data")
+        FRONT_END = "nltk"
         return stop, word_tokenize
-    except (ImportError, LookupError):
+    except (ImportError, LookupError) as e:
+        FRONT_END = "restated"
+        logger.warning("keywords_preprocess: NLTK or its punkt / stopwords data is not available (%s); using the restated Treebank "
+                       "tokenizer (pinned), a rule-based sentence splitter that APPROXIMATES Punkt and a stopword list restated from "
+                       "memory (both unpinned): tokens of multi-sentence texts can differ from the reference's.", type(e).__name__)
         return ENGLISH_STOPWORDS, _word_tokenize_restated
+
+
+def front_end_info() -> dict:
+    """Which tokenizer front end keywords_preprocess uses in this process, and what of it is pinned."""
+    _front_end()
+    if FRONT_END == "nltk":
+        return {"front_end": "nltk", "word_tokenize": "nltk (Punkt + Treebank)", "stopwords": "nltk_data", "stemmer": "native Snowball (pinned)"}
+    return {"front_end": "restated", "word_tokenize": "Treebank restated (pinned on 24 744 sentences) + rule-based sentence split (APPROXIMATES Punkt, unpinned)",
+            "stopwords": "179-word list restated from memory (unpinned)", "stemmer": "native Snowball (pinned)"}
+
+
+def _note_multi_sentence(text: str) -> None:
+    """The one place the approximation can change tokens: a text the restated splitter cuts into several sentences."""
+    global _warned_multi_sentence
+    if FRONT_END == "restated" and not _warned_multi_sentence and len(split_sentences(text)) > 1:
+        _warned_multi_sentence = True
+        logger.warning("keywords_preprocess: tokenising multi-sentence text with the approximate sentence splitter (NLTK data absent); "
+                       "sentence-final periods may be attached differently from the reference's word_tokenize.  Pass stored "
+                       "`tokenized_text`, a `preprocess` callable, or install nltk with punkt + stopwords to remove the difference.")
 
 
 def word_tokenize(text: str) -> List[str]:
@@ -158,4 +192,5 @@ def word_tokenize(text: str) -> List[str]:
 
 def keywords_preprocess(text: str) -> List[str]:
     stop, tokenize = _front_end()
+    _note_multi_sentence(text)
     return stem_tokens([t for t in tokenize(text) if t not in stop])

@@ -253,7 +253,7 @@ def test_large_shard_wide_scan_with_sample_thresholds(amd, metric):
             alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs)
         assert_same_ids(metric, rows[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} q={i}")
         np.testing.assert_allclose(dist[i], wdist, rtol=0, atol=2e-7)
-    # B = 1 .. 32 take the 32-query kernel: same answers
+    # a smaller batch of the same queries rides the same 16-queries-per-wave kernels (fewer waves active): same answers
     _, _, rows32, dist32, _, _ = dev.search(qs[:32], 10, metric)
     np.testing.assert_array_equal(rows32, rows[:32])
     np.testing.assert_array_equal(dist32, dist[:32])

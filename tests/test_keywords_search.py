@@ -35,3 +35,22 @@ def test_keywords_preprocess_chain():
     # "The" survives the (case-sensitive) stopword filter and is stemmed lower-case; "the", "by", "were" are dropped;
     # Treebank splits "weren't" into "were" + "n't"; the final period is a token
     assert got == ["the", "run", "dog", "n't", "easili", "fool", "generous", "nation", "alp", "."]
+
+
+def test_the_unpinned_front_end_says_so(caplog):
+    """Without NLTK's data the mirror falls back to restatements of which the sentence splitter and the stopword list are
+    unpinned: it must say so (once) and report which front end is active."""
+    import logging
+
+    from aidial_rag_amd import keywords_search as ks
+
+    info = ks.front_end_info()
+    assert info["front_end"] in ("nltk", "restated")
+    if info["front_end"] == "restated":
+        assert "unpinned" in info["word_tokenize"] and "unpinned" in info["stopwords"]
+        ks._warned_multi_sentence = False
+        with caplog.at_level(logging.WARNING, logger=ks.__name__):
+            ks.keywords_preprocess("One sentence here. And a second one follows.")
+            ks.keywords_preprocess("Again two. Sentences.")
+        hits = [r for r in caplog.records if "approximate sentence splitter" in r.getMessage()]
+        assert len(hits) == 1  # once per process

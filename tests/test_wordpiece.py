@@ -84,6 +84,10 @@ def test_beyond_bmp_goes_to_the_fallback_or_raises(toks):
 
     ref, mine, words = toks
     both(ref, mine, ["emoji \U0001f600 here", "plain", "math \U0001d400 bold"])
+    # literal special tokens in the text: the reference's tokenizer emits their ids (matched before normalisation); the
+    # native one hands such texts back instead of spelling them out as '[', 'sep', ']'
+    both(ref, mine, ["a [SEP] b [MASK] [CLS] [UNK] [PAD]", "[sep] lower case is ordinary text", "ends with [CLS]", "[MASK]",
+                     "[SE P] [ SEP] [SEPP] are not special"])
     lone = WordPieceTokenizer(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "a"])
     assert lone(["a a"])["input_ids"] == [[2, 4, 4, 3]]
     with pytest.raises(ValueError):
