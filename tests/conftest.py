@@ -17,3 +17,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# ---- measured margins that a pass / fail line hides (encoder error against float32, ...): tests hand them to `note`, the
+# run prints them in its summary whatever the capture mode
+_NOTES = []
+
+
+@pytest.fixture
+def note():
+    return _NOTES.append
+
+
+def pytest_terminal_summary(terminalreporter):
+    if _NOTES:
+        terminalreporter.write_sep("-", "measured margins")
+        for line in _NOTES:
+            terminalreporter.write_line(line)

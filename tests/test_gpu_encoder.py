@@ -38,7 +38,7 @@ def split_hidden(hidden, seqs):
 
 
 @pytest.mark.parametrize("layers", [0, 1, 2, 12])
-def test_hidden_states_vs_transformers(setup, layers):
+def test_hidden_states_vs_transformers(setup, layers, note):
     model, enc, seqs, oe = setup
     _, hidden = enc.debug_hidden(seqs, layers)
     want = oe.hidden_states(model, seqs, layers)
@@ -48,17 +48,17 @@ def test_hidden_states_vs_transformers(setup, layers):
         err = np.abs(got - w).max()
         worst = max(worst, float(err))
         assert err < tol, f"len {len(s)} layers {layers}: max abs err {err}"
-    print(f"\n[encoder parity] {layers} layers: max |hidden - float32 transformers| = {worst:.3e} (gate {tol:.1e})")
+    note(f"[encoder parity] {layers} layers: max |hidden - float32 transformers| = {worst:.3e} (gate {tol:.1e})")
 
 
-def test_embeddings_cls_normalised(setup):
+def test_embeddings_cls_normalised(setup, note):
     model, enc, seqs, oe = setup
     got = enc.encode_ids(seqs)
     want = oe.embed(model, seqs)
     np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
     cos = (got * want).sum(1)
-    print(f"\n[encoder parity] embedding cosine vs float32 transformers: min {cos.min():.6f}, mean {cos.mean():.6f} (gate 0.9995); "
-          f"max |component error| {np.abs(got - want).max():.3e}")
+    note(f"[encoder parity] embedding cosine vs float32 transformers: min {cos.min():.6f}, mean {cos.mean():.6f} (gate 0.9995); "
+         f"max |component error| {np.abs(got - want).max():.3e}")
     assert cos.min() > 0.9995, cos
     raw = enc.encode_ids(seqs, normalize=False)
     np.testing.assert_allclose(raw / np.linalg.norm(raw, axis=1, keepdims=True), got, atol=1e-5)
