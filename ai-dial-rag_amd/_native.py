@@ -18,7 +18,7 @@ METRIC_CODES = {"cosine_sim": 0, "euclidean_dist": 1, "sqeuclidean_dist": 2, "in
 DTYPE_F32, DTYPE_F16 = 0, 1
 FLAG_UNCERTAIN = 1  # never returned since ABI 2
 FLAG_EXACT_PASS = 2  # the query was answered by the exact pass (exact_topk_kernel)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NativeLibraryMissing(ImportError):

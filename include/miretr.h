@@ -32,8 +32,10 @@
 extern "C" {
 #endif
 
-#define MIR_ABI_VERSION 2 /* 2: results always exact (exact pass), any k; mir_bm25_tune / _corpus_stats / _idf_from_stats /
-                             _set_global_stats, mir_rrf_fuse_batch, mir_wordpiece_* added */
+#define MIR_ABI_VERSION 3 /* 2: results always exact (exact pass), any k; mir_bm25_tune / _corpus_stats / _idf_from_stats /
+                             _set_global_stats, mir_rrf_fuse_batch, mir_wordpiece_* added
+                             3: mir_index_scan_stats added; mir_bm25_search[_device] take any k (no MIR_ERR_UNSUPPORTED past 64);
+                                mir_bm25_workspace_bytes grew (candidate pool of the wave-grain fast pass) */
 
 /* status codes */
 #define MIR_OK 0
@@ -59,12 +61,19 @@ extern "C" {
 #define MIR_DTYPE_F32 0
 #define MIR_DTYPE_F16 1
 
-/* per-query result flags (out_flags).  Results are ALWAYS the reference's: the
- * filter scan proves its candidate set complete for almost every query; a query
- * it cannot prove (more near-ties at the cut than its lists hold, or k beyond
- * the lists) is recomputed by the exact pass - the reference formula in float64
- * over every row, stable order on (distance, row) - before the call returns /
- * in stream order.  The flag only reports which route a query took. */
+/* per-query result flags (out_flags).  Results are ALWAYS the reference's.
+ * float32 shards of >= 32K rows at d <= 384 are searched by the sieve: a bf16
+ * filter with a worst-case error margin lets through every row that can reach a
+ * proven lower bound of the k-th best distance, EVERY candidate is re-scored
+ * with the reference formula in float64, and the reference order is taken over
+ * them - exact by construction; only a full candidate buffer (thousands of rows
+ * inside the margin) hands a query to the exact pass.  The other shapes use
+ * filter scans with candidate lists whose completeness is proven a posteriori;
+ * a query they cannot prove (more near-ties at the cut than the lists hold), and
+ * any k beyond the filters (64 on the sieve; 52 / 48 / 56 / 28 on the list scans)
+ * is recomputed by the exact pass - the reference formula in float64 over every
+ * row, stable order on (distance, row) - before the call returns / in stream
+ * order.  The flag only reports which route a query took. */
 #define MIR_FLAG_UNCERTAIN 1  /* never returned since ABI 2 (kept for callers of ABI 1) */
 #define MIR_FLAG_EXACT_PASS 2 /* answered by the exact pass */
 
@@ -250,11 +259,13 @@ int32_t mir_bm25_scores(mir_bm25 *h, const int32_t *q_terms_host, int32_t nq, do
 
 /* _get_top_n_indexes (bm25_retriever.py:81-84) for b queries; q_ptr[b+1]
  * slices q_terms.  Outputs [b][k]: out_idx = doc_offset + local document
- * index, best first; out_count[q] = min(k, n_docs).  k <= 64. */
+ * index, best first; out_count[q] = min(k, n_docs).  Any k >= 1 (the reference takes any n): up to 64 by the
+ * selection kernels, beyond that the dense score vectors are ranked in rounds of 64. */
 int32_t mir_bm25_search(mir_bm25 *h, const int32_t *q_terms_host, const int32_t *q_ptr_host, int32_t b,
                         int32_t k, int64_t *out_idx, double *out_score, int32_t *out_count);
 /* Same with every buffer in HBM, asynchronous on `stream`; `workspace` holds
- * mir_bm25_workspace_bytes(h, b, k) bytes of HBM. */
+ * mir_bm25_workspace_bytes(h, b, k) bytes of HBM (no initial contents required; since ABI 3 it includes the candidate
+ * pool of the wave-grain fast pass: up to b x 16 384 x 12 bytes, and for k > 64 a chunk of dense score vectors). */
 int64_t mir_bm25_workspace_bytes(const mir_bm25 *h, int32_t b, int32_t k);
 int32_t mir_bm25_search_device(mir_bm25 *h, const int32_t *q_terms_device, const int32_t *q_ptr_device,
                                int32_t b, int32_t k, int64_t *out_idx, double *out_score, int32_t *out_count,
