@@ -904,23 +904,28 @@ __global__ __launch_bounds__(256) void bm25_select_kernel(WavePool pool, int k, 
         // more than a thousand candidates: first cut them down with EIGHT loads in flight per thread.  The k-th best float key
         // of 1024 candidates sampled across the array bounds the answer from below (~k n / 1024 candidates reach it); those go
         // to an LDS list, and block_topk runs on the list
-        float key4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = (int)(((long long)(tid + 256 * u) * n) >> 10);
-            key4[u] = (float)pos(i);
-            s_key[tid + 256 * u] = key4[u];
+            s_key[tid + 256 * u] = (float)pos(i);
         }
-        if (tid == 0) { s_thr = -__builtin_inff(); s_m = 0; }
-        __syncthreads();
+        if (tid == 0) s_m = 0;
+        // the sample sorted descending (bitonic, 55 steps of two compare-exchanges per thread; counting, for each of a thread's
+        // four keys, how many of the 1024 are greater cost six times as many instructions)
+        for (int size = 2; size <= 1024; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (key4[u] > -__builtin_inff()) {
-                int gt, ge;
-                count_keys(s_key, 1024, key4[u], gt, ge);
-                if (gt < k && k <= ge) s_thr = key4[u];
+                for (int u = 0; u < 2; ++u) {
+                    const int t2 = tid + 256 * u;
+                    const int lo = 2 * t2 - (t2 & (stride - 1)), hi = lo + stride;
+                    const bool desc = (lo & size) == 0;
+                    const float x = s_key[lo], y = s_key[hi];
+                    if ((x < y) == desc) { s_key[lo] = y; s_key[hi] = x; }
+                }
             }
-        }
+        __syncthreads();
+        if (tid == 0) s_thr = s_key[k - 1];  // -inf when fewer than k sampled candidates are positive: everything passes
         __syncthreads();
         const float thr = s_thr;
         for (int i0 = 0; i0 < n; i0 += 256 * 8) {

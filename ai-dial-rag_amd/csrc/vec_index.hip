@@ -293,6 +293,7 @@ struct SearchPlan {
     int nwg_first = 0;        // layout16 progressive scan: workgroups (= candidate lists) and tiles of the first launch;
     uint32_t tiles_first = 0; // nwg counts the lists of BOTH launches (0 = one launch)
     bool sieve = false;       // large layout16 shard: hi-only filter + exhaustive verification (vec_kernels_sieve.h); nwg = workgroups per launch
+    uint32_t sample_tpw = 0;  // the sieve's threshold sample: tiles per sample workgroup
 };
 
 static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int ksteps, const SearchPlan &pl, bool host_api) {
@@ -683,8 +684,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             sa.out_doc = o_doc; sa.out_chunk = o_chunk; sa.out_row = o_row; sa.out_dist = o_dist; sa.out_count = o_count;
             sa.out_flags = o_flags; sa.nflag = sb.nflag; sa.flagged = sb.flagged; sa.stats = ix->d_stats;
             sa.q = dq; sa.qt = sb.qt; sa.d = d;
-            const uint32_t tpw = std::min<uint32_t>(kSampleTilesPerWg, ix->n_tiles / (4u * kSampleWgs));  // (>= 1: plan())
-            rc = sieve(0, (uint32_t)kSampleWgs * tpw, kSampleWgs, nullptr, nullptr, true);
+            rc = sieve(0, (uint32_t)kSampleWgs * pl.sample_tpw, kSampleWgs, nullptr, nullptr, true);
             if (rc != MIR_OK) return rc;
             sample_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(reinterpret_cast<const float *>(sb.part_sample), kSampleWgs, qpw,
                                                                         k, nq, reinterpret_cast<unsigned long long *>(gt));
@@ -828,8 +828,13 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
             pl->klist = std::min(k, kMaxList);
             // shards of >= 64 tiles per workgroup in two filter launches (1/16 of the tiles, but not fewer than ~157K rows
             // nor more than 1/4, then the rest with the exact k-th best so far as the threshold); smaller ones in one
-            pl->tiles_first = (int64_t)ix->n_tiles >= 64 * (int64_t)wgs
-                                  ? std::max<uint32_t>(ix->n_tiles / 16, std::min<uint32_t>(ix->n_tiles / 4, 4896u)) : 0;
+            // (experiments: MIR_SIEVE_TWO_PHASE_TILES = shards with at least this many tiles per workgroup take two launches;
+            //  MIR_SIEVE_SAMPLE_TPW = tiles per sample workgroup on one-launch shards)
+            static const int two_phase_tiles = getenv("MIR_SIEVE_TWO_PHASE_TILES") ? atoi(getenv("MIR_SIEVE_TWO_PHASE_TILES")) : 64;
+            static const int single_tpw = getenv("MIR_SIEVE_SAMPLE_TPW") ? atoi(getenv("MIR_SIEVE_SAMPLE_TPW")) : kSampleTilesPerWg;
+            const bool two = (int64_t)ix->n_tiles >= (int64_t)two_phase_tiles * wgs;
+            pl->tiles_first = two ? std::max<uint32_t>(ix->n_tiles / 16, std::min<uint32_t>(ix->n_tiles / 4, 4896u)) : 0;
+            pl->sample_tpw = std::max<uint32_t>(1, std::min<uint32_t>(two ? kSampleTilesPerWg : single_tpw, ix->n_tiles / (4u * kSampleWgs)));
             return MIR_OK;
         }
     }
