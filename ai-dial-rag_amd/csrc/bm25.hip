@@ -408,9 +408,19 @@ __global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_
             const int qb = q_ptr[q], len = q_ptr[q + 1] - qb;
             if (len <= kBm25Chunk) {
                 long long sdf = 0;
-                for (int j = 0; j < len; ++j) {
-                    const int t = q_terms[qb + j];
-                    if (t >= 0 && t < m.vocab) sdf += m.t_ptr[t + 1] - m.t_ptr[t];
+                for (int j0 = 0; j0 < len; j0 += 8) {  // eight terms' two dependent loads in flight at once (one by one: 59 us at b = 4096)
+                    int t[8];
+                    int64_t a[8], e[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = j0 + u < len ? q_terms[qb + j0 + u] : -1;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool ok = t[u] >= 0 && t[u] < m.vocab;
+                        a[u] = ok ? m.t_ptr[t[u]] : 0;
+                        e[u] = ok ? m.t_ptr[t[u] + 1] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sdf += e[u] - a[u];
                 }
                 if (sdf <= (long long)kWvHeavy * m.ntiles) { need = sdf; fits = true; }
             }
