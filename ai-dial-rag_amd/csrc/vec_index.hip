@@ -503,6 +503,32 @@ static int32_t launch_sieve(const mir_index *ix, const uint4 *qsplit_g, const do
     return MIR_OK;
 }
 
+// the float16-native sieve's filter launch (vec_kernels_sieve.h, sieve_h16_kernel)
+template <int KIND>
+static int32_t launch_sieve16(const mir_index *ix, const uint4 *qfrag_g, const float *qscale_g, const double *q_norm_g, const double *q_sq_g,
+                              int nq, int nwg, uint32_t tile0, uint32_t n_tiles, int nan_guard, const uint64_t *gthr_g, uint64_t *cand,
+                              uint32_t *ccount, float *part_sample, bool sample, unsigned long long *stat, hipStream_t stream) {
+    const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
+    const size_t lds = sieve16_lds_bytes();
+    const uint32_t n_rows = (uint32_t)ix->n;
+#define MIR_SIEVE16_CASE(KS)                                                                                           \
+    do {                                                                                                               \
+        auto kern = sample ? sieve_h16_kernel<KS, KIND, true> : sieve_h16_kernel<KS, KIND, false>;                     \
+        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qfrag_g, qscale_g, q_norm_g, q_sq_g, ix->d_maxnorm, n_rows, tile0, \
+                                                    n_tiles, nq, nan_guard, gthr_g, cand, ccount, part_sample, stat);  \
+    } while (0)
+    if (ix->ksteps == 64) MIR_SIEVE16_CASE(32);
+    else if (ix->ksteps == 32) MIR_SIEVE16_CASE(16);
+    else {
+        set_error("internal: the float16 sieve has no instance for %d k-steps", ix->ksteps);
+        return MIR_ERR_UNSUPPORTED;
+    }
+#undef MIR_SIEVE16_CASE
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
 // float16-native scan: 128 queries per launch, 16 per wave, one float16 product per fragment (vec_kernels_h16.h)
 template <int KIND>
 static int32_t launch_scan_h16(const mir_index *ix, const uint4 *qfrag_g, const float *qscale_g, int nq, int klist, int nwg,
@@ -667,15 +693,22 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             const int q0 = qpw * g;
             const double *qn = sb.q_norm + q0, *qsq = sb.q_sq + q0;
             const int guard = metric == MIR_METRIC_EUCLIDEAN_DIST ? 1 : 0;
+            const uint4 *qs16 = sb.qsplit + (size_t)g * (kQ16Queries / 16) * (ix->ksteps / 2) * 64;  // native16: hi fragments only
+            const float *qsc = sb.qscale + (size_t)g * qpw;
             auto sieve = [&](uint32_t t0, uint32_t nt, int wgs, uint64_t *cand, uint32_t *cc, bool smp) {
                 float *ps = reinterpret_cast<float *>(sb.part_sample);
                 unsigned long long *st = smp ? nullptr : ix->d_stats + (t0 ? 1 : 0);
+                if (ix->native16) {
+                    if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve16<SCAN_IP>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+                    if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve16<SCAN_COS>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+                    return launch_sieve16<SCAN_L2>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+                }
                 if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve<SCAN_IP>(ix, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
                 if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve<SCAN_COS>(ix, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
                 return launch_sieve<SCAN_L2>(ix, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
             };
             SieveVerifyArgs va;
-            va.docs = ix->d_orig; va.doc_sq = ix->d_docsq; va.d = d; va.metric = metric; va.q0 = q0; va.nq = nq; va.b = b;
+            va.docs = ix->d_orig; va.docs16 = ix->d_f16; va.doc_sq = ix->d_docsq; va.d = d; va.metric = metric; va.q0 = q0; va.nq = nq; va.b = b;
             va.q = dq; va.q_sq = sb.q_sq; va.q_norm = sb.q_norm; va.l = sb.sv;
             SieveSelectArgs sa;
             sa.l = sb.sv; sa.q0 = q0; sa.nq = nq; sa.k = k; sa.metric = metric; sa.q_norm = sb.q_norm; sa.max_norm = ix->d_maxnorm;
@@ -817,7 +850,8 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
     // The reference takes any `limit` (embeddings_index.py:58,81).  Beyond what the filter's per-lane candidate
     // lists hold (LDS), an index that could actually return that many rows is searched by the exact pass alone.
     static const bool sieve_off = getenv("MIR_NO_SIEVE") != nullptr;  // (A/B measurements against the round-2 scan)
-    if (ix->layout16 && !sieve_off && k <= kSieveMaxK) {
+    static const bool sieve16_off = getenv("MIR_NO_SIEVE16") != nullptr;
+    if (((ix->layout16 && !sieve_off) || (ix->native16 && !sieve16_off && !sieve_off)) && k <= kSieveMaxK) {
         // large shards (the progressive scan's: >= 64 tiles per workgroup): filter on the hi blocks alone, verify every candidate
         const int wgs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), (int64_t)ix->n_tiles));
         if (ix->n_tiles >= 4u * kSampleWgs) {  // from 32K rows: there is a sample to take the first threshold from

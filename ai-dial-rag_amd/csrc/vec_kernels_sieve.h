@@ -31,6 +31,7 @@
 // (`nan_guard`): k rows at or above T that are certainly not NaN keep the argument above intact.
 #pragma once
 #include "vec_kernels_q16.h"
+#include "vec_kernels_h16.h"
 
 #ifndef SIEVE_ABL
 #define SIEVE_ABL 0  // measurement builds only (tools/run_vec_variants.sh): 1 = half the MFMAs, 2 = half the LDS fragment reads
@@ -251,6 +252,203 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     }
 }
 
+// ---------------------------------------------------------------- the filter on a float16-native index (config C5)
+// The same sieve over the float16 image of vec_kernels_h16.h (rows exact in float16, ONE product per fragment on
+// v_mfma_f32_16x16x32_f16, the query scaled by a power of two and rounded to float16): |true value - v| <= 6e-4 |x||q|
+// (kH16RelErr), a seventh of the bf16 margin.  A tile is 64 KiB at d = 1024: the ring holds four stages of 16 k-steps (32 KiB,
+// half a tile), three in flight; the accumulators run over a tile's stages, the filter over the finished tile runs in the
+// shadow of the next tile's first MFMAs.  Every stage brings the tile's 32 norms along (16 bytes per wave): one more
+// counted DMA per stage, the same for every stage.
+constexpr int kSieve16Stages = 4;
+__host__ __device__ constexpr size_t sieve16_lds_bytes() { return (size_t)kSieve16Stages * (kH16StageKs * 2048 + kTileRows * 4) + 64; }
+
+template <int KS32, int KIND, bool SAMPLE>
+__global__ __launch_bounds__(512, 2) void sieve_h16_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
+                                                           const uint4 *__restrict__ qfrag, const float *__restrict__ qscale_inv,
+                                                           const double *__restrict__ q_norm, const double *__restrict__ q_sq,
+                                                           const float *__restrict__ max_norm, uint32_t n_rows, uint32_t tile0,
+                                                           uint32_t n_tiles, int nq, int nan_guard, const uint64_t *__restrict__ gthr,
+                                                           uint64_t *__restrict__ cand, uint32_t *__restrict__ ccount,
+                                                           float *__restrict__ part_sample, unsigned long long *__restrict__ stat) {
+    static_assert(KS32 % kH16StageKs == 0, "float16 sieve: d padded to a multiple of 512");
+    constexpr int NS = kSieve16Stages;
+    constexpr int SPT = KS32 / kH16StageKs;   // stages per tile
+    constexpr int SB = kH16StageKs * 2;       // 1-KiB blocks per stage
+    constexpr int STAGE_U4 = SB * 64;
+    constexpr int TILE_U4 = SPT * STAGE_U4;
+    constexpr int PPW = SB / 8;               // 1-KiB DMA pieces per wave per stage
+    constexpr bool AUX = KIND != SCAN_IP;
+    constexpr int PW = PPW + (AUX ? 1 : 0);   // vector-memory operations per wave per stage
+    constexpr int D = NS - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *ring = reinterpret_cast<uint4 *>(smem);                                   // [NS][STAGE_U4]
+    float *aux_lds = reinterpret_cast<float *>(smem + (size_t)NS * STAGE_U4 * 16);    // [NS][32]
+    uint32_t *s_count = reinterpret_cast<uint32_t *>(aux_lds + NS * kTileRows);
+
+    const int tid = threadIdx.x, lane = tid & 63, qc = lane & 15, jg = lane >> 4;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qloc = wave8 * 16 + qc;
+    const bool lane_live = qloc < nq;
+    const bool active = nq > wave8 * 16;
+    const uint32_t G = gridDim.x;
+    if (tid == 0) *s_count = 0;
+
+    float mg = 0.f, bound = -__builtin_inff(), guard = __builtin_inff(), best = -__builtin_inff(), inv_s = 0.f;
+    if (lane_live) {
+        inv_s = qscale_inv[qloc];
+        const float qn = (float)q_norm[qloc] * (1.0f + 1e-6f);
+        mg = (float)kH16RelErr * qn * (KIND == SCAN_COS ? 1.0f : max_norm[0]) * (KIND == SCAN_L2 ? 2.0f : 1.0f);
+        if (!SAMPLE) {
+            const uint64_t key = gthr[qloc];
+            if (key != 0) {
+                const float t = key_value(key);
+                bound = t - mg - 2e-6f * fabsf(t);
+            }
+        } else if (nan_guard) {
+            const float qs = (float)q_sq[qloc];
+            guard = qs - 1e-5f * fabsf(qs);
+        }
+    }
+    f16x8 qh[KS32];
+    {
+        const uint4 *qs = qfrag + (size_t)wave8 * KS32 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) qh[s] = __builtin_bit_cast(f16x8, qs[s * 64]);
+    }
+    const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + G - 1) / G : 0;
+    const uint32_t NG = my_tiles * SPT;
+
+    auto issue = [&](uint32_t g) {
+        const uint32_t tile = tile0 + blockIdx.x + (g / SPT) * G;
+        const uint4 *src = docs + (size_t)tile * TILE_U4 + (size_t)(g % SPT) * STAGE_U4 + (wave8 * PPW) * 64 + lane;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave8 * PPW) * 64) * 16);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
+        if (AUX) {
+            const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_addr_of(aux_lds) + ((g % NS) * kTileRows + wave8 * 4) * 4);
+            if (lane < 4) glds4_b32(aux + (size_t)tile * kTileRows + wave8 * 4 + lane, adst);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < KS32; ++s) asm volatile("" : "+v"(qh[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t g = 0; g < (uint32_t)D && g < NG; ++g) issue(g);
+    auto wait_stage = [&](uint32_t g) {
+        const uint32_t younger = (NG - 1 - g) < (uint32_t)(D - 1) ? (NG - 1 - g) : (uint32_t)(D - 1);
+        if (younger == (uint32_t)(D - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    uint64_t *region = cand + (size_t)blockIdx.x * kSieveRegion;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    auto filter = [&](const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], uint32_t t) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d0 = c0[i] * inv_s, d1 = c1[i] * inv_s;
+            v[i] = KIND == SCAN_IP ? d0 : KIND == SCAN_L2 ? fmaf(2.0f, d0, -ax[i]) : d0 * ax[i];
+            v[4 + i] = KIND == SCAN_IP ? d1 : KIND == SCAN_L2 ? fmaf(2.0f, d1, -ax[4 + i]) : d1 * ax[4 + i];
+        }
+        if (SAMPLE) {
+            if (lane_live) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (v[r] + mg < guard) best = fmaxf(best, v[r] - mg);
+            }
+            return;
+        }
+        uint32_t pm = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound)) << r;
+        if (!lane_live) pm = 0;
+        if (!__any(pm != 0)) return;
+        const uint32_t row0 = t * kTileRows + 4 * jg;
+        if (t * kTileRows + kTileRows > n_rows) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (row0 + 16 * (r >> 2) + (r & 3) >= n_rows) pm &= ~(1u << r);
+        }
+        while (__any(pm != 0)) {
+            const bool has = pm != 0;
+            const int r = has ? __builtin_ctz(pm) : 0;
+            const unsigned long long bal = __ballot(has);
+            const int leader = __builtin_ctzll(bal);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(s_count, (uint32_t)__popcll(bal));
+            base = __shfl(base, leader, 64);
+            const uint32_t slot = base + (uint32_t)__popcll(bal & lt_mask);
+            if (has && slot < (uint32_t)kSieveRegion)
+                region[slot] = ((uint64_t)(uint32_t)qloc << 32) | (uint64_t)(row0 + 16 * (r >> 2) + (r & 3));
+            pm &= pm - 1;
+        }
+    };
+
+    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+    float pax[8] = {};
+    uint32_t pt = 0;
+    bool have_prev = false;
+    for (uint32_t ts = 0; ts < my_tiles; ++ts) {
+        const uint32_t t = tile0 + blockIdx.x + ts * G;
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        float cax[8] = {};
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const uint32_t g = ts * SPT + j;
+            wait_stage(g);
+            __builtin_amdgcn_s_barrier();
+            if (!active) {
+                if (g + D < NG) issue(g + D);
+                continue;
+            }
+            const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
+            uint4 f0[3], f1[3];
+            f0[0] = st[0 * 64]; f1[0] = st[1 * 64];
+            f0[1] = st[2 * 64]; f1[1] = st[3 * 64];
+            if (AUX && j == SPT - 1) {  // rows 16 rh + 4 jg + i of this tile (every stage's slot holds them)
+                const float4 a0 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * kTileRows + 4 * jg);
+                const float4 a1 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * kTileRows + 16 + 4 * jg);
+                cax[0] = a0.x; cax[1] = a0.y; cax[2] = a0.z; cax[3] = a0.w;
+                cax[4] = a1.x; cax[5] = a1.y; cax[6] = a1.z; cax[7] = a1.w;
+            }
+#pragma unroll
+            for (int s = 0; s < kH16StageKs; ++s) {
+                if (s + 2 < kH16StageKs) {
+                    f0[(s + 2) % 3] = st[(2 * (s + 2) + 0) * 64];
+                    f1[(s + 2) % 3] = st[(2 * (s + 2) + 1) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f0[s % 3]), qh[j * kH16StageKs + s], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f1[s % 3]), qh[j * kH16StageKs + s], c1, 0, 0, 0);
+                if (s == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + D < NG) issue(g + D);
+                }
+                if (j == 0 && s == 2 && have_prev) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    filter(p0, p1, pax, pt);
+                }
+            }
+        }
+        if (active) {
+            p0 = c0; p1 = c1; pt = t; have_prev = true;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pax[i] = cax[i];
+        }
+    }
+    if (have_prev) filter(p0, p1, pax, pt);
+    if (SAMPLE) {
+        const float o = __shfl_xor(best, 16, 64);
+        const float b2 = fmaxf(best, o);
+        if (lane_live && (jg == 0 || jg == 2)) part_sample[((size_t)blockIdx.x * kQ16Queries + qloc) * 2 + (jg >> 1)] = b2;
+        return;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ccount[blockIdx.x] = *s_count;
+        if (stat && *s_count) atomicAdd(stat, (unsigned long long)*s_count);
+    }
+}
+
 // ---------------------------------------------------------------- verify
 // One workgroup of 16 waves per region; a wave takes candidates wave, wave + 16, ... : the reference formula in float64
 // (exact_metric_wave) and an append to the query's list.
@@ -265,7 +463,8 @@ struct SieveLists {
 struct SieveVerifyArgs {
     const uint64_t *cand;   // [regions][kSieveRegion]
     const uint32_t *ccount; // [regions]
-    const float *docs;      // f32 [n][d]
+    const float *docs;      // f32 [n][d], or null with
+    const _Float16 *docs16; // f16 [n][d] (float16-native index)
     const float *doc_sq;
     int d, metric, q0, nq, b;  // the launch's queries are q0 .. q0 + nq - 1 of b
     const double *q, *q_sq, *q_norm;
@@ -288,8 +487,10 @@ __global__ __launch_bounds__(1024) void sieve_verify_kernel(SieveVerifyArgs a) {
         const int qi = a.q0 + (int)(key >> 32);
         const uint32_t row = (uint32_t)key;
         double rv;
-        const double dist = exact_metric_wave(a.docs + (size_t)row * a.d, a.q + (size_t)qi * a.d, a.d, a.metric, a.doc_sq[row],
-                                              a.q_sq[qi], a.q_norm[qi], lane, &rv);
+        const double dist = a.docs16 ? exact_metric_wave(a.docs16 + (size_t)row * a.d, a.q + (size_t)qi * a.d, a.d, a.metric, a.doc_sq[row],
+                                                         a.q_sq[qi], a.q_norm[qi], lane, &rv)
+                                     : exact_metric_wave(a.docs + (size_t)row * a.d, a.q + (size_t)qi * a.d, a.d, a.metric, a.doc_sq[row],
+                                                         a.q_sq[qi], a.q_norm[qi], lane, &rv);
         if (lane == 0) {
             const uint32_t slot = atomicAdd(&a.l.count[(size_t)qi * kSieveCountStride], 1u);
             if (slot < (uint32_t)kSieveQueryCap) {

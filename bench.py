@@ -200,7 +200,7 @@ def c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex,
         "ms_per_step": round(1e3 * elapsed / steps, 4),
         "qps": round(B * steps / elapsed, 1),
         "index_hbm_bytes_per_gpu": hbm,
-        "roofline": {"bound": "hbm", "kernel": "scan_topk_h16_kernel (2 launches per shard + list_threshold_kernel)", "bytes_per_launch": bytes_pass,
+        "roofline": {"bound": "hbm", "kernel": "sieve_h16_kernel: two filter launches over the float16 image with sieve_verify_kernel + sieve_select_kernel between them (round 2: scan_topk_h16_kernel with candidate lists; MIR_NO_SIEVE16=1 selects it)", "bytes_per_launch": bytes_pass,
                      "avg_launch_ms": round(avg_ms, 4), "achieved": round(bytes_pass / (avg_ms * 1e-3) / 1e9, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_pass / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "launches": launches},

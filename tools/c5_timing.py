@@ -22,10 +22,10 @@ for B in (32, 128):
     st = torch.cuda.current_stream().cuda_stream
     def step():
         ix.search_device(q.data_ptr(), B, k, "inner_product", o_row.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), o_flg.data_ptr(), stream=st)
-    for _ in range(2): step()
+    for _ in range(6): step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(5): step()
+    for _ in range(10): step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 5
-    print(f"B={B}: {dt*1e3:.2f} ms/step, {B/dt:.0f} QPS, source-bytes rate {n*d*2/dt/1e12:.2f} TB/s, flags {int(o_flg.sum())}", flush=True)
+    dt = (time.perf_counter() - t0) / 10
+    print(f"B={B}: {dt*1e3:.2f} ms/step, {B/dt:.0f} QPS, source-bytes rate {n*d*2/dt/1e12:.2f} TB/s, flags {int(o_flg.sum())}", ix.scan_stats(), flush=True)
