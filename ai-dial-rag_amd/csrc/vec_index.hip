@@ -303,10 +303,10 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.qsplit = c.take<uint4>((size_t)ngroups * (qpw / 32) * ksteps * 128);
     sb.q_sq = c.take<double>(b);
     sb.q_norm = c.take<double>(b);
-    sb.qscale = c.take<float>((size_t)ngroups * 128);
+    sb.qscale = c.take<float>((size_t)ngroups * std::max(128, qpw));
     sb.part = c.take<uint64_t>((size_t)ngroups * nwg * qpw * klist);
     // one zeroed control block: gthr | nflag | arrive[b] | sieve over[b] | sieve kth_valid[b] | sieve count[b][32]  (u32 arrays padded to u64)
-    const size_t gthr_words = (size_t)ngroups * 128, arrive_words = ((size_t)b + 1) / 2;
+    const size_t gthr_words = (size_t)ngroups * std::max(128, qpw), arrive_words = ((size_t)b + 1) / 2;
     const size_t count_words = pl.sieve ? (size_t)b * kSieveCountStride / 2 : 0;
     sb.ctl_words = (int)(gthr_words + 1 + 3 * arrive_words + count_words);
     sb.gthr = c.take<uint64_t>((size_t)sb.ctl_words);
@@ -320,7 +320,7 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.bound_row = c.take<uint32_t>(b);
     sb.part_exact = c.take<uint64_t>((size_t)b * pl.exact_grid * std::min(k, kExactRound) * 2);
     sb.qt = c.take<double>((size_t)((b + kXbQ - 1) / kXbQ) * xb_dpad(d) * kXbQ);
-    sb.part_sample = c.take<uint64_t>((size_t)kSampleWgs * 128 * klist);
+    sb.part_sample = c.take<uint64_t>(std::max((size_t)kSampleWgs * 128 * klist, (size_t)kSampleWgs * std::max(128, qpw)));  // (the sieve's sample: two floats per workgroup and query)
     const size_t sv_q = pl.sieve ? (size_t)b * kSieveQueryCap : 0;
     sb.sv_cand = c.take<uint64_t>(pl.sieve ? (size_t)2 * nwg * kSieveRegion : 0);
     sb.sv_ccount = c.take<uint32_t>(pl.sieve ? (size_t)2 * nwg : 0);
@@ -475,7 +475,7 @@ static int32_t launch_scan_q16(const mir_index *ix, const uint4 *qsplit_g, const
 
 // the sieve's filter launch over tiles [tile0, tile0 + n_tiles) (vec_kernels_sieve.h); sample = the threshold pre-pass
 template <int KIND>
-static int32_t launch_sieve(const mir_index *ix, const uint4 *qsplit_g, const double *q_norm_g, const double *q_sq_g, int nq, int nwg,
+static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g, const double *q_norm_g, const double *q_sq_g, int nq, int nwg,
                             uint32_t tile0, uint32_t n_tiles, int nan_guard, const uint64_t *gthr_g, uint64_t *cand, uint32_t *ccount,
                             float *part_sample, bool sample, unsigned long long *stat, hipStream_t stream) {
     const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
@@ -484,7 +484,8 @@ static int32_t launch_sieve(const mir_index *ix, const uint4 *qsplit_g, const do
     const uint32_t n_rows = (uint32_t)ix->n;
 #define MIR_SIEVE_CASE(KS)                                                                                             \
     case KS: {                                                                                                         \
-        auto kern = sample ? sieve_q16_kernel<KS, KIND, true> : sieve_q16_kernel<KS, KIND, false>;                     \
+        auto kern = qpw > 128 ? (sample ? sieve_q16_kernel<KS, KIND, true, 2> : sieve_q16_kernel<KS, KIND, false, 2>)  \
+                              : (sample ? sieve_q16_kernel<KS, KIND, true, 1> : sieve_q16_kernel<KS, KIND, false, 1>); \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, q_norm_g, q_sq_g, ix->d_maxnorm, n_rows, tile0, n_tiles, \
                                                     nq, nan_guard, gthr_g, cand, ccount, part_sample, stat);           \
@@ -653,8 +654,8 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         }
         return MIR_OK;
     }
-    if (ix->layout16 && qpw == kQ16Queries) {
-        const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (kQ16Queries / 16);
+    if (ix->layout16 && qpw >= kQ16Queries) {
+        const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (qpw / 16);
         prep_queries16_kernel<<<dim3(std::max(ntiles16 * ks32 + b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(
             dq, b, d, ks32, ntiles16, sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords);
     } else if (ix->native16) {
@@ -689,7 +690,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         int32_t rc;
         if (pl.sieve) {
             // filter (hi blocks only) -> verify (reference formula for every candidate) -> select: exact by construction
-            uint64_t *gt = sb.gthr + (size_t)g * 128;
+            uint64_t *gt = sb.gthr + (size_t)g * std::max(128, qpw);
             const int q0 = qpw * g;
             const double *qn = sb.q_norm + q0, *qsq = sb.q_sq + q0;
             const int guard = metric == MIR_METRIC_EUCLIDEAN_DIST ? 1 : 0;
@@ -703,9 +704,9 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                     if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve16<SCAN_COS>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
                     return launch_sieve16<SCAN_L2>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
                 }
-                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve<SCAN_IP>(ix, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
-                if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve<SCAN_COS>(ix, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
-                return launch_sieve<SCAN_L2>(ix, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve<SCAN_IP>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+                if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve<SCAN_COS>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+                return launch_sieve<SCAN_L2>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
             };
             SieveVerifyArgs va;
             va.docs = ix->d_orig; va.docs16 = ix->d_f16; va.doc_sq = ix->d_docsq; va.d = d; va.metric = metric; va.q0 = q0; va.nq = nq; va.b = b;
@@ -856,7 +857,10 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
         const int wgs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), (int64_t)ix->n_tiles));
         if (ix->n_tiles >= 4u * kSampleWgs) {  // from 32K rows: there is a sample to take the first threshold from
             pl->sieve = true;
-            pl->qpw = kQ16Queries;
+            // 128 queries per filter launch, or 256 (two query tiles per wave) when the batch has more: the stream of a pass is
+            // the same, the matrix work doubles (MIR_SIEVE_QPL=128 keeps 128)
+            static const int qpl_max = getenv("MIR_SIEVE_QPL") ? atoi(getenv("MIR_SIEVE_QPL")) : 256;
+            pl->qpw = (ix->layout16 && b > kQ16Queries && qpl_max >= 256) ? 2 * kQ16Queries : kQ16Queries;
             pl->ngroups = (b + pl->qpw - 1) / pl->qpw;
             pl->nwg = wgs;
             pl->klist = std::min(k, kMaxList);

@@ -48,7 +48,10 @@ constexpr int kSieveCountStride = 32;  // a query's append counter has a 128-byt
 
 __host__ __device__ constexpr size_t sieve_lds_bytes(int ks32) { return (size_t)kSieveStages * (ks32 * 2 * 1024 + kTileRows * 4) + 64; }
 
-template <int KS32, int KIND, bool SAMPLE>
+// QT = query tiles (16 queries each) per wave: 1 -> 128 queries per launch; 2 -> 256: every 1-KiB document fragment read from
+// LDS feeds BOTH tiles' MFMAs (the stream and the LDS traffic of a pass are the same, the matrix work doubles: at 128 queries
+// the matrix pipe is half idle behind the HBM stream).
+template <int KS32, int KIND, bool SAMPLE, int QT>
 __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
                                                            const uint4 *__restrict__ qsplit, const double *__restrict__ q_norm,
                                                            const double *__restrict__ q_sq, const float *__restrict__ max_norm,
@@ -56,6 +59,7 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
                                                            const uint64_t *__restrict__ gthr, uint64_t *__restrict__ cand,
                                                            uint32_t *__restrict__ ccount, float *__restrict__ part_sample,
                                                            unsigned long long *__restrict__ stat) {
+    static_assert(QT == 1 || QT == 2, "query tiles per wave");
     constexpr int NS = kSieveStages;
     constexpr int SB = KS32 * 2;          // 1-KiB blocks per stage = a tile's hi blocks
     constexpr int STAGE_U4 = SB * 64;
@@ -64,6 +68,7 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     constexpr bool AUX = KIND != SCAN_IP; // the tile's 32 norms travel with it: 16 bytes per wave, one more DMA
     constexpr int PW = PPW + (AUX ? 1 : 0);  // vector-memory operations per wave per stage
     constexpr int D = NS - 1;             // stages in flight: stage g's slot is free again once stage g has been read
+    constexpr int QPL = 128 * QT;         // queries per launch
     static_assert(SB % 8 == 0, "sieve: d padded to a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *ring = reinterpret_cast<uint4 *>(smem);                                  // [NS][STAGE_U4]
@@ -72,35 +77,40 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
 
     const int tid = threadIdx.x, lane = tid & 63, qc = lane & 15, jg = lane >> 4;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qloc = wave8 * 16 + qc;              // this lane's query in the launch
-    const bool lane_live = qloc < nq;
-    const bool active = nq > wave8 * 16;
     const uint32_t G = gridDim.x;
     if (tid == 0) *s_count = 0;
 
-    // the hi*hi value's margin in ranking units, and this lane's pass bound T - mg (with the float32 rounding of v itself)
-    float mg = 0.f, bound = -__builtin_inff(), guard = __builtin_inff(), best = -__builtin_inff();
-    if (lane_live) {
-        const float qn = (float)q_norm[qloc] * (1.0f + 1e-6f);
-        mg = kHiHiRelErr * qn * (KIND == SCAN_COS ? 1.0f : max_norm[0]) * (KIND == SCAN_L2 ? 2.0f : 1.0f);
-        if (!SAMPLE) {
-            const uint64_t key = gthr[qloc];
-            if (key != 0) {
-                const float t = key_value(key);
-                bound = t - mg - 2e-6f * fabsf(t);
-            }
-        } else if (nan_guard) {
-            // sq = q_sq - v < 0 is NaN under euclidean_dist: rows whose v + mg could reach q_sq do not count as known rows
-            const float qs = (float)q_sq[qloc];
-            guard = qs - 1e-5f * fabsf(qs);
-        }
-    }
-
-    bf16x8 qh[KS32];
-    {
-        const uint4 *qs = qsplit + (size_t)wave8 * KS32 * 128 + lane;
+    // per query tile u of the wave: this lane's query, the hi*hi value's margin in ranking units, and the lane's pass bound
+    // T - mg (with the float32 rounding of v itself)
+    int qloc[QT];
+    bool lane_live[QT];
+    float mg[QT], bound[QT], guard[QT], best[QT];
+    bf16x8 qh[QT][KS32];
+    const bool active = nq > wave8 * QT * 16;  // (the wave's first tile has queries)
 #pragma unroll
-        for (int s = 0; s < KS32; ++s) qh[s] = __builtin_bit_cast(bf16x8, qs[(s * 2 + 0) * 64]);
+    for (int u = 0; u < QT; ++u) {
+        const int t16 = wave8 * QT + u;
+        qloc[u] = t16 * 16 + qc;
+        lane_live[u] = qloc[u] < nq;
+        mg[u] = 0.f; bound[u] = -__builtin_inff(); guard[u] = __builtin_inff(); best[u] = -__builtin_inff();
+        if (lane_live[u]) {
+            const float qn = (float)q_norm[qloc[u]] * (1.0f + 1e-6f);
+            mg[u] = kHiHiRelErr * qn * (KIND == SCAN_COS ? 1.0f : max_norm[0]) * (KIND == SCAN_L2 ? 2.0f : 1.0f);
+            if (!SAMPLE) {
+                const uint64_t key = gthr[qloc[u]];
+                if (key != 0) {
+                    const float t = key_value(key);
+                    bound[u] = t - mg[u] - 2e-6f * fabsf(t);
+                }
+            } else if (nan_guard) {
+                // sq = q_sq - v < 0 is NaN under euclidean_dist: rows whose v + mg could reach q_sq do not count as known rows
+                const float qs = (float)q_sq[qloc[u]];
+                guard[u] = qs - 1e-5f * fabsf(qs);
+            }
+        }
+        const uint4 *qs = qsplit + (size_t)t16 * KS32 * 128 + lane;
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) qh[u][s] = __builtin_bit_cast(bf16x8, qs[(s * 2 + 0) * 64]);
     }
     const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + G - 1) / G : 0;
     const uint32_t NG = my_tiles;
@@ -118,7 +128,9 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     };
     // ordinary loads are complete before the first DMA (the counted waits below count DMAs only)
 #pragma unroll
-    for (int s = 0; s < KS32; ++s) asm volatile("" : "+v"(qh[s]));
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) asm volatile("" : "+v"(qh[u][s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t g = 0; g < (uint32_t)D && g < NG; ++g) issue(g);
 
@@ -130,9 +142,9 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     uint64_t *region = cand + (size_t)blockIdx.x * kSieveRegion;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    // The filter of one tile: this lane's 8 values against its bound.  It runs one tile LATE, in the shadow of the
-    // next tile's MFMAs (its ~30 vector instructions after a tile's last MFMA were exposed at every barrier).
-    auto filter = [&](const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], uint32_t t) {
+    // The filter of one tile and query tile: this lane's 8 values against its bound.  It runs one tile LATE, in the shadow of
+    // the next tile's MFMAs (its ~30 vector instructions after a tile's last MFMA were exposed at every barrier).
+    auto filter = [&](int u, const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], uint32_t t) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -141,17 +153,17 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         }
         if (SAMPLE) {
             // a LOWER bound of this lane's best true value over rows that are certainly not NaN (sample tiles are whole tiles)
-            if (lane_live) {
+            if (lane_live[u]) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
-                    if (v[r] + mg < guard) best = fmaxf(best, v[r] - mg);
+                    if (v[r] + mg[u] < guard[u]) best[u] = fmaxf(best[u], v[r] - mg[u]);
             }
             return;
         }
         uint32_t pm = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound)) << r;  // NaN passes; no bound yet: everything passes
-        if (!lane_live) pm = 0;
+        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound[u])) << r;  // NaN passes; no bound yet: everything passes
+        if (!lane_live[u]) pm = 0;
         if (!__any(pm != 0)) return;
         // rare (a few per cent of the wave-tiles): write the passing (query, row) pairs to this workgroup's region
         const uint32_t row0 = t * kTileRows + 4 * jg;  // this lane's rows: row0 + 16 rh + i
@@ -170,12 +182,14 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
             base = __shfl(base, leader, 64);
             const uint32_t slot = base + (uint32_t)__popcll(bal & lt_mask);
             if (has && slot < (uint32_t)kSieveRegion)
-                region[slot] = ((uint64_t)(uint32_t)qloc << 32) | (uint64_t)(row0 + 16 * (r >> 2) + (r & 3));
+                region[slot] = ((uint64_t)(uint32_t)qloc[u] << 32) | (uint64_t)(row0 + 16 * (r >> 2) + (r & 3));
             pm &= pm - 1;
         }
     };
 
-    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};  // the previous tile: accumulators, norms, index
+    f32x4 p0[QT], p1[QT];  // the previous tile: accumulators, norms, index
+#pragma unroll
+    for (int u = 0; u < QT; ++u) { p0[u] = f32x4{0.f, 0.f, 0.f, 0.f}; p1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float pax[8] = {};
     uint32_t pt = 0;
     bool have_prev = false;
@@ -187,7 +201,9 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
             if (g + D < NG) issue(g + D);
             continue;
         }
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 c0[QT], c1[QT];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) { c0[u] = f32x4{0.f, 0.f, 0.f, 0.f}; c1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
         uint4 f0[3], f1[3];
         f0[0] = st[0 * 64]; f1[0] = st[1 * 64];
@@ -219,8 +235,11 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
 #if SIEVE_ABL == 1  // half of the MFMAs, all LDS reads
             if (!(s & 1)) {
 #endif
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0[s % 3]), qh[s], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1[s % 3]), qh[s], c1, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) {
+                c0[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0[s % 3]), qh[u][s], c0[u], 0, 0, 0);
+                c1[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1[s % 3]), qh[u][s], c1[u], 0, 0, 0);
+            }
 #if SIEVE_ABL == 1
             }
 #endif
@@ -228,21 +247,31 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
                 __builtin_amdgcn_sched_barrier(0);
                 if (g + D < NG) issue(g + D);
             }
-            if (s == 2 && have_prev) {
-                __builtin_amdgcn_sched_barrier(0);
-                filter(p0, p1, pax, pt);
-            }
+#pragma unroll
+            for (int u = 0; u < QT; ++u)
+                if (s == 2 + u && have_prev) {  // the previous tile's filter, one query tile per k-step
+                    __builtin_amdgcn_sched_barrier(0);
+                    filter(u, p0[u], p1[u], pax, pt);
+                }
         }
-        p0 = c0; p1 = c1; pt = t; have_prev = true;
+#pragma unroll
+        for (int u = 0; u < QT; ++u) { p0[u] = c0[u]; p1[u] = c1[u]; }
+        pt = t; have_prev = true;
 #pragma unroll
         for (int i = 0; i < 8; ++i) pax[i] = cax[i];
     }
-    if (have_prev) filter(p0, p1, pax, pt);
+    if (have_prev) {
+#pragma unroll
+        for (int u = 0; u < QT; ++u) filter(u, p0[u], p1[u], pax, pt);
+    }
     if (SAMPLE) {
         // four lanes hold a query's column: two values per query, each the maximum over distinct rows
-        const float o = __shfl_xor(best, 16, 64);
-        const float b2 = fmaxf(best, o);
-        if (lane_live && (jg == 0 || jg == 2)) part_sample[((size_t)blockIdx.x * kQ16Queries + qloc) * 2 + (jg >> 1)] = b2;
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            const float o = __shfl_xor(best[u], 16, 64);
+            const float b2 = fmaxf(best[u], o);
+            if (lane_live[u] && (jg == 0 || jg == 2)) part_sample[((size_t)blockIdx.x * QPL + qloc[u]) * 2 + (jg >> 1)] = b2;
+        }
         return;
     }
     __syncthreads();

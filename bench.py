@@ -40,10 +40,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=384)
-    ap.add_argument("--batch", type=int, default=128,
-                    help="queries per step (B).  One pass of the shard serves up to 128 queries at (nearly) the same cost, "
-                         "so 128 gives the most QPS (~52k at ~82 %% of the HBM roofline; 96: ~40k at 83 %%; 64: ~27k); the "
-                         "sweep reports the others")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="queries per step (B).  One pass of the shard serves up to 256 queries (two 16-query tiles per wave): the "
+                         "stream is the same as for 128, the matrix work doubles, so 256 gives the most QPS (~120k; 128: ~89k; 64: ~50k); "
+                         "the sweep reports the others")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="sqeuclidean_dist")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample (0 = skip)")
@@ -316,12 +316,12 @@ def variant_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher, kind)
     res = {"workload": f"{kind}: {n} x {d} float32 unit rows, {args.metric}, k={k}, {B} queries per step, {steps} steps of fresh queries",
            "ms_per_step": round(1e3 * el / steps, 4), "qps": round(B * steps / el, 1),
            "scan_bracket_ms": round(avg_ms, 4),
-           "roofline_frac_survey_bytes": round(bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "roofline_frac": round(bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "exact_pass_queries": exact, "exact_pass_share": round(exact / (steps * B), 4),
            "queries_aimed_at_clusters_share": round(aimed / pool, 2),
            "ids_identical_to_cpu_oracle_on_2_queries": same, "oracle_s": round(t_oracle, 1)}
-    res["roofline_frac_streamed_bytes"] = round((n * ((d + 127) // 128 * 128) * 2 + (0 if args.metric == "inner_product" else 4 * n))
-                                                / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    res["frac_streamed_bytes"] = round((n * ((d + 127) // 128 * 128) * 2 + (0 if args.metric == "inner_product" else 4 * n))
+                                       / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if stats:
         res["scan_stats"] = stats
     return res
@@ -809,19 +809,22 @@ def main():
     qps = B * args.steps / elapsed
 
     # ---- roofline of the dominant kernel, per shard pass ----
-    # SURVEY.md 8(d)'s algorithmic bytes: shard rows * d * 4 + 4 B/row norm column (sqeuclid/cosine) + the query tile + its
-    # results.  Since round 3 a float32 shard of >= 32K rows at d <= 384 is searched by the sieve (csrc/vec_kernels_sieve.h),
-    # which streams only the bf16 hi blocks of the index image - HALF of those bytes: `achieved` / `frac` price the bytes
-    # the kernel actually moves (what the PMC counters see), `frac_survey_bytes` the survey's figure, side by side.
+    # `achieved` / `frac` follow the contract: SURVEY.md 8(d)'s ALGORITHMIC bytes of a pass - shard rows * d * 4 + 4 B/row norm column
+    # (sqeuclid/cosine) + the query tile + its results - over the measured duration.  Since round 3 a float32 shard of >= 32K rows at
+    # d <= 384 is searched by the sieve (csrc/vec_kernels_sieve.h), which STREAMS only the bf16 hi blocks of the index image - half of
+    # those bytes (`traffic`, from the PMC counters, shows it: 0.51 x the algorithmic bytes): `streamed_bytes_per_launch` /
+    # `frac_streamed_bytes` price what actually crosses the HBM interface, side by side.  At 256 queries per pass the filter is as much
+    # matrix-bound as stream-bound (`mfma_*`: the hi*hi products of a pass against the dense bf16 peak).
     n_loc = hi - lo
     aux = 0 if args.metric == "inner_product" else 4 * n_loc
     wide = d <= 384 and d > 64 and k <= 52
     sieve = d <= 384 and d > 64 and k <= 64 and n_loc >= 32768 and os.environ.get("MIR_NO_SIEVE") is None
-    qpl = 128 if (wide or sieve) else 32
+    qpl = (256 if B > 128 else 128) if sieve else 128 if wide else 32
     q_launch = min(B, qpl)  # queries actually riding one launch
-    survey_bytes = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
+    passes = -(-B // qpl)   # launches groups per step (1 at the default batch)
+    bytes_launch = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
     d_pad = (d + 127) // 128 * 128
-    bytes_launch = (n_loc * d_pad * 2 + aux + q_launch * d * 4 + q_launch * k * 12) if sieve else survey_bytes
+    streamed = (n_loc * d_pad * 2 + aux + q_launch * d * 4 + q_launch * k * 12) if sieve else bytes_launch
     avg_ms = scan_ms / max(launches, 1)
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
     # HBM traffic per launch comes from PMC counters, which cannot be collected inside this run (rocprofv3 --pmc
@@ -841,6 +844,7 @@ def main():
         kernel_name = "scan_topk_q16_kernel (2 launches per shard + list_threshold_kernel)"
     else:
         kernel_name = "scan_topk_kernel"
+    mfma_tflops = 2.0 * n_loc * d_pad * q_launch / (avg_ms * 1e-3) / 1e12 if sieve else None
 
     result = {
         "metric": "retrieval_qps_10Mx384",
@@ -873,17 +877,20 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "bytes_per_launch": bytes_launch,
+            "bytes_per_launch_is": "SURVEY.md 8(d) algorithmic bytes of one shard pass",
             "traffic": traffic,
             "traffic_source": traffic_source,
-            "bytes_per_launch": bytes_launch,
-            "bytes_per_launch_is": ("bytes the sieve streams: rows * d_pad * 2 (bf16 hi blocks) + norm column + queries + results" if sieve
-                                    else "SURVEY.md 8(d) algorithmic bytes"),
-            "survey_bytes_per_launch": survey_bytes,
-            "frac_survey_bytes": round(survey_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "streamed_bytes_per_launch": streamed,
+            "streamed_bytes_is": ("what the sieve moves: rows * d_pad * 2 (bf16 hi blocks) + norm column + queries + results" if sieve
+                                  else "the algorithmic bytes"),
+            "frac_streamed_bytes": round(streamed / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "mfma_tflops_hi_hi": None if mfma_tflops is None else round(mfma_tflops, 1),
+            "mfma_frac_of_2500_tflops_bf16": None if mfma_tflops is None else round(mfma_tflops / 2500.0, 4),
             "avg_launch_ms": round(avg_ms, 4),
             "launches": launches,
             # the same bytes over the whole step (prep, threshold pre-pass, filter, verify, select, exact-pass gate, merge)
-            "step_frac": round(bytes_launch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "step_frac": round(passes * bytes_launch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         },
         "sieve": sieve_stats if sieve else None,  # candidates per query and filter launch, queries handed to the exact pass (rank 0's shard)
         "exact_pass_queries": int(flags_total.item()) // 2,  # queries the filter could not prove (flag bit 2), recomputed exactly
@@ -895,7 +902,7 @@ def main():
     # ---- the same index at other batch sizes: queries per pass trade QPS against roofline fraction ----
     if args.sweep:
         sweep = []
-        for Bs in (1, 32, 64, 96, 128):
+        for Bs in (1, 32, 64, 128, 192, 256):
             if Bs == B:
                 continue
             index.profile(True)
@@ -917,7 +924,7 @@ def main():
             a_ms = ms / max(ln, 1)
             sweep.append({"queries_per_step": Bs, "qps": round(Bs * 10 / el, 1), "ms_per_step": round(1e3 * el / 10, 4),
                           "scan_launch_ms": round(a_ms, 4), "roofline_frac": round(bytes_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                          "frac_survey_bytes": round(survey_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+                          "frac_streamed_bytes": round(streamed / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         result["batch_sweep"] = sweep
     index.close()  # release the shard before the other legs allocate theirs
     if args.variants and world == 1:

@@ -89,18 +89,20 @@ def test_sieve_equals_oracle(ei, corpus, metric):
 def test_batch_sizes_groups_and_row_offset(ei, corpus):
     docs, qs, _, _ = corpus
     rng = np.random.default_rng(5)
-    big = rng.standard_normal((200, 384))
+    big = rng.standard_normal((300, 384))
     big[:12] = qs
     ix = ei.DeviceIndex.from_host(docs, row_offset=10_000_000_000)
     one = ix.search(big[:1], 10, "sqeuclidean_dist")
     full = ix.search(big[:128], 10, "sqeuclidean_dist")
-    two_groups = ix.search(big, 10, "sqeuclidean_dist")   # 200 queries: two launches groups of 128 and 72
+    wide = ix.search(big[:200], 10, "sqeuclidean_dist")   # 129..256 queries: ONE launch group, two 16-query tiles per wave
+    two_groups = ix.search(big, 10, "sqeuclidean_dist")   # 300 queries: two launch groups, of 256 and 44
     for a, b in zip(one, full):
         np.testing.assert_array_equal(a[0], b[0])
-    for a, b in zip(full, two_groups):
+    for a, b, c in zip(full, wide, two_groups):
         np.testing.assert_array_equal(a, b[:128])
+        np.testing.assert_array_equal(b, c[:200])
     assert int(np.delete(two_groups[5], 3).sum()) == 0  # (query 3 is all zeros)
-    for i in (0, 5, 130, 199):
+    for i in (0, 5, 130, 199, 255, 256, 299):
         got = [o[i] for o in two_groups]
         got[2] = got[2] - 10_000_000_000
         check("sqeuclidean_dist", big[i], docs, tuple(got), 10, f"q={i}")
