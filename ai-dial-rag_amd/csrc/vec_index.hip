@@ -270,11 +270,9 @@ struct SearchBuffers {
     uint64_t *part_sample;  // [kSampleWgs][128][klist], reused by every launch (stream-ordered)
     // the sieve (vec_kernels_sieve.h): candidate regions of its two launches, the queries' verified lists
     uint64_t *sv_cand;      // [2][nwg][kSieveRegion]
+    float *sv_candv;        // [2][nwg][kSieveRegion]
     uint32_t *sv_ccount;    // [2][nwg]
-    SieveLists sv;          // dist / rv / row [b][kSieveQueryCap]; count / over [b] live in the zeroed control block
-    double *sv_kth_dist;    // [b]
-    uint32_t *sv_kth_row;   // [b]
-    uint32_t *sv_kth_valid; // [b] (control block)
+    SieveLists sv;          // rv / row [b][kSieveQueryCap]; count / over [b] live in the zeroed control block
     int32_t *o_doc;  // host API staging of outputs, [b][k]
     int64_t *o_chunk;
     int64_t *o_row;
@@ -305,16 +303,15 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.q_norm = c.take<double>(b);
     sb.qscale = c.take<float>((size_t)ngroups * std::max(128, qpw));
     sb.part = c.take<uint64_t>((size_t)ngroups * nwg * qpw * klist);
-    // one zeroed control block: gthr | nflag | arrive[b] | sieve over[b] | sieve kth_valid[b] | sieve count[b][32]  (u32 arrays padded to u64)
+    // one zeroed control block: gthr | nflag | arrive[b] | sieve over[b] | sieve count[b][32]  (u32 arrays padded to u64)
     const size_t gthr_words = (size_t)ngroups * std::max(128, qpw), arrive_words = ((size_t)b + 1) / 2;
     const size_t count_words = pl.sieve ? (size_t)b * kSieveCountStride / 2 : 0;
-    sb.ctl_words = (int)(gthr_words + 1 + 3 * arrive_words + count_words);
+    sb.ctl_words = (int)(gthr_words + 1 + 2 * arrive_words + count_words);
     sb.gthr = c.take<uint64_t>((size_t)sb.ctl_words);
     sb.nflag = base ? reinterpret_cast<int32_t *>(sb.gthr + gthr_words) : nullptr;
     sb.arrive = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1) : nullptr;
     sb.sv.over = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + arrive_words) : nullptr;
-    sb.sv_kth_valid = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + 2 * arrive_words) : nullptr;
-    sb.sv.count = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + 3 * arrive_words) : nullptr;
+    sb.sv.count = base ? reinterpret_cast<uint32_t *>(sb.gthr + gthr_words + 1 + 2 * arrive_words) : nullptr;
     sb.flagged = c.take<int32_t>(b);
     sb.bound_dist = c.take<double>(b);
     sb.bound_row = c.take<uint32_t>(b);
@@ -323,12 +320,10 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.part_sample = c.take<uint64_t>(std::max((size_t)kSampleWgs * 128 * klist, (size_t)kSampleWgs * std::max(128, qpw)));  // (the sieve's sample: two floats per workgroup and query)
     const size_t sv_q = pl.sieve ? (size_t)b * kSieveQueryCap : 0;
     sb.sv_cand = c.take<uint64_t>(pl.sieve ? (size_t)2 * nwg * kSieveRegion : 0);
+    sb.sv_candv = c.take<float>(pl.sieve ? (size_t)2 * nwg * kSieveRegion : 0);
     sb.sv_ccount = c.take<uint32_t>(pl.sieve ? (size_t)2 * nwg : 0);
-    sb.sv.dist = c.take<double>(sv_q);
     sb.sv.rv = c.take<float>(sv_q);
     sb.sv.row = c.take<uint32_t>(sv_q);
-    sb.sv_kth_dist = c.take<double>(pl.sieve ? b : 0);
-    sb.sv_kth_row = c.take<uint32_t>(pl.sieve ? b : 0);
     if (host_api) {
         sb.o_doc = c.take<int32_t>((size_t)b * k);
         sb.o_chunk = c.take<int64_t>((size_t)b * k);
@@ -476,8 +471,8 @@ static int32_t launch_scan_q16(const mir_index *ix, const uint4 *qsplit_g, const
 // the sieve's filter launch over tiles [tile0, tile0 + n_tiles) (vec_kernels_sieve.h); sample = the threshold pre-pass
 template <int KIND>
 static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g, const double *q_norm_g, const double *q_sq_g, int nq, int nwg,
-                            uint32_t tile0, uint32_t n_tiles, int nan_guard, const uint64_t *gthr_g, uint64_t *cand, uint32_t *ccount,
-                            float *part_sample, bool sample, unsigned long long *stat, hipStream_t stream) {
+                            uint32_t tile0, uint32_t n_tiles, int nan_guard, const uint64_t *gthr_g, uint64_t *cand, float *candv,
+                            uint32_t *ccount, float *part_sample, bool sample, unsigned long long *stat, hipStream_t stream) {
     const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
     const int ks32 = ix->ksteps / 2;
     const size_t lds = sieve_lds_bytes(ks32);
@@ -488,7 +483,7 @@ static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g,
                               : (sample ? sieve_q16_kernel<KS, KIND, true, 1> : sieve_q16_kernel<KS, KIND, false, 1>); \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, q_norm_g, q_sq_g, ix->d_maxnorm, n_rows, tile0, n_tiles, \
-                                                    nq, nan_guard, gthr_g, cand, ccount, part_sample, stat);           \
+                                                    nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat);    \
         break;                                                                                                         \
     }
     switch (ks32) {
@@ -508,7 +503,7 @@ static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g,
 template <int KIND>
 static int32_t launch_sieve16(const mir_index *ix, const uint4 *qfrag_g, const float *qscale_g, const double *q_norm_g, const double *q_sq_g,
                               int nq, int nwg, uint32_t tile0, uint32_t n_tiles, int nan_guard, const uint64_t *gthr_g, uint64_t *cand,
-                              uint32_t *ccount, float *part_sample, bool sample, unsigned long long *stat, hipStream_t stream) {
+                              float *candv, uint32_t *ccount, float *part_sample, bool sample, unsigned long long *stat, hipStream_t stream) {
     const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
     const size_t lds = sieve16_lds_bytes();
     const uint32_t n_rows = (uint32_t)ix->n;
@@ -517,7 +512,7 @@ static int32_t launch_sieve16(const mir_index *ix, const uint4 *qfrag_g, const f
         auto kern = sample ? sieve_h16_kernel<KS, KIND, true> : sieve_h16_kernel<KS, KIND, false>;                     \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qfrag_g, qscale_g, q_norm_g, q_sq_g, ix->d_maxnorm, n_rows, tile0, \
-                                                    n_tiles, nq, nan_guard, gthr_g, cand, ccount, part_sample, stat);  \
+                                                    n_tiles, nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat); \
     } while (0)
     if (ix->ksteps == 64) MIR_SIEVE16_CASE(32);
     else if (ix->ksteps == 32) MIR_SIEVE16_CASE(16);
@@ -689,36 +684,38 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         const int nq = std::min(qpw, b - qpw * g);
         int32_t rc;
         if (pl.sieve) {
-            // filter (hi blocks only) -> verify (reference formula for every candidate) -> select: exact by construction
+            // filter (hi blocks only) -> scatter to the queries' lists -> select (reference formula for the rows that can be among
+            // the first k): exact by construction
             uint64_t *gt = sb.gthr + (size_t)g * std::max(128, qpw);
             const int q0 = qpw * g;
             const double *qn = sb.q_norm + q0, *qsq = sb.q_sq + q0;
             const int guard = metric == MIR_METRIC_EUCLIDEAN_DIST ? 1 : 0;
             const uint4 *qs16 = sb.qsplit + (size_t)g * (kQ16Queries / 16) * (ix->ksteps / 2) * 64;  // native16: hi fragments only
             const float *qsc = sb.qscale + (size_t)g * qpw;
-            auto sieve = [&](uint32_t t0, uint32_t nt, int wgs, uint64_t *cand, uint32_t *cc, bool smp) {
+            auto sieve = [&](uint32_t t0, uint32_t nt, int wgs, uint64_t *cand, float *cv, uint32_t *cc, bool smp) {
                 float *ps = reinterpret_cast<float *>(sb.part_sample);
                 unsigned long long *st = smp ? nullptr : ix->d_stats + (t0 ? 1 : 0);
                 if (ix->native16) {
-                    if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve16<SCAN_IP>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
-                    if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve16<SCAN_COS>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
-                    return launch_sieve16<SCAN_L2>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+                    if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve16<SCAN_IP>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                    if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve16<SCAN_COS>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                    return launch_sieve16<SCAN_L2>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
                 }
-                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve<SCAN_IP>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
-                if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve<SCAN_COS>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
-                return launch_sieve<SCAN_L2>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cc, ps, smp, st, stream);
+                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve<SCAN_IP>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve<SCAN_COS>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                return launch_sieve<SCAN_L2>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
             };
-            SieveVerifyArgs va;
-            va.docs = ix->d_orig; va.docs16 = ix->d_f16; va.doc_sq = ix->d_docsq; va.d = d; va.metric = metric; va.q0 = q0; va.nq = nq; va.b = b;
-            va.q = dq; va.q_sq = sb.q_sq; va.q_norm = sb.q_norm; va.l = sb.sv;
+            SieveScatterArgs ca;
+            ca.q0 = q0; ca.nq = nq; ca.l = sb.sv;
             SieveSelectArgs sa;
-            sa.l = sb.sv; sa.q0 = q0; sa.nq = nq; sa.k = k; sa.metric = metric; sa.q_norm = sb.q_norm; sa.max_norm = ix->d_maxnorm;
-            sa.gthr = reinterpret_cast<unsigned long long *>(gt); sa.kth_dist = sb.sv_kth_dist; sa.kth_row = sb.sv_kth_row;
-            sa.kth_valid = sb.sv_kth_valid; sa.chunk_ids = ix->d_chunk; sa.doc_ids = ix->d_doc; sa.row_offset = ix->row_offset;
+            sa.l = sb.sv; sa.q0 = q0; sa.nq = nq; sa.k = k; sa.metric = metric; sa.d = d; sa.nan_guard = guard;
+            sa.rel_err = ix->native16 ? (float)kH16RelErr : kHiHiRelErr;
+            sa.docs = ix->d_orig; sa.docs16 = ix->d_f16; sa.doc_sq = ix->d_docsq;
+            sa.q = dq; sa.q_sq = sb.q_sq; sa.q_norm = sb.q_norm; sa.max_norm = ix->d_maxnorm;
+            sa.gthr = reinterpret_cast<unsigned long long *>(gt);
+            sa.chunk_ids = ix->d_chunk; sa.doc_ids = ix->d_doc; sa.row_offset = ix->row_offset;
             sa.out_doc = o_doc; sa.out_chunk = o_chunk; sa.out_row = o_row; sa.out_dist = o_dist; sa.out_count = o_count;
-            sa.out_flags = o_flags; sa.nflag = sb.nflag; sa.flagged = sb.flagged; sa.stats = ix->d_stats;
-            sa.q = dq; sa.qt = sb.qt; sa.d = d;
-            rc = sieve(0, (uint32_t)kSampleWgs * pl.sample_tpw, kSampleWgs, nullptr, nullptr, true);
+            sa.out_flags = o_flags; sa.nflag = sb.nflag; sa.flagged = sb.flagged; sa.stats = ix->d_stats; sa.qt = sb.qt;
+            rc = sieve(0, (uint32_t)kSampleWgs * pl.sample_tpw, kSampleWgs, nullptr, nullptr, nullptr, true);
             if (rc != MIR_OK) return rc;
             sample_threshold_kernel<<<dim3(nq), dim3(256), 0, stream>>>(reinterpret_cast<const float *>(sb.part_sample), kSampleWgs, qpw,
                                                                         k, nq, reinterpret_cast<unsigned long long *>(gt));
@@ -727,9 +724,10 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             if (rc != MIR_OK) return rc;
             for (int phase = pl.tiles_first ? 0 : 1; phase < 2 && rc == MIR_OK; ++phase) {  // (one launch: the final phase alone)
                 uint64_t *cand = sb.sv_cand + (size_t)phase * nwg * kSieveRegion;
+                float *cv = sb.sv_candv + (size_t)phase * nwg * kSieveRegion;
                 uint32_t *cc = sb.sv_ccount + (size_t)phase * nwg;
-                rc = phase == 0 ? sieve(0, pl.tiles_first, nwg, cand, cc, false)
-                                : sieve(pl.tiles_first, ix->n_tiles - pl.tiles_first, nwg, cand, cc, false);
+                rc = phase == 0 ? sieve(0, pl.tiles_first, nwg, cand, cv, cc, false)
+                                : sieve(pl.tiles_first, ix->n_tiles - pl.tiles_first, nwg, cand, cv, cc, false);
                 if (rc != MIR_OK) break;
                 if (phase == 1 && ev0) {  // the bracket: both filter launches and what runs between them
                     MIR_HIP(hipEventRecord(ev1, stream));
@@ -737,12 +735,12 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                     ix->prof_events.emplace_back(ev0, ev1);
                     ev1 = nullptr;
                 }
-                va.cand = cand; va.ccount = cc;
-                sieve_verify_kernel<<<dim3(nwg * kSieveVerifySplit), dim3(1024), 0, stream>>>(va);
+                ca.cand = cand; ca.candv = cv; ca.ccount = cc;
+                sieve_scatter_kernel<<<dim3(nwg * kSieveScatterSplit), dim3(256), 0, stream>>>(ca);
                 sa.mode = phase;
                 MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sieve_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)sieve_select_lds_bytes()));
-                sieve_select_kernel<<<dim3(nq), dim3(256), sieve_select_lds_bytes(), stream>>>(sa);
+                sieve_select_kernel<<<dim3(nq), dim3(kSieveSelectThreads), sieve_select_lds_bytes(), stream>>>(sa);
                 MIR_HIP(hipGetLastError());
             }
             if (rc != MIR_OK) return rc;

@@ -9,26 +9,29 @@
 //   filter   sieve_q16_kernel: v = hi*hi value of (row, query) in the scan's ranking units.  With
 //            |true value - v| <= mg = 4e-3*|x||q| (kHiHiRelErr, worst case), a row whose true value reaches a
 //            threshold T has v >= T - mg.  Every (row, query) with !(v < T - mg) is written out as a CANDIDATE
-//            (8 bytes; ~4e-5 of the pairs with the thresholds below) - a superset of all rows at or above T.
-//   verify   sieve_verify_kernel: the reference's own float64 formula (exact_metric_wave) for every candidate,
-//            from the float32 rows; appended to the query's list.
-//   select   sieve_select_kernel: the reference's order (distance, NaN last, row) over the query's verified
-//            candidates; the first k are the result.
+//            (row, query, v: 12 bytes; ~4e-5 of the pairs with the thresholds below) - a superset of all rows at or above T.
+//   scatter  sieve_scatter_kernel: the candidates, written per workgroup, are appended to their queries' lists.
+//   select   sieve_select_kernel, per query: kv = the k-th largest v of the list; k rows have true values >= kv - mg, so
+//            every row of the true first k has v >= kv - 2 mg: those few (2-4 k of the few hundred listed) get the
+//            reference's own float64 formula from the float32 rows (exact_metric_wave) and the reference's order
+//            (distance, NaN last, row); the first k are the result.  (Until late in round 3 EVERY candidate was
+//            evaluated in float64, by a kernel of its own after each launch: ~25 % of a 1.25M-row shard's step.)
 //
 // Exactness.  T is a lower bound of the query's k-th best TRUE value (k rows at or above it are known), so all of
-// the true top k are at or above T, hence among the candidates, hence verified and ordered exactly.  No candidate
-// list is bounded by k: the only way to lose a row is a full buffer, which is counted; the query then takes the exact
-// pass (exact_topk_batch_kernel).  There is no "uncertain" outcome and no completeness check.
+// the true top k are at or above T, hence among the candidates, hence - by the same argument with kv - among the rows
+// evaluated and ordered exactly.  No candidate list is bounded by k: the only way to lose a row is a full buffer, which is
+// counted; the query then takes the exact pass (exact_topk_batch_kernel).  There is no "uncertain" outcome and no
+// completeness check.
 //
 // Thresholds, progressively (as the q16 scan): a 32K-row sample gives T0 (the k-th largest of 512 per-lane lower
-// bounds v - mg over distinct rows); launch 1 sieves the first 1/16 of the tiles with T0; its verified candidates
-// give T1 = the exact k-th best true value so far; launch 2 sieves the rest with T1.  The candidates of both
-// launches are ranked together at the end.
+// bounds v - mg over distinct rows); launch 1 sieves the first 1/16 of the tiles with T0; the k-th largest v of its
+// candidates gives T1 = kv - mg; launch 2 sieves the rest with T1.  The candidates of both launches are selected from
+// together at the end.
 //
 // euclidean_dist quirk (embeddings_metrics.py:50): sqrt of a negative rounding residue is NaN and sorts LAST, so
-// a row (nearly) identical to the query has the LARGEST ranking value and the WORST rank.  T1 is taken from the k-th
-// candidate in the reference's order and only if that one is not NaN; T0's sample skips rows that could be NaN
-// (`nan_guard`): k rows at or above T that are certainly not NaN keep the argument above intact.
+// a row (nearly) identical to the query has the LARGEST ranking value and the WORST rank.  Rows that could be NaN
+// (v + mg reaches |q|^2, `nan_guard`) are left out of kv and of T0's sample - k rows at or above T that are certainly not
+// NaN keep the argument above intact - and are always evaluated.
 #pragma once
 #include "vec_kernels_q16.h"
 #include "vec_kernels_h16.h"
@@ -40,9 +43,9 @@
 namespace mir {
 
 constexpr int kSieveStages = 6;        // LDS-DMA ring: 6 x 24 KiB at d = 384, five stages in flight
-constexpr int kSieveRegion = 8192;     // candidates a workgroup can write per launch (64 KiB of HBM each)
-constexpr int kSieveQueryCap = 8192;   // verified candidates kept per query (~55 k of them arrive on a 10M-row shard)
-constexpr int kSieveSelectCap = 1024;  // of which the final ranking holds the ones not worse than launch 1's k-th
+constexpr int kSieveRegion = 8192;     // candidates a workgroup can write per launch (96 KiB of HBM each)
+constexpr int kSieveQueryCap = 8192;   // candidates listed per query (~55 k of them arrive on a 10M-row shard)
+constexpr int kSieveSelectCap = 1024;  // of which at most this many may need the float64 formula (within 2 mg of the k-th largest v)
 constexpr int kSieveMaxK = 64;
 constexpr int kSieveCountStride = 32;  // a query's append counter has a 128-byte line of its own (43K appends on 4 shared lines took 120 us)
 
@@ -57,8 +60,8 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
                                                            const double *__restrict__ q_sq, const float *__restrict__ max_norm,
                                                            uint32_t n_rows, uint32_t tile0, uint32_t n_tiles, int nq, int nan_guard,
                                                            const uint64_t *__restrict__ gthr, uint64_t *__restrict__ cand,
-                                                           uint32_t *__restrict__ ccount, float *__restrict__ part_sample,
-                                                           unsigned long long *__restrict__ stat) {
+                                                           float *__restrict__ candv, uint32_t *__restrict__ ccount,
+                                                           float *__restrict__ part_sample, unsigned long long *__restrict__ stat) {
     static_assert(QT == 1 || QT == 2, "query tiles per wave");
     constexpr int NS = kSieveStages;
     constexpr int SB = KS32 * 2;          // 1-KiB blocks per stage = a tile's hi blocks
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only in the last D - 1 stages of the launch
     };
     uint64_t *region = cand + (size_t)blockIdx.x * kSieveRegion;
+    float *regionv = candv + (size_t)blockIdx.x * kSieveRegion;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     // The filter of one tile and query tile: this lane's 8 values against its bound.  It runs one tile LATE, in the shadow of
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound[u])) << r;  // NaN passes; no bound yet: everything passes
         if (!lane_live[u]) pm = 0;
         if (!__any(pm != 0)) return;
-        // rare (a few per cent of the wave-tiles): write the passing (query, row) pairs to this workgroup's region
+        // rare (a few per cent of the wave-tiles): write the passing (query, row) pairs and their values to this workgroup's region
         const uint32_t row0 = t * kTileRows + 4 * jg;  // this lane's rows: row0 + 16 rh + i
         if (t * kTileRows + kTileRows > n_rows) {
 #pragma unroll
@@ -181,8 +185,13 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
             if (lane == leader) base = atomicAdd(s_count, (uint32_t)__popcll(bal));
             base = __shfl(base, leader, 64);
             const uint32_t slot = base + (uint32_t)__popcll(bal & lt_mask);
-            if (has && slot < (uint32_t)kSieveRegion)
+            float vr = v[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) vr = r == i ? v[i] : vr;
+            if (has && slot < (uint32_t)kSieveRegion) {
                 region[slot] = ((uint64_t)(uint32_t)qloc[u] << 32) | (uint64_t)(row0 + 16 * (r >> 2) + (r & 3));
+                regionv[slot] = vr;
+            }
             pm &= pm - 1;
         }
     };
@@ -297,8 +306,9 @@ __global__ __launch_bounds__(512, 2) void sieve_h16_kernel(const uint4 *__restri
                                                            const double *__restrict__ q_norm, const double *__restrict__ q_sq,
                                                            const float *__restrict__ max_norm, uint32_t n_rows, uint32_t tile0,
                                                            uint32_t n_tiles, int nq, int nan_guard, const uint64_t *__restrict__ gthr,
-                                                           uint64_t *__restrict__ cand, uint32_t *__restrict__ ccount,
-                                                           float *__restrict__ part_sample, unsigned long long *__restrict__ stat) {
+                                                           uint64_t *__restrict__ cand, float *__restrict__ candv,
+                                                           uint32_t *__restrict__ ccount, float *__restrict__ part_sample,
+                                                           unsigned long long *__restrict__ stat) {
     static_assert(KS32 % kH16StageKs == 0, "float16 sieve: d padded to a multiple of 512");
     constexpr int NS = kSieve16Stages;
     constexpr int SPT = KS32 / kH16StageKs;   // stages per tile
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void sieve_h16_kernel(const uint4 *__restri
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     uint64_t *region = cand + (size_t)blockIdx.x * kSieveRegion;
+    float *regionv = candv + (size_t)blockIdx.x * kSieveRegion;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     auto filter = [&](const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], uint32_t t) {
@@ -406,8 +417,13 @@ __global__ __launch_bounds__(512, 2) void sieve_h16_kernel(const uint4 *__restri
             if (lane == leader) base = atomicAdd(s_count, (uint32_t)__popcll(bal));
             base = __shfl(base, leader, 64);
             const uint32_t slot = base + (uint32_t)__popcll(bal & lt_mask);
-            if (has && slot < (uint32_t)kSieveRegion)
+            float vr = v[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) vr = r == i ? v[i] : vr;
+            if (has && slot < (uint32_t)kSieveRegion) {
                 region[slot] = ((uint64_t)(uint32_t)qloc << 32) | (uint64_t)(row0 + 16 * (r >> 2) + (r & 3));
+                regionv[slot] = vr;
+            }
             pm &= pm - 1;
         }
     };
@@ -478,58 +494,105 @@ __global__ __launch_bounds__(512, 2) void sieve_h16_kernel(const uint4 *__restri
     }
 }
 
-// ---------------------------------------------------------------- verify
-// One workgroup of 16 waves per region; a wave takes candidates wave, wave + 16, ... : the reference formula in float64
-// (exact_metric_wave) and an append to the query's list.
+// ---------------------------------------------------------------- scatter
+// The candidates of a filter launch lie in per-workgroup regions; a thread per candidate appends (row, filter value) to its
+// query's list.  No row is read here: what is worth the reference formula is decided per query, from the values alone.
 struct SieveLists {
-    double *dist;      // [b][kSieveQueryCap] reference distance
-    float *rv;         // [b][kSieveQueryCap] true ranking value (the scan's units), rounded to float
+    float *rv;         // [b][kSieveQueryCap] the filter's value v of (row, query), in the scan's ranking units: |true value - v| <= mg
     uint32_t *row;     // [b][kSieveQueryCap]
     uint32_t *count;   // [b][kSieveCountStride] (word 0) appended so far (may exceed the capacity: the rest was dropped)
     uint32_t *over;    // [b] != 0: a candidate of this query was dropped somewhere -> exact pass
 };
 
-struct SieveVerifyArgs {
-    const uint64_t *cand;   // [regions][kSieveRegion]
+struct SieveScatterArgs {
+    const uint64_t *cand;   // [regions][kSieveRegion] (query of the launch << 32 | row)
+    const float *candv;     // [regions][kSieveRegion]
     const uint32_t *ccount; // [regions]
-    const float *docs;      // f32 [n][d], or null with
-    const _Float16 *docs16; // f16 [n][d] (float16-native index)
-    const float *doc_sq;
-    int d, metric, q0, nq, b;  // the launch's queries are q0 .. q0 + nq - 1 of b
-    const double *q, *q_sq, *q_norm;
+    int q0, nq;             // the launch's queries are q0 .. q0 + nq - 1
     SieveLists l;
 };
 
-constexpr int kSieveVerifySplit = 4;  // workgroups per region: a wave's candidates are a serial chain of dependent loads
-__global__ __launch_bounds__(1024) void sieve_verify_kernel(SieveVerifyArgs a) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int reg = blockIdx.x / kSieveVerifySplit, part = blockIdx.x % kSieveVerifySplit;
+constexpr int kSieveScatterSplit = 2;  // workgroups per region
+__global__ __launch_bounds__(256) void sieve_scatter_kernel(SieveScatterArgs a) {
+    const int tid = threadIdx.x;
+    const int reg = blockIdx.x / kSieveScatterSplit, part = blockIdx.x % kSieveScatterSplit;
     uint32_t cnt = a.ccount[reg];
     if (cnt > (uint32_t)kSieveRegion) {  // the region overflowed: whose candidates were lost is unknown
         if (part == 0)
-            for (int i = tid; i < a.nq; i += 1024) a.l.over[a.q0 + i] = 1;
+            for (int i = tid; i < a.nq; i += 256) a.l.over[a.q0 + i] = 1;
         cnt = kSieveRegion;
     }
     const uint64_t *region = a.cand + (size_t)reg * kSieveRegion;
-    for (uint32_t e = part * 16 + wave; e < cnt; e += 16 * kSieveVerifySplit) {
+    const float *regionv = a.candv + (size_t)reg * kSieveRegion;
+    for (uint32_t e = part * 256 + tid; e < cnt; e += 256 * kSieveScatterSplit) {
         const uint64_t key = region[e];
+        const float v = regionv[e];
         const int qi = a.q0 + (int)(key >> 32);
-        const uint32_t row = (uint32_t)key;
-        double rv;
-        const double dist = a.docs16 ? exact_metric_wave(a.docs16 + (size_t)row * a.d, a.q + (size_t)qi * a.d, a.d, a.metric, a.doc_sq[row],
-                                                         a.q_sq[qi], a.q_norm[qi], lane, &rv)
-                                     : exact_metric_wave(a.docs + (size_t)row * a.d, a.q + (size_t)qi * a.d, a.d, a.metric, a.doc_sq[row],
-                                                         a.q_sq[qi], a.q_norm[qi], lane, &rv);
-        if (lane == 0) {
-            const uint32_t slot = atomicAdd(&a.l.count[(size_t)qi * kSieveCountStride], 1u);
-            if (slot < (uint32_t)kSieveQueryCap) {
-                a.l.dist[(size_t)qi * kSieveQueryCap + slot] = dist;
-                a.l.rv[(size_t)qi * kSieveQueryCap + slot] = (float)rv;
-                a.l.row[(size_t)qi * kSieveQueryCap + slot] = row;
-            } else {
-                a.l.over[qi] = 1;
-            }
+        const uint32_t slot = atomicAdd(&a.l.count[(size_t)qi * kSieveCountStride], 1u);
+        if (slot < (uint32_t)kSieveQueryCap) {
+            a.l.row[(size_t)qi * kSieveQueryCap + slot] = (uint32_t)key;
+            a.l.rv[(size_t)qi * kSieveQueryCap + slot] = v;
+        } else {
+            a.l.over[qi] = 1;
         }
+    }
+}
+
+// ---- wave-level selection helpers of the select kernel ----
+// maximum over the wave of a 32-bit unsigned key, uniform: four DPP steps within each row of 16 lanes, then the four rows
+__device__ __forceinline__ uint32_t sieve_wave_max_u32(uint32_t x) {
+#define MIR_DPP_MAX(CTRL)                                                                              \
+    {                                                                                                  \
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);    \
+        x = x > o ? x : o;                                                                             \
+    }
+    MIR_DPP_MAX(0xB1)   // quad_perm [1,0,3,2]
+    MIR_DPP_MAX(0x4E)   // quad_perm [2,3,0,1]
+    MIR_DPP_MAX(0x141)  // row_half_mirror
+    MIR_DPP_MAX(0x140)  // row_mirror
+#undef MIR_DPP_MAX
+    const uint32_t a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+// the wave's largest key over every lane's r[0..R), removed from the one register that holds it (one instance); 0 = none left
+template <int R>
+__device__ __forceinline__ uint32_t sieve_extract_max(uint32_t (&r)[R], int lane) {
+    uint32_t m = r[0];
+#pragma unroll
+    for (int j = 1; j < R; ++j) m = r[j] > m ? r[j] : m;
+    const uint32_t wm = sieve_wave_max_u32(m);
+    const unsigned long long bal = __ballot(m == wm);
+    if (wm != 0 && lane == __builtin_ctzll(bal)) {
+        bool done = false;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const bool hit = !done && r[j] == wm;
+            r[j] = hit ? 0u : r[j];
+            done = done || hit;
+        }
+    }
+    return wm;
+}
+// this wave's share of the n values (entries tid, tid + nt, ...; -inf = nothing) -> its k largest as orderable keys, out[0..k)
+template <int R>
+__device__ __forceinline__ void sieve_wave_topk(const float *vals, int n, int k, int tid, int nt, uint32_t *out) {
+    const int lane = tid & 63;
+    uint32_t r[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int e = j * nt + tid;
+        const float v = e < n ? vals[e] : -__builtin_inff();
+        r[j] = v > -__builtin_inff() ? orderable(v) : 0u;
+    }
+    if (__builtin_amdgcn_readfirstlane(tid - lane) >= n) {  // (a wave with no entry at all)
+        if (lane < k) out[lane] = 0u;
+        return;
+    }
+    for (int t = 0; t < k; ++t) {
+        const uint32_t wm = sieve_extract_max<R>(r, lane);
+        if (lane == 0) out[t] = wm;
     }
 }
 
@@ -537,12 +600,14 @@ __global__ __launch_bounds__(1024) void sieve_verify_kernel(SieveVerifyArgs a) {
 struct SieveSelectArgs {
     SieveLists l;
     int q0, nq, k, metric, mode;   // mode 0: thresholds for the next launch; 1: the result
-    const double *q_norm;
+    int d, nan_guard;
+    float rel_err;                 // the filter's bound: kHiHiRelErr / kH16RelErr
+    const float *docs;             // f32 [n][d], or null with
+    const _Float16 *docs16;        // f16 [n][d] (float16-native index)
+    const float *doc_sq;
+    const double *q, *q_sq, *q_norm;
     const float *max_norm;
     unsigned long long *gthr;      // [nq] of this launch group
-    double *kth_dist;              // [b] launch 1's k-th best (mode 0 writes, mode 1 reads)
-    uint32_t *kth_row;             // [b]
-    uint32_t *kth_valid;           // [b]
     const int64_t *chunk_ids;
     const int32_t *doc_ids;
     int64_t row_offset;
@@ -555,31 +620,39 @@ struct SieveSelectArgs {
     int32_t *nflag;
     int32_t *flagged;
     unsigned long long *stats;     // mir_index_scan_stats counters (see there)
-    const double *q;               // [b][d]: a query handed to the exact pass is published to
-    double *qt;                    // the pass's transposed copy
-    int d;
+    double *qt;                    // the exact pass's transposed copy of the queries handed to it
 };
 
-// grid = nq (one block per query), block = 256.  The query's verified candidates (a few hundred) -> LDS; a float32
-// pre-filter (how many ranking values are greater than mine: full-rate compares, four per LDS read) leaves the ~k
-// entries that can be among the first k; only those are ranked with the reference's float64 order.
-__host__ __device__ constexpr size_t sieve_select_lds_bytes() { return (size_t)kSieveQueryCap * 16 + 16 + (size_t)kSieveSelectCap * 2; }
-__global__ __launch_bounds__(256) void sieve_select_kernel(SieveSelectArgs a) {
+// grid = nq (one block per query), block = 1024.  Everything up to the last step works on the filter's values alone.
+//   With mg the filter's bound, a listed row's true value lies in [v - mg, v + mg].  kv = the k-th largest v over listed rows
+//   that are certainly not NaN; then k rows have true values >= kv - mg =: T, so T is a lower bound of the k-th best true value:
+//   mode 0: T is the next launch's threshold (the filter lets v >= T - mg through);
+//   mode 1: a row of the true first k has true value >= T, hence v >= kv - 2 mg: only those (~2-4 k of the few hundred listed)
+//           are worth the reference's float64 formula (exact_metric_wave, one wave per row) and are ranked in the
+//           reference's order; the first k are the result.
+// Rows that may be NaN under euclidean_dist (v + mg reaches |q|^2: sqrt of a negative residue, sorts LAST) count for nothing
+// in kv and are always evaluated: a row identical to the query may as well be the best one.
+__host__ __device__ constexpr size_t sieve_select_lds_bytes() {
+    return (size_t)kSieveQueryCap * 8 + 16 + (size_t)kSieveSelectCap * 10;
+}
+constexpr int kSieveSelectThreads = 1024;
+__global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(SieveSelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sel_lds[];
-    double *s_d = reinterpret_cast<double *>(sel_lds);                                      // [kSieveQueryCap]
-    float *s_v = reinterpret_cast<float *>(sel_lds + (size_t)kSieveQueryCap * 8);            // [kSieveQueryCap + 4]
-    uint32_t *s_r = reinterpret_cast<uint32_t *>(sel_lds + (size_t)kSieveQueryCap * 12 + 16);  // [kSieveQueryCap]
-    uint16_t *s_fin = reinterpret_cast<uint16_t *>(sel_lds + (size_t)kSieveQueryCap * 16 + 16);  // [kSieveSelectCap]
-    __shared__ int s_n, s_nn, s_f, s_slot;
-    const int tid = threadIdx.x, lane = tid & 63;
+    float *s_v = reinterpret_cast<float *>(sel_lds);                                             // [kSieveQueryCap + 4] -inf: may be NaN / padding
+    uint32_t *s_r = reinterpret_cast<uint32_t *>(sel_lds + (size_t)kSieveQueryCap * 4 + 16);      // [kSieveQueryCap]
+    double *s_d = reinterpret_cast<double *>(sel_lds + (size_t)kSieveQueryCap * 8 + 16);          // [kSieveSelectCap]
+    uint16_t *s_fin = reinterpret_cast<uint16_t *>(sel_lds + (size_t)kSieveQueryCap * 8 + 16 + (size_t)kSieveSelectCap * 8);  // [kSieveSelectCap]
+    __shared__ int s_ns, s_f, s_slot, s_have;
+    __shared__ float s_kv;
+    constexpr int NT = kSieveSelectThreads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = a.q0 + blockIdx.x;
     const uint32_t total = a.l.count[(size_t)qi * kSieveCountStride];
     const int n = (int)(total < (uint32_t)kSieveQueryCap ? total : (uint32_t)kSieveQueryCap);
-    const double *ld = a.l.dist + (size_t)qi * kSieveQueryCap;
     const uint32_t *lr = a.l.row + (size_t)qi * kSieveQueryCap;
     const float *lv = a.l.rv + (size_t)qi * kSieveQueryCap;
     const bool over = a.l.over[qi] != 0;
-    if (tid == 0) { s_n = 0; s_nn = 0; s_f = 0; }
+    if (tid == 0) { s_ns = 0; s_f = 0; s_have = 0; }
     __syncthreads();
     auto to_exact_pass = [&]() {  // (whole block)
         if (a.mode != 1) return;
@@ -591,61 +664,76 @@ __global__ __launch_bounds__(256) void sieve_select_kernel(SieveSelectArgs a) {
             if (a.out_count) a.out_count[qi] = 0;
         }
         __syncthreads();
-        exact_publish_query(a.qt, s_slot, a.q + (size_t)qi * a.d, a.d, a.metric, a.q_norm[qi], tid, 256);
+        exact_publish_query(a.qt, s_slot, a.q + (size_t)qi * a.d, a.d, a.metric, a.q_norm[qi], tid, NT);
     };
     if (over) {  // a candidate of this query was dropped somewhere (mode 0: the sample's threshold stays)
         to_exact_pass();
         return;
     }
-    // ---- 0. the candidates that can still be among the first k: all of them, or (mode 1, launch 1 found k) those not
-    //         worse than launch 1's k-th.  A NaN distance ranks last whatever its ranking value: -inf for the pre-filter
-    const bool cut = a.mode == 1 && a.kth_valid[qi] != 0;
-    const double kd = cut ? a.kth_dist[qi] : 0.0;
-    const uint32_t kr = cut ? a.kth_row[qi] : 0u;
-    for (int e0 = 0; e0 < n; e0 += 256) {
+    const float qn = (float)a.q_norm[qi] * (1.0f + 1e-6f);
+    const float mg = a.rel_err * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) *
+                     (a.metric == MIR_METRIC_INNER_PRODUCT || a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : 2.0f);  // (as the filter's)
+    float guard = __builtin_inff();
+    if (a.nan_guard) {
+        const float qs = (float)a.q_sq[qi];
+        guard = qs - 1e-5f * fabsf(qs);
+    }
+    // ---- 0. the list -> LDS; s_v = -inf for rows that may be NaN (and for a NaN / infinite v)
+    for (int e0 = 0; e0 < n; e0 += NT) {
         const int e = e0 + tid;
-        bool keep = false;
-        double dd = 0.0;
-        uint32_t rr = 0;
-        float vv = 0.f;
+        bool safe = false;
         if (e < n) {
-            dd = ld[e]; rr = lr[e]; vv = lv[e];
-            keep = !cut || !dist_before(kd, kr, dd, rr);
+            const float v = lv[e];
+            safe = v + mg < guard && v > -__builtin_inff();
+            s_v[e] = safe ? v : -__builtin_inff();
+            s_r[e] = lr[e];
         }
-        const bool is_num = dd == dd;
-        const unsigned long long bal = __ballot(keep), nbal = __ballot(keep && is_num);
-        int base = 0;
-        if (bal && lane == __builtin_ctzll(bal)) {
-            base = atomicAdd(&s_n, __popcll(bal));
-            atomicAdd(&s_nn, __popcll(nbal));
-        }
-        base = __shfl(base, bal ? __builtin_ctzll(bal) : 0, 64);
-        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (keep) { s_d[slot] = dd; s_r[slot] = rr; s_v[slot] = is_num ? vv : -__builtin_inff(); }
+        const unsigned long long bal = __ballot(safe);
+        if (bal && lane == __builtin_ctzll(bal)) atomicAdd(&s_ns, __popcll(bal));
     }
     __syncthreads();
-    const int m = s_n, nn = s_nn;
-    if (tid < 4) s_v[m + tid] = -__builtin_inff();  // pad to a multiple of 4
+    const int ns = s_ns;
+    // ---- 1. kv = the k-th largest of the safe values, by a tournament: every wave extracts the k largest of its share (k rounds
+    //         of a wave maximum that removes one instance), wave 0 then extracts the k largest of those.  (Counting, for every
+    //         entry, the entries above it was 23 us for 340 entries and 0.9 ms for 3900 at k = 64.)
+    if (ns >= a.k) {
+        uint32_t *part = reinterpret_cast<uint32_t *>(s_d);  // [16][64] (s_d is not in use yet)
+        if (n <= NT) sieve_wave_topk<1>(s_v, n, a.k, tid, NT, part + wave * 64);
+        else sieve_wave_topk<kSieveQueryCap / kSieveSelectThreads>(s_v, n, a.k, tid, NT, part + wave * 64);
+        __syncthreads();
+        if (wave == 0) {
+            const int nw = n <= NT ? (n + 63) / 64 : NT / 64;   // waves that held entries
+            uint32_t r[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = j * 64 + lane;  // (wave i / k, its i % k-th largest)
+                r[j] = i < nw * a.k ? part[(i / a.k) * 64 + i % a.k] : 0u;
+            }
+            uint32_t wm = 0;
+            for (int t = 0; t < a.k; ++t) wm = sieve_extract_max<16>(r, lane);
+            if (lane == 0) { s_kv = unorderable(wm); s_have = 1; }
+        }
+    }
     __syncthreads();
-    // ---- 1. float32 pre-filter: an entry stays if fewer than k ranking values are strictly greater than its own (float
-    //         rounding is monotone, so every entry of the true first k stays); with fewer than k numeric distances the
-    //         NaN ones are needed too: everything stays
-    const int m4 = (m + 3) & ~3;
-    for (int e0 = 0; e0 < m; e0 += 256) {
+    const bool have = s_have != 0;
+    const float kv = have ? s_kv : 0.f;
+    if (a.mode == 0) {
+        if (have && tid == 0) {
+            const float thr = kv - mg - 4e-6f * fabsf(kv);
+            const unsigned long long key = (unsigned long long)orderable(thr) << 32;
+            if (thr == thr && key > a.gthr[blockIdx.x]) a.gthr[blockIdx.x] = key;
+        }
+        if (tid == 0) atomicAdd(a.stats + 4, (unsigned long long)n);  // entries listed after launch 1
+        return;
+    }
+    // ---- 2. the rows that can be among the first k: v >= kv - 2 mg, the ones that may be NaN, everything without a kv
+    const float cut = have ? kv - 2.0f * mg - 1e-5f * fabsf(kv) - 1e-6f * mg : -__builtin_inff();
+    for (int e0 = 0; e0 < n; e0 += NT) {
         const int e = e0 + tid;
         bool fin = false;
-        if (e < m) {
-            if (nn < a.k) {
-                fin = true;
-            } else {
-                const float mine = s_v[e];
-                int gt = 0;
-                for (int u = 0; u < m4; u += 4) {
-                    const float4 x = *reinterpret_cast<const float4 *>(s_v + u);
-                    gt += (x.x > mine) + (x.y > mine) + (x.z > mine) + (x.w > mine);
-                }
-                fin = gt < a.k && mine > -__builtin_inff();
-            }
+        if (e < n) {
+            const float v = s_v[e];
+            fin = !(v > -__builtin_inff()) || !(v < cut);
         }
         const unsigned long long bal = __ballot(fin);
         int base = 0;
@@ -656,47 +744,38 @@ __global__ __launch_bounds__(256) void sieve_select_kernel(SieveSelectArgs a) {
     }
     __syncthreads();
     const int f = s_f;
-    if (f > kSieveSelectCap) {  // a mass of equal ranking values at the cut: the exact pass orders them
+    if (f > kSieveSelectCap) {  // a mass of rows within the filter's resolution of the cut: the exact pass orders them
         to_exact_pass();
         return;
     }
-    // ---- 2. the reference's order among the finalists
-    const int kout = a.k < m ? a.k : m;
-    for (int i = tid; i < f; i += 256) {
-        const int e = s_fin[i];
-        const double dd = s_d[e];
-        const uint32_t rr = s_r[e];
+    // ---- 3. the reference's float64 formula for those, one wave per row
+    const double *qv = a.q + (size_t)qi * a.d;
+    const double q_sq = a.q_sq[qi], q_norm = a.q_norm[qi];
+    for (int i = wave; i < f; i += NT / 64) {
+        const uint32_t row = s_r[s_fin[i]];
+        double rv;
+        const double dist = a.docs16 ? exact_metric_wave(a.docs16 + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lane, &rv)
+                                     : exact_metric_wave(a.docs + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lane, &rv);
+        if (lane == 0) s_d[i] = dist;
+    }
+    __syncthreads();
+    // ---- 4. the reference's order among them
+    const int kout = a.k < f ? a.k : f;
+    for (int i = tid; i < f; i += NT) {
+        const double dd = s_d[i];
+        const uint32_t rr = s_r[s_fin[i]];
         int rank = 0;
-        for (int c = 0; c < f; ++c) {
-            const int o = s_fin[c];
-            rank += dist_before(s_d[o], s_r[o], dd, rr) ? 1 : 0;  // (an entry is not before itself)
-        }
-        if (a.mode == 1) {
-            if (rank < a.k) {
-                const size_t o = (size_t)qi * a.k + rank;
-                if (a.out_row) a.out_row[o] = a.row_offset + (int64_t)rr;
-                if (a.out_dist) a.out_dist[o] = dd;
-                if (a.out_doc) a.out_doc[o] = a.doc_ids ? a.doc_ids[rr] : 0;
-                if (a.out_chunk) a.out_chunk[o] = a.chunk_ids ? a.chunk_ids[rr] : (int64_t)rr;
-            }
-        } else if (rank == a.k - 1 && m >= a.k) {
-            // launch 1's k-th best in the reference's order: the cut of the final ranking and, unless it is a NaN
-            // distance (whose ranking value says nothing about the rows before it), the threshold of launch 2
-            a.kth_dist[qi] = dd;
-            a.kth_row[qi] = rr;
-            a.kth_valid[qi] = 1;
-            if (dd == dd) {
-                const float t = s_v[e];
-                const float qn = (float)a.q_norm[qi] * (1.0f + 1e-6f);
-                const float slack = 2e-6f * fabsf(t) + 1e-6f * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]);
-                const float thr = t - slack;  // (float)rv rounds to nearest: the slack covers that too
-                const unsigned long long key = (unsigned long long)orderable(thr) << 32;
-                if (thr == thr && key > a.gthr[blockIdx.x]) a.gthr[blockIdx.x] = key;
-            }
+        for (int c = 0; c < f; ++c) rank += dist_before(s_d[c], s_r[s_fin[c]], dd, rr) ? 1 : 0;  // (an entry is not before itself)
+        if (rank < a.k) {
+            const size_t o = (size_t)qi * a.k + rank;
+            if (a.out_row) a.out_row[o] = a.row_offset + (int64_t)rr;
+            if (a.out_dist) a.out_dist[o] = dd;
+            if (a.out_doc) a.out_doc[o] = a.doc_ids ? a.doc_ids[rr] : 0;
+            if (a.out_chunk) a.out_chunk[o] = a.chunk_ids ? a.chunk_ids[rr] : (int64_t)rr;
         }
     }
-    if (tid == 0) atomicAdd(a.stats + 4 + a.mode, (unsigned long long)m);  // entries ranked after launch 1 / at the end
-    if (a.mode == 1 && tid == 0) {
+    if (tid == 0) {
+        atomicAdd(a.stats + 5, (unsigned long long)f);  // rows evaluated in float64
         atomicAdd(a.stats + 2, 1ull);
         if (a.out_count) a.out_count[qi] = kout;
         if (a.out_flags) a.out_flags[qi] = 0;

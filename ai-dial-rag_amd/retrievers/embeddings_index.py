@@ -168,15 +168,15 @@ class DeviceIndex:
 
     def scan_stats(self, reset: bool = True) -> dict:
         """Counters of the sieve (large float32 shards) since the last reset: candidates per filter launch, queries
-        answered, queries handed to the exact pass, verified candidates ranked."""
+        answered, queries handed to the exact pass, candidates listed after the first launch, rows evaluated in float64."""
         out = np.zeros(8, np.int64)
         nat.check(nat.lib.mir_index_scan_stats(self._h, 1 if reset else 0, nat.ptr(out)))
         q = max(int(out[2] + out[3]), 1)
         return {"queries": int(out[2] + out[3]), "to_exact_pass": int(out[3]),
                 "candidates_per_query_first_launch": round(float(out[0]) / q, 1),
                 "candidates_per_query_second_launch": round(float(out[1]) / q, 1),
-                "ranked_per_query_after_first_launch": round(float(out[4]) / q, 1),
-                "ranked_per_query_final": round(float(out[5]) / q, 1)}
+                "listed_per_query_after_first_launch": round(float(out[4]) / q, 1),
+                "evaluated_in_float64_per_query": round(float(out[5]) / q, 1)}
 
     def metric_eval(self, query: np.ndarray, metric) -> np.ndarray:
         q = nat.as_f64_queries(query, self.d)[0]
