@@ -148,25 +148,42 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
 
     // The filter of one tile and query tile: this lane's 8 values against its bound.  It runs one tile LATE, in the shadow of
     // the next tile's MFMAs (its ~30 vector instructions after a tile's last MFMA were exposed at every barrier).
+    // SCAN_L2: a tile's accumulators START at -|x|^2 / 2 (row-wise, the MFMA's C operand), so that c = x.q - |x|^2 / 2 and the
+    // ranking value 2 x.q - |x|^2 is 2 c: the filter compares c with half the bound and needs no arithmetic at all.
     auto filter = [&](int u, const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], uint32_t t) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[i] = KIND == SCAN_IP ? c0[i] : KIND == SCAN_L2 ? fmaf(2.0f, c0[i], -ax[i]) : c0[i] * ax[i];
-            v[4 + i] = KIND == SCAN_IP ? c1[i] : KIND == SCAN_L2 ? fmaf(2.0f, c1[i], -ax[4 + i]) : c1[i] * ax[4 + i];
+            v[i] = KIND == SCAN_COS ? c0[i] * ax[i] : c0[i];
+            v[4 + i] = KIND == SCAN_COS ? c1[i] * ax[4 + i] : c1[i];
         }
         if (SAMPLE) {
             // a LOWER bound of this lane's best true value over rows that are certainly not NaN (sample tiles are whole tiles)
             if (lane_live[u]) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    if (v[r] + mg[u] < guard[u]) best[u] = fmaxf(best[u], v[r] - mg[u]);
+                for (int r = 0; r < 8; ++r) {
+                    const float w = KIND == SCAN_L2 ? 2.0f * v[r] : v[r];
+                    if (w + mg[u] < guard[u]) best[u] = fmaxf(best[u], w - mg[u]);
+                }
             }
             return;
         }
+        // one compare per value, their results OR-ed as lane masks (scalar unit): beside the MFMAs every vector instruction
+        // of the common path costs matrix-pipe issue slots
+        const float bnd = KIND == SCAN_L2 ? 0.5f * bound[u] : bound[u];
+        bool pass = false;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pass |= !(v[r] < bnd);  // NaN passes; no bound yet: everything passes
+        pass &= lane_live[u];
+        if (!__any(pass)) return;
+        asm volatile("" : "+s"(t));  // (everything below depends on t: hipcc must not compute the rare path's row masks ahead of the branch)
+        if (KIND == SCAN_L2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] *= 2.0f;
+        }
         uint32_t pm = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound[u])) << r;  // NaN passes; no bound yet: everything passes
+        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound[u])) << r;
         if (!lane_live[u]) pm = 0;
         if (!__any(pm != 0)) return;
         // rare (a few per cent of the wave-tiles): write the passing (query, row) pairs and their values to this workgroup's region
@@ -210,9 +227,6 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
             if (g + D < NG) issue(g + D);
             continue;
         }
-        f32x4 c0[QT], c1[QT];
-#pragma unroll
-        for (int u = 0; u < QT; ++u) { c0[u] = f32x4{0.f, 0.f, 0.f, 0.f}; c1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
         uint4 f0[3], f1[3];
         f0[0] = st[0 * 64]; f1[0] = st[1 * 64];
@@ -223,6 +237,17 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
             const float4 a1 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * kTileRows + 16 + 4 * jg);
             cax[0] = a0.x; cax[1] = a0.y; cax[2] = a0.z; cax[3] = a0.w;
             cax[4] = a1.x; cax[5] = a1.y; cax[6] = a1.z; cax[7] = a1.w;
+        }
+        f32x4 c0[QT], c1[QT];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            if (KIND == SCAN_L2) {
+                c0[u] = f32x4{-0.5f * cax[0], -0.5f * cax[1], -0.5f * cax[2], -0.5f * cax[3]};
+                c1[u] = f32x4{-0.5f * cax[4], -0.5f * cax[5], -0.5f * cax[6], -0.5f * cax[7]};
+            } else {
+                c0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                c1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
 #pragma unroll
         for (int s = 0; s < KS32; ++s) {
