@@ -7,7 +7,7 @@
 
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of the bytes of 16-B-per-lane streaming reads
 (LDS-DMA included) -> read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.  The correction is calibrated for the
-streaming filter launches; the verify / select kernels between them (random 1.5-KiB row reads, a few MB) are listed
+streaming filter launches; the scatter / select kernels between them (candidate records, list entries and the ~20 rows per query that are evaluated: a few MB) are listed
 separately with the same factor, which over-states them at worst."""
 import csv, json, sys
 from collections import defaultdict
@@ -36,18 +36,18 @@ def mean_of(by, key):
     return sum(v) / len(v)
 name, f1, f2 = split_filter(fetch)
 _, w1, w2 = split_filter(write)
-fv, fs = mean_of(fetch, "sieve_verify_kernel"), mean_of(fetch, "sieve_select_kernel")
-wv, ws = mean_of(write, "sieve_verify_kernel"), mean_of(write, "sieve_select_kernel")
+fv, fs = mean_of(fetch, "sieve_scatter_kernel"), mean_of(fetch, "sieve_select_kernel")
+wv, ws = mean_of(write, "sieve_scatter_kernel"), mean_of(write, "sieve_select_kernel")
 reads = 2 * (f1 + f2) * 1024
-between = 2 * (fv + fs) * 1024 + (wv + ws) * 1024  # one verify + select pair sits inside the bracket (the mean is over both pairs)
+between = 2 * (fv + fs) * 1024 + (wv + ws) * 1024  # one scatter + select pair sits inside the bracket (the mean is over both pairs)
 hbm = reads + (w1 + w2) * 1024 + between
 streamed = n * ((d + 127) // 128 * 128) * 2 + 4 * n + B * d * 4 + B * 10 * 12
 print(json.dumps({
     "sieve": True,
-    "kernel": name + ": the two filter launches that stream one shard's bf16 hi blocks (first 1/16 of the tiles, then the rest), plus the sieve_verify_kernel / sieve_select_kernel pair between them - what bench.py's HIP events bracket; the 32K-row sample launch before them is outside the bracket",
+    "kernel": name + ": the two filter launches that stream one shard's bf16 hi blocks (first 1/16 of the tiles, then the rest), plus the sieve_scatter_kernel / sieve_select_kernel pair between them - what bench.py's HIP events bracket; the 32K-row sample launch before them is outside the bracket",
     "rows_per_launch": n, "dim": d, "queries_per_launch": B,
-    "FETCH_SIZE_KiB_mean": {"first_launch": f1, "second_launch": f2, "verify_kernel": fv, "select_kernel": fs},
-    "WRITE_SIZE_KiB_mean": {"first_launch": w1, "second_launch": w2, "verify_kernel": wv, "select_kernel": ws},
+    "FETCH_SIZE_KiB_mean": {"first_launch": f1, "second_launch": f2, "scatter_kernel": fv, "select_kernel": fs},
+    "WRITE_SIZE_KiB_mean": {"first_launch": w1, "second_launch": w2, "scatter_kernel": wv, "select_kernel": ws},
     "correction": "gfx950: FETCH_SIZE counts 1/2 of 16-B-per-lane streaming reads, LDS-DMA included (MI355X_MICROARCH.md, HBM) -> read bytes = 2*FETCH_SIZE*1024; WRITE_SIZE exact",
     "hbm_bytes_per_launch": hbm,
     "streamed_bytes_per_launch_by_construction": streamed,
