@@ -154,3 +154,27 @@ def test_overflowing_buffers_take_the_exact_pass(ei):
     for i in range(16):
         assert list(out[2][i]) == [0, 1, 2, 3, 4]
     ix.close()
+
+
+def test_clustered_corpus_256_queries_per_launch(ei):
+    """A corpus of tight clusters (intra-cluster cosine ~0.9) with the queries aimed at cluster centres: hundreds of rows lie
+    within the filter's margin of the k-th value, so the select step evaluates hundreds of rows per query in float64 instead of
+    ~2 k; 256 queries ride one launch (two query tiles per wave), k = 64 fills the tournament's rounds."""
+    rng = np.random.default_rng(31)
+    d, nc = 384, 512
+    centres = rng.standard_normal((nc, d)).astype(np.float32)
+    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    docs = centres[rng.integers(0, nc, N)] + np.float32(0.48 / np.sqrt(d)) * rng.standard_normal((N, d)).astype(np.float32)
+    docs /= np.linalg.norm(docs, axis=1, keepdims=True)
+    assert docs.dtype == np.float32
+    qs = (centres[rng.integers(0, nc, 256)] + (0.3 / np.sqrt(d)) * rng.standard_normal((256, d))).astype(np.float64)
+    ix = ei.DeviceIndex.from_host(docs)
+    ix.scan_stats()
+    for metric, k in (("sqeuclidean_dist", 10), ("cosine_sim", 64), ("inner_product", 64), ("euclidean_dist", 10)):
+        out = ix.search(qs, k, metric)
+        assert int(out[5].sum()) == 0, f"{metric}: the sieve needed the exact pass: {out[5]}"
+        for i in (0, 17, 128, 255):
+            check(metric, qs[i], docs, tuple(o[i] for o in out), k, f"clustered {metric} k={k} q={i}")
+    st = ix.scan_stats()
+    assert st["to_exact_pass"] == 0 and st["evaluated_in_float64_per_query"] > 64
+    ix.close()
