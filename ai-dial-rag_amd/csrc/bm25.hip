@@ -22,13 +22,15 @@
 // query order (deterministic rounding, a document occurs at most once per term
 // so no atomics on scores), then selects the tile's top-k from LDS.  HBM traffic
 // per query is the postings of its terms (12 B each), read once, coalesced.
-// Three kernels:
-//   bm25_sparse_kernel  the fast pass: several queries per workgroup, software-
-//                       pipelined; ranks only the positive touched documents
-//   bm25_tile_kernel    the exact dense pass (all 8192 documents of a tile, zeros
-//                       and negatives included) for the queries bm25_merge_kernel
-//                       found short of k positive documents; also get_scores
-//   bm25_merge_kernel   merges the tiles' candidates, flags the short queries
+// The kernels of a search, five dispatches (seven until late in round 3):
+//   bm25_plan_kernel    routes every query: light (one wave per (tile, query) pair) or heavy (the tile kernel)
+//   bm25_wave_kernel    the light queries' fast pass: every touched document with its score into the query's pool slice
+//   bm25_sparse_kernel  the heavy queries' fast pass: several queries per workgroup, software-pipelined; ranks only the
+//                       positive touched documents of a tile
+//   bm25_finish_kernel  per query: the light query's selection over its pool slice / the heavy query's merge of its tiles;
+//                       flags the queries short of k positive documents
+//   bm25_tile_kernel    the exact dense pass (all 8192 documents of a tile, zeros and negatives included) for the flagged
+//                       queries, whose last tile merges them; also get_scores
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -248,17 +250,30 @@ constexpr int kBm25Chunk = 64;     // query terms resolved per metadata round
 constexpr int kBm25Regs = 4;       // postings a thread holds per accumulate round (256*4 per round)
 constexpr int kBm25Cand = 1024;    // distinct touched documents listed per tile (sparse pass)
 
+// the dense fallback's own merge (bm25_tile_kernel's last-arriving workgroup per query); arrive == nullptr: none
+struct DenseMerge {
+    uint32_t *arrive;     // [b], zero at launch
+    int64_t doc_offset, n_docs;
+    int32_t *need_dense;
+    int64_t *out_idx;
+    double *out_score;
+    int32_t *out_count;
+};
+__device__ void bm25_merge_tail(double *part_score, const int32_t *part_idx, const int32_t *part_cnt, int ntiles, int k,
+                                const DenseMerge &dm, int q);
+
 __global__ __launch_bounds__(256) void bm25_tile_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms,
                                                         const int32_t *__restrict__ q_ptr, int k,
                                                         const int32_t *__restrict__ need_dense,
                                                         double *__restrict__ out_scores,
                                                         double *__restrict__ part_score,
                                                         int32_t *__restrict__ part_idx,
-                                                        int32_t *__restrict__ part_cnt) {
+                                                        int32_t *__restrict__ part_cnt, DenseMerge dm) {
     __shared__ double sc[kBm25Tile];
     __shared__ double red_s[4];
     __shared__ int64_t red_i[4];
     __shared__ int red_p[4];
+    __shared__ int s_last;
     __shared__ int64_t m_lo[kBm25Chunk];
     __shared__ double m_idf[kBm25Chunk];
     __shared__ int m_off[kBm25Chunk + 1];
@@ -359,6 +374,16 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(Bm25Dev m, const int32_t
             red_s, red_i, red_p);
         if (tid == 0) *my_cnt = kout;
     }
+    if (!dm.arrive) return;
+    // the fallback launch merges its own tiles: the query's last workgroup to get here (its candidates and everybody else's
+    // are visible behind the fences) does what a second dispatch of bm25_merge_kernel did
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&dm.arrive[q], 1u) == (uint32_t)(m.ntiles - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    bm25_merge_tail(part_score, part_idx, part_cnt, m.ntiles, k, dm, q);
 }
 
 // ---- routing between the two fast passes (bm25_wave_kernel below, one wave per (tile, query); this tile kernel for the
@@ -381,6 +406,7 @@ struct WavePool {
     int32_t *light;    // [b] 1: the query is the wave kernel's
     uint32_t *off;     // [b] its first pool entry
     int32_t *hlist;    // [b] the heavy queries, for bm25_sparse_kernel; hlist[b] = their number
+    uint32_t *arrive;  // [b] dense pass: tiles of the query that have written their candidates (the last one merges them)
     long long capacity;
 };
 __host__ __device__ inline long long wave_pool_capacity(int b, int ntiles) {
@@ -440,6 +466,7 @@ __global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_
             pool.light[q] = light ? 1 : 0;
             pool.off[q] = light ? (uint32_t)at : 0u;
             pool.count[(size_t)q * kWvCountStride] = 0;
+            pool.arrive[q] = 0;
             if (!light) pool.hlist[atomicAdd(&s_nheavy, 1)] = q;  // (any order: a heavy query's tiles are merged by bm25_merge_kernel)
         }
         __syncthreads();
@@ -869,9 +896,9 @@ __global__ __launch_bounds__(64 * kWvWaves) void bm25_wave_kernel(Bm25Dev m, con
 constexpr int kSelList = 2048;
 // grid = b, block = 256: a light query's top k over the candidates of all its tiles (bm25_wave_kernel); flags it for the
 // dense pass when fewer than k documents are positive or a tile overflowed.  Heavy queries: bm25_merge_kernel's.
-__global__ __launch_bounds__(256) void bm25_select_kernel(WavePool pool, int k, int64_t doc_offset, int64_t n_docs,
-                                                          int32_t *__restrict__ need_dense, int64_t *__restrict__ out_idx,
-                                                          double *__restrict__ out_score, int32_t *__restrict__ out_count) {
+__device__ __forceinline__ void bm25_select_body(WavePool pool, int k, int64_t doc_offset, int64_t n_docs,
+                                                 int32_t *__restrict__ need_dense, int64_t *__restrict__ out_idx,
+                                                 double *__restrict__ out_score, int32_t *__restrict__ out_count, TopkLds &L) {
     __shared__ double red_s[4];
     __shared__ int64_t red_i[4];
     __shared__ int red_p[4];
@@ -880,9 +907,7 @@ __global__ __launch_bounds__(256) void bm25_select_kernel(WavePool pool, int k, 
     __shared__ __attribute__((aligned(16))) float s_key[1024];
     __shared__ double l_s[kSelList];
     __shared__ int l_i[kSelList];
-    __shared__ TopkLds L;
     const int tid = threadIdx.x, q = blockIdx.x;
-    if (!pool.light[q]) return;
     const uint32_t word = pool.count[(size_t)q * kWvCountStride];
     const bool overflow = (word >> 31) != 0;
     const int n = (int)(word & 0x7fffffffu);
@@ -982,22 +1007,16 @@ __global__ __launch_bounds__(256) void bm25_select_kernel(WavePool pool, int k, 
 // grid = b, block = 256: merge the tiles' candidates of one query.
 // mode 0: merge the sparse pass and flag the queries that came up short (need_dense[q] = 1);
 // mode 1: merge the dense pass, for the flagged queries only.
-__global__ __launch_bounds__(256) void bm25_merge_kernel(double *__restrict__ part_score,
-                                                         const int32_t *__restrict__ part_idx,
-                                                         const int32_t *__restrict__ part_cnt, int ntiles, int k,
-                                                         int64_t doc_offset, int64_t n_docs, int mode,
-                                                         const int32_t *__restrict__ light, int32_t *__restrict__ need_dense,
-                                                         int64_t *__restrict__ out_idx,
-                                                         double *__restrict__ out_score,
-                                                         int32_t *__restrict__ out_count) {
+__device__ __forceinline__ void bm25_merge_body(double *__restrict__ part_score, const int32_t *__restrict__ part_idx,
+                                                const int32_t *__restrict__ part_cnt, int ntiles, int k, int64_t doc_offset,
+                                                int64_t n_docs, int mode, int q, int32_t *__restrict__ need_dense,
+                                                int64_t *__restrict__ out_idx, double *__restrict__ out_score,
+                                                int32_t *__restrict__ out_count, TopkLds &L) {
     __shared__ double red_s[4];
     __shared__ int64_t red_i[4];
     __shared__ int red_p[4];
     __shared__ int s_total;
-    __shared__ TopkLds L;
-    const int tid = threadIdx.x, q = blockIdx.x;
-    if (mode == 1 && !need_dense[q]) return;
-    if (mode == 0 && light[q]) return;  // bm25_select_kernel's
+    const int tid = threadIdx.x;
     double *ps = part_score + (size_t)q * ntiles * k;
     const int32_t *pi = part_idx + (size_t)q * ntiles * k;
     const int32_t *pc = part_cnt + (size_t)q * ntiles;
@@ -1031,6 +1050,28 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(double *__restrict__ pa
         out_count[q] = kout;
         if (mode == 0) need_dense[q] = (kout < k && (int64_t)kout < n_docs) ? 1 : 0;
     }
+}
+
+__device__ void bm25_merge_tail(double *part_score, const int32_t *part_idx, const int32_t *part_cnt, int ntiles, int k,
+                                const DenseMerge &dm, int q) {
+    __shared__ TopkLds L;
+    bm25_merge_body(part_score, part_idx, part_cnt, ntiles, k, dm.doc_offset, dm.n_docs, 1, q, dm.need_dense, dm.out_idx, dm.out_score,
+                    dm.out_count, L);
+}
+
+// grid = b, block = 256: the end of the fast passes, one dispatch for both kinds of query - a light query's selection over
+// its candidates (bm25_wave_kernel's), a heavy query's merge of its tiles (bm25_sparse_kernel's).  (Two kernels until late
+// in round 3, each returning at once for the other kind: a dispatch is ~5 us of a single query's ~45.)
+__global__ __launch_bounds__(256) void bm25_finish_kernel(WavePool pool, double *__restrict__ part_score,
+                                                          const int32_t *__restrict__ part_idx,
+                                                          const int32_t *__restrict__ part_cnt, int ntiles, int k,
+                                                          int64_t doc_offset, int64_t n_docs, int32_t *__restrict__ need_dense,
+                                                          int64_t *__restrict__ out_idx, double *__restrict__ out_score,
+                                                          int32_t *__restrict__ out_count) {
+    __shared__ TopkLds L;  // (one for both kinds: the block's LDS decides how many queries a CU finishes at a time)
+    const int q = blockIdx.x;
+    if (pool.light[q]) bm25_select_body(pool, k, doc_offset, n_docs, need_dense, out_idx, out_score, out_count, L);
+    else bm25_merge_body(part_score, part_idx, part_cnt, ntiles, k, doc_offset, n_docs, 0, q, need_dense, out_idx, out_score, out_count, L);
 }
 
 // ---- any n (bm25_retriever.py:81-84 takes any n): beyond the 64 results the selection kernels hold, the dense score
@@ -1380,7 +1421,7 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     const int T = h->ntiles;
     if (k <= 0) {  // get_scores: dense score vector only
         bm25_tile_kernel<<<dim3(T, b), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, 0, nullptr, d_scores, nullptr,
-                                                                 nullptr, nullptr);
+                                                                 nullptr, nullptr, DenseMerge{});
         MIR_HIP(hipGetLastError());
         return MIR_OK;
     }
@@ -1395,9 +1436,10 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     pool.light = need + b;
     pool.off = reinterpret_cast<uint32_t *>(pool.light + b);
     pool.hlist = reinterpret_cast<int32_t *>(pool.off + b);
-    pool.count = reinterpret_cast<uint32_t *>(pool.hlist + b + 1);
+    pool.arrive = reinterpret_cast<uint32_t *>(pool.hlist + b + 1);
+    pool.count = pool.arrive + b;
     {
-        size_t o = (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 16 + 4 + (size_t)b * kWvCountStride * 4;
+        size_t o = (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 20 + 4 + (size_t)b * kWvCountStride * 4;
         o = (o + 255) & ~(size_t)255;
         pool.score = reinterpret_cast<double *>(p + o);
         pool.doc = reinterpret_cast<int32_t *>(p + o + (size_t)pool.capacity * 8);
@@ -1419,25 +1461,22 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     bm25_sparse_kernel<<<dim3(T, (b + qc - 1) / qc), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, b, qc, k, pool.hlist, part_score,
                                                                         part_idx, part_cnt);
     MIR_HIP(hipGetLastError());
-    bm25_merge_kernel<<<dim3(b), dim3(256), 0, s>>>(part_score, part_idx, part_cnt, T, k, h->doc_offset, h->n_docs, 0, pool.light, need,
-                                                    d_out_idx, d_out_score, d_out_count);
+    bm25_finish_kernel<<<dim3(b), dim3(256), 0, s>>>(pool, part_score, part_idx, part_cnt, T, k, h->doc_offset, h->n_docs, need, d_out_idx,
+                                                     d_out_score, d_out_count);
     MIR_HIP(hipGetLastError());
-    bm25_select_kernel<<<dim3(b), dim3(256), 0, s>>>(pool, k, h->doc_offset, h->n_docs, need, d_out_idx, d_out_score, d_out_count);
-    MIR_HIP(hipGetLastError());
-    // 2. exact dense pass for the queries with fewer than k positive documents (workgroups of
-    //    the other queries exit at once; usually that is all of them)
-    bm25_tile_kernel<<<dim3(T, b), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, k, need, nullptr, part_score,
-                                                             part_idx, part_cnt);
-    MIR_HIP(hipGetLastError());
-    bm25_merge_kernel<<<dim3(b), dim3(256), 0, s>>>(part_score, part_idx, part_cnt, T, k, h->doc_offset, h->n_docs, 1, pool.light, need,
-                                                    d_out_idx, d_out_score, d_out_count);
+    // 2. exact dense pass for the queries with fewer than k positive documents (workgroups of the other queries exit at
+    //    once; usually that is all of them); a query's last tile merges them
+    DenseMerge dm;
+    dm.arrive = pool.arrive; dm.doc_offset = h->doc_offset; dm.n_docs = h->n_docs; dm.need_dense = need;
+    dm.out_idx = d_out_idx; dm.out_score = d_out_score; dm.out_count = d_out_count;
+    bm25_tile_kernel<<<dim3(T, b), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, k, need, nullptr, part_score, part_idx, part_cnt, dm);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }
 
-// [part_score | part_idx | part_cnt | need, light, off (b each), hlist (b + 1) | count (b x 32) | pool scores | pool documents]
+// [part_score | part_idx | part_cnt | need, light, off (b each), hlist (b + 1), arrive (b) | count (b x 32) | pool scores | pool documents]
 static size_t part_bytes(int b, int T, int k) {
-    size_t o = (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 16 + 4 + (size_t)b * kWvCountStride * 4;
+    size_t o = (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 20 + 4 + (size_t)b * kWvCountStride * 4;
     o = (o + 255) & ~(size_t)255;
     return o + (size_t)wave_pool_capacity(b, T) * 12 + 64;
 }
@@ -1462,7 +1501,8 @@ static int32_t bm25_run_large_k(mir_bm25 *h, const int32_t *d_terms, const int32
     for (int q0 = 0; q0 < b; q0 += chunk) {
         const int nq = std::min(chunk, b - q0);
         // (the tile kernel reads q_ptr[q], q_ptr[q + 1] of query q = blockIdx.y: offset the ptr array, scores land at [0, nq))
-        bm25_tile_kernel<<<dim3(h->ntiles, nq), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr + q0, 0, nullptr, scores, nullptr, nullptr, nullptr);
+        bm25_tile_kernel<<<dim3(h->ntiles, nq), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr + q0, 0, nullptr, scores, nullptr, nullptr, nullptr,
+                                                                   DenseMerge{});
         MIR_HIP(hipGetLastError());
         for (int r = 0; r < rounds; ++r) {
             bm25_dense_topk_kernel<<<dim3(nq), dim3(kDkThreads), 0, s>>>(scores, h->n_docs, k, r, h->doc_offset, q0, bound_s, bound_i, d_out_idx,
