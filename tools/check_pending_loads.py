@@ -24,14 +24,22 @@ def compile_asm(unit: str) -> str:
     """The ISA of <unit>.hip, compiled with EXACTLY the command the Makefile uses for build/<unit>.o (asked of `make -n`),
     plus -save-temps, in a scratch directory."""
     dry = subprocess.run(["make", "-C", CSRC, "-n", "-B", f"build/{unit}.o"], check=True, capture_output=True, text=True).stdout
-    line = next(l for l in dry.splitlines() if "hipcc" in l and f"{unit}.hip" in l)
+    line = next((l for l in dry.splitlines() if f"{unit}.hip" in l and " -c " in l), None)
+    if line is None:
+        raise RuntimeError(f"check_pending_loads: `make -n -B build/{unit}.o` shows no compile command for {unit}.hip:\n{dry}")
     words = line.split()
     cut = words.index("-c")
-    flags = words[1:cut]  # everything between the compiler and `-c <source> -o <object>`
+    first = next(i for i, w in enumerate(words[:cut]) if w.startswith("-"))  # (the compiler may be `ccache hipcc`, an absolute path, ...)
+    compiler, flags = words[:first], words[first:cut]
     with tempfile.TemporaryDirectory() as tmp:
-        cmd = [words[0], *flags, "-I" + CSRC, "-save-temps", "-c", os.path.join(CSRC, unit + ".hip"), "-o", os.devnull]
+        cmd = [*compiler, *flags, "-I" + CSRC, "-save-temps", "-c", os.path.join(CSRC, unit + ".hip"), "-o", os.devnull]
         subprocess.run(cmd, cwd=tmp, check=True, stderr=subprocess.DEVNULL)
-        return open(os.path.join(tmp, unit + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+        import glob
+        found = glob.glob(os.path.join(tmp, unit + "-hip-amdgcn-*.s"))
+        if len(found) != 1:
+            raise RuntimeError(f"check_pending_loads: expected one device ISA file for {unit}.hip, found {found or 'none'} "
+                               f"(command: {' '.join(cmd)})")
+        return open(found[0]).read()
 
 
 def kernel_body(asm: str, needle: str) -> list:
