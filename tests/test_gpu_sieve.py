@@ -178,3 +178,34 @@ def test_clustered_corpus_256_queries_per_launch(ei):
     st = ix.scan_stats()
     assert st["to_exact_pass"] == 0 and st["evaluated_in_float64_per_query"] > 64
     ix.close()
+
+
+def test_concurrent_searches_share_a_handle(ei, corpus):
+    """The reference calls `find` from several executor threads at once (semantic_retriever.py:54-56): eight threads with
+    different batch sizes (one and two query tiles per wave, two launch groups) on one handle, each with its own workspace."""
+    import threading
+
+    docs, qs, _, _ = corpus
+    rng = np.random.default_rng(12)
+    big = rng.standard_normal((300, 384))
+    big[:12] = qs
+    ix = ei.DeviceIndex.from_host(docs)
+    want = ix.search(big, 10, "sqeuclidean_dist")
+    sizes = [1, 7, 64, 128, 129, 200, 256, 300]
+    out, err = [None] * len(sizes), []
+
+    def work(t):
+        try:
+            out[t] = [ix.search(big[: sizes[t]], 10, "sqeuclidean_dist") for _ in range(4)]
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(len(sizes))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not err, err
+    for t, n in enumerate(sizes):
+        for got in out[t]:
+            for a, b in zip(got, want):
+                np.testing.assert_array_equal(a, b[:n])
+    ix.close()
