@@ -45,7 +45,8 @@ namespace mir {
 constexpr int kSieveStages = 6;        // LDS-DMA ring: 6 x 24 KiB at d = 384, five stages in flight
 constexpr int kSieveRegion = 8192;     // candidates a workgroup can write per launch (96 KiB of HBM each)
 constexpr int kSieveQueryCap = 8192;   // candidates listed per query (~55 k of them arrive on a 10M-row shard)
-constexpr int kSieveSelectCap = 1024;  // of which at most this many may need the float64 formula (within 2 mg of the k-th largest v)
+constexpr int kSieveSelectCap = 4096;  // of which at most this many may need the float64 formula (within 2 mg of the k-th largest v):
+                                       // a few dozen as a rule; thousands of near-copies of one row cost a query's block ~1 ms, not the exact pass
 constexpr int kSieveMaxK = 64;
 constexpr int kSieveCountStride = 32;  // a query's append counter has a 128-byte line of its own (43K appends on 4 shared lines took 120 us)
 

@@ -947,6 +947,25 @@ def main():
                           "scan_launch_ms": round(a_ms, 4), "roofline_frac": round(bytes_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                           "frac_streamed_bytes": round(streamed / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         result["batch_sweep"] = sweep
+        # the other metrics of embeddings_metrics.py at the headline batch (north_star names cosine; the index is the same image)
+        others = []
+        for mt in ("cosine_sim", "inner_product", "euclidean_dist", "sqeuclidean_dist"):
+            if mt == args.metric:
+                continue
+            for i in range(5):
+                searcher.search(queries[i * B : (i + 1) * B], k, mt)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(10):
+                searcher.search(queries[i * B : (i + 1) * B], k, mt)
+            barrier()
+            el = time.perf_counter() - t0
+            tm = torch.tensor([el], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+            others.append({"metric": mt, "queries_per_step": B, "qps": round(B * 10 / el, 1), "ms_per_step": round(1e3 * el / 10, 4)})
+        result["metric_sweep"] = others
     index.close()  # release the shard before the other legs allocate theirs
     if args.variants and world == 1:
         for kind in ("clustered", "near_duplicate"):

@@ -146,6 +146,16 @@ def test_overflowing_buffers_take_the_exact_pass(ei):
     for i in (0, 1, 3, 4, 5):  # (numpy's own gemv gives bit-identical rows distances that differ in the last bit, by
         check("sqeuclidean_dist", qs[i], docs, tuple(o[i] for o in out), 10, f"q={i}")  # position: no order to compare for query 2)
     ix.close()
+    # 2 500 copies: every one of them is within the filter's margin of the k-th value and gets the float64 formula - no exact pass
+    docs2 = docs.copy()
+    docs2[same[2500:]] = rng.standard_normal((len(same) - 2500, d)).astype(np.float32)
+    ix = ei.DeviceIndex.from_host(docs2)
+    ix.scan_stats()
+    out = ix.search(qs, 10, "sqeuclidean_dist")
+    assert list(out[5]) == [0] * 6
+    assert list(out[2][2]) == list(same[:10]) and len(set(out[3][2])) == 1
+    assert ix.scan_stats()["evaluated_in_float64_per_query"] > 2500 / 6
+    ix.close()
     docs[:] = docs[0]
     ix = ei.DeviceIndex.from_host(docs)
     q16 = rng.standard_normal((16, d))  # 16 x 600 000 candidates over 256 regions of 8192: the regions overflow too
