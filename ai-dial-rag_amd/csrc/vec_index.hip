@@ -869,7 +869,8 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
             static const int two_phase_tiles = getenv("MIR_SIEVE_TWO_PHASE_TILES") ? atoi(getenv("MIR_SIEVE_TWO_PHASE_TILES")) : 64;
             static const int single_tpw = getenv("MIR_SIEVE_SAMPLE_TPW") ? atoi(getenv("MIR_SIEVE_SAMPLE_TPW")) : kSampleTilesPerWg;
             const bool two = (int64_t)ix->n_tiles >= (int64_t)two_phase_tiles * wgs;
-            pl->tiles_first = two ? std::max<uint32_t>(ix->n_tiles / 16, std::min<uint32_t>(ix->n_tiles / 4, 4896u)) : 0;
+            static const uint32_t first_div = getenv("MIR_SIEVE_FIRST_DIV") ? (uint32_t)atoi(getenv("MIR_SIEVE_FIRST_DIV")) : 16u;  // (experiments)
+            pl->tiles_first = two ? std::max<uint32_t>(ix->n_tiles / first_div, std::min<uint32_t>(ix->n_tiles / 4, 4896u)) : 0;
             pl->sample_tpw = std::max<uint32_t>(1, std::min<uint32_t>(two ? kSampleTilesPerWg : single_tpw, ix->n_tiles / (4u * kSampleWgs)));
             return MIR_OK;
         }

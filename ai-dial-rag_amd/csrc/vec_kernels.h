@@ -205,6 +205,8 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const T *__restrict__ sr
         inv_norm[row] = 1.0f / fmaxf((float)sqrt(s), 1e-8f);
     }
     // wave max, then one atomic per wave (positive floats order as uints)
+    // word 1: some row holds a NaN or an infinity (fmaxf drops a NaN: the maximum alone would not tell)
+    if (__ballot(!(nrm < __builtin_inff())) != 0ull && (threadIdx.x & 63) == 0) atomicOr(max_norm_bits + 1, 1u);
     for (int off = 32; off >= 1; off >>= 1) nrm = fmaxf(nrm, __shfl_xor(nrm, off, 64));
     if ((threadIdx.x & 63) == 0 && nrm > 0.f) atomicMax(max_norm_bits, __float_as_uint(nrm));
 }
@@ -260,6 +262,8 @@ __global__ __launch_bounds__(256) void row_norms_lds_kernel(const T *__restrict_
             inv_norm[row] = 1.0f / fmaxf((float)sqrt(s), 1e-8f);
         }
     }
+    // word 1: some row holds a NaN or an infinity (fmaxf drops a NaN: the maximum alone would not tell)
+    if (__ballot(!(nrm < __builtin_inff())) != 0ull && (threadIdx.x & 63) == 0) atomicOr(max_norm_bits + 1, 1u);
     for (int off = 32; off >= 1; off >>= 1) nrm = fmaxf(nrm, __shfl_xor(nrm, off, 64));
     if ((threadIdx.x & 63) == 0 && nrm > 0.f) atomicMax(max_norm_bits, __float_as_uint(nrm));
 }

@@ -37,7 +37,14 @@
 #include "vec_kernels_h16.h"
 
 #ifndef SIEVE_ABL
-#define SIEVE_ABL 0  // measurement builds only (tools/run_vec_variants.sh): 1 = half the MFMAs, 2 = half the LDS fragment reads
+#define SIEVE_ABL 0  // measurement builds only (tools/run_vec_variants.sh; results are wrong, only the time means something): 1 = half the
+                     // MFMAs, 3 = no DMA after the prologue, 4 = no filter, 5 = no barrier
+#endif
+#ifndef SIEVE_MAX3
+#define SIEVE_MAX3 1  // 0 = the eight-compare form of the filter's common path on every index (measurement builds)
+#endif
+#ifndef SIEVE_PREFETCH
+#define SIEVE_PREFETCH 2  // k-steps a fragment pair is requested from LDS ahead of its MFMAs
 #endif
 
 namespace mir {
@@ -88,14 +95,18 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     // T - mg (with the float32 rounding of v itself)
     int qloc[QT];
     bool lane_live[QT];
+    unsigned long long live_mask[QT];
     float mg[QT], bound[QT], guard[QT], best[QT];
     bf16x8 qh[QT][KS32];
     const bool active = nq > wave8 * QT * 16;  // (the wave's first tile has queries)
+    // (word 1 of the index's norm statistics: a row with a NaN or an infinity was seen at build time)
+    const bool finite_rows = __builtin_amdgcn_readfirstlane(__float_as_uint(max_norm[1])) == 0u;
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         const int t16 = wave8 * QT + u;
         qloc[u] = t16 * 16 + qc;
         lane_live[u] = qloc[u] < nq;
+        live_mask[u] = __builtin_amdgcn_ballot_w64(lane_live[u]);
         mg[u] = 0.f; bound[u] = -__builtin_inff(); guard[u] = __builtin_inff(); best[u] = -__builtin_inff();
         if (lane_live[u]) {
             const float qn = (float)q_norm[qloc[u]] * (1.0f + 1e-6f);
@@ -139,6 +150,9 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     for (uint32_t g = 0; g < (uint32_t)D && g < NG; ++g) issue(g);
 
     auto wait_stage = [&](uint32_t g) {  // stage g has landed: all but the younger stages' operations are done
+#if SIEVE_ABL == 3
+        return;
+#endif
         const uint32_t younger = (NG - 1 - g) < (uint32_t)(D - 1) ? (NG - 1 - g) : (uint32_t)(D - 1);
         if (younger == (uint32_t)(D - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only in the last D - 1 stages of the launch
@@ -172,11 +186,25 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         // one compare per value, their results OR-ed as lane masks (scalar unit): beside the MFMAs every vector instruction
         // of the common path costs matrix-pipe issue slots
         const float bnd = KIND == SCAN_L2 ? 0.5f * bound[u] : bound[u];
-        bool pass = false;
+        if (SIEVE_MAX3 && finite_rows) {
+            // no row of the index holds a NaN or an infinity (its largest norm is finite): a value is NaN only if the QUERY is,
+            // and then all eight are - the maximum of the eight (v_max3: a NaN operand is ignored) decides: four instructions and
+            // one compare into a scalar mask.  (As C++ the maxima came with a canonicalising v_max x, x per input.)
+            float m1, m2, m3, m;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(v[3]), "v"(v[4]), "v"(v[5]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(v[6]), "v"(v[7]), "v"(m1));
+            asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m2), "v"(m3));
+            unsigned long long mk;
+            asm("v_cmp_nlt_f32 %0, %1, %2" : "=s"(mk) : "v"(m), "v"(bnd));
+            if ((mk & live_mask[u]) == 0ull) return;
+        } else {
+            bool pass = false;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pass |= !(v[r] < bnd);  // NaN passes; no bound yet: everything passes
-        pass &= lane_live[u];
-        if (!__any(pass)) return;
+            for (int r = 0; r < 8; ++r) pass |= !(v[r] < bnd);  // NaN passes; no bound yet: everything passes
+            pass &= lane_live[u];
+            if (__builtin_amdgcn_ballot_w64(pass) == 0ull) return;
+        }
         asm volatile("" : "+s"(t));  // (everything below depends on t: hipcc must not compute the rare path's row masks ahead of the branch)
         if (KIND == SCAN_L2) {
 #pragma unroll
@@ -223,15 +251,18 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     for (uint32_t g = 0; g < my_tiles; ++g) {
         const uint32_t t = tile0 + blockIdx.x + g * G;
         wait_stage(g);
+#if SIEVE_ABL != 5
         __builtin_amdgcn_s_barrier();   // every wave's pieces of stage g are in; everybody has left stage g - 1's slot
+#endif
         if (!active) {
             if (g + D < NG) issue(g + D);
             continue;
         }
         const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + lane;
-        uint4 f0[3], f1[3];
-        f0[0] = st[0 * 64]; f1[0] = st[1 * 64];
-        f0[1] = st[2 * 64]; f1[1] = st[3 * 64];
+        constexpr int PF = SIEVE_PREFETCH;  // fragment pairs requested ahead of the k-step that multiplies them
+        uint4 f0[PF + 1], f1[PF + 1];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) { f0[i] = st[(2 * i + 0) * 64]; f1[i] = st[(2 * i + 1) * 64]; }
         float cax[8] = {};
         if (AUX) {  // rows 16 rh + 4 jg + i of this tile
             const float4 a0 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * kTileRows + 4 * jg);
@@ -252,41 +283,37 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         }
 #pragma unroll
         for (int s = 0; s < KS32; ++s) {
-#if SIEVE_ABL == 2  // half of the LDS reads (every fragment used twice), all MFMAs
-            if (s + 2 < KS32 && !(s & 1)) {
-                f0[(s + 2) % 3] = st[(2 * (s + 2) + 0) * 64];
-                f1[(s + 2) % 3] = st[(2 * (s + 2) + 1) * 64];
-            } else if (s + 2 < KS32) {
-                f0[(s + 2) % 3] = f0[(s + 1) % 3];
-                f1[(s + 2) % 3] = f1[(s + 1) % 3];
+            if (s + PF < KS32) {
+                f0[(s + PF) % (PF + 1)] = st[(2 * (s + PF) + 0) * 64];
+                f1[(s + PF) % (PF + 1)] = st[(2 * (s + PF) + 1) * 64];
             }
-#else
-            if (s + 2 < KS32) {
-                f0[(s + 2) % 3] = st[(2 * (s + 2) + 0) * 64];
-                f1[(s + 2) % 3] = st[(2 * (s + 2) + 1) * 64];
-            }
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #if SIEVE_ABL == 1  // half of the MFMAs, all LDS reads
             if (!(s & 1)) {
 #endif
 #pragma unroll
             for (int u = 0; u < QT; ++u) {
-                c0[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0[s % 3]), qh[u][s], c0[u], 0, 0, 0);
-                c1[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1[s % 3]), qh[u][s], c1[u], 0, 0, 0);
+                c0[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0[s % (PF + 1)]), qh[u][s], c0[u], 0, 0, 0);
+                c1[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1[s % (PF + 1)]), qh[u][s], c1[u], 0, 0, 0);
             }
 #if SIEVE_ABL == 1
             }
 #endif
             if (s == 1) {  // the next stage's DMA once the matrix pipe has work queued
                 __builtin_amdgcn_sched_barrier(0);
+#if SIEVE_ABL != 3
                 if (g + D < NG) issue(g + D);
+#endif
             }
 #pragma unroll
             for (int u = 0; u < QT; ++u)
                 if (s == 2 + u && have_prev) {  // the previous tile's filter, one query tile per k-step
                     __builtin_amdgcn_sched_barrier(0);
+#if SIEVE_ABL != 4
                     filter(u, p0[u], p1[u], pax, pt);
+#else
+                    if (g == 0xffffff) filter(u, p0[u], p1[u], pax, pt);
+#endif
                 }
         }
 #pragma unroll
