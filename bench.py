@@ -3,9 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one batch of B synthetic queries: the
-fused scan + top-k over this rank's row shard, float64 re-score, and (N > 1)
-one RCCL all-gather of per-shard partial top-k plus a local merge.  The index
+A step = one pass of the hot path over one batch of B synthetic queries (256 by
+default: one launch group of the sieve): the filter over this rank's row shard,
+the float64 reference formula for the rows that can be among the first k, their
+reference order, and (N > 1) one RCCL all-gather of per-shard partial top-k plus
+a local merge.  The index
 and the queries are resident in HBM before the timed region.  The total index
 is fixed at --rows as N grows ("strong" scaling: the shard is rows / N).
 Before the W warm-up steps the same step runs untimed until 12 launches have
@@ -42,7 +44,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=256,
                     help="queries per step (B).  One pass of the shard serves up to 256 queries (two 16-query tiles per wave): the "
-                         "stream is the same as for 128, the matrix work doubles, so 256 gives the most QPS (~120k; 128: ~89k; 64: ~50k); "
+                         "stream is the same as for 128, the matrix work doubles, so 256 gives the most QPS (~137k; 128: ~95k; 64: ~52k); "
                          "the sweep reports the others")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="sqeuclidean_dist")
