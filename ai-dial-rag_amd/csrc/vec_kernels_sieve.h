@@ -7,7 +7,7 @@
 // correction, no list and no compaction at all:
 //
 //   filter   sieve_q16_kernel: v = hi*hi value of (row, query) in the scan's ranking units.  With
-//            |true value - v| <= mg = 4e-3*|x||q| (kHiHiRelErr, worst case), a row whose true value reaches a
+//            |true value - v| <= mg = 8e-3*|x||q| (kHiHiRelErr, worst case), a row whose true value reaches a
 //            threshold T has v >= T - mg.  Every (row, query) with !(v < T - mg) is written out as a CANDIDATE
 //            (row, query, v: 12 bytes; ~4e-5 of the pairs with the thresholds below) - a superset of all rows at or above T.
 //   scatter  sieve_scatter_kernel: the candidates, written per workgroup, are appended to their queries' lists.

@@ -219,3 +219,51 @@ def test_concurrent_searches_share_a_handle(ei, corpus):
             for a, b in zip(got, want):
                 np.testing.assert_array_equal(a, b[:n])
     ix.close()
+
+
+def test_worst_case_bf16_rounding(ei):
+    """The filter's margin must cover bfloat16's WORST case, u = 2^-8 per operand, not the error of random data.  Rows A
+    sit with all their mass on coordinates where row and query round DOWN (hi.hi under-states x.q by 0.77 %), decoy rows D
+    on coordinates where both round UP (over-stated by 0.79 %), and D's true product is just BELOW A's: a margin of
+    4e-3 |x||q| (this constant until late in round 3) drops the A rows - the true first five - behind 64 decoys."""
+    rng = np.random.default_rng(21)
+    d, h = 384, 192
+    down = np.float32((1 + 2.0**-8 * (1 - 2.0**-6)) * 2.0**-4)   # bf16 -> 2^-4
+    up = np.float32((1 + 2.0**-8 * (1 + 2.0**-6)) * 2.0**-4)     # bf16 -> (1 + 2^-7) 2^-4
+    q = np.zeros(d)
+    q[:h], q[h:] = float(down), float(up)
+    a_row = np.zeros(d, np.float32)
+    a_row[:h] = down
+    d_row = np.zeros(d, np.float32)
+    d_row[h:] = up
+    tv_a = float(a_row.astype(np.float64) @ q)
+    d_row[h] = np.float32((tv_a * (1 - 2e-4) - 191 * float(up) ** 2) / float(up))  # D's product: 2e-4 below A's
+    tv_d = float(d_row.astype(np.float64) @ q)
+    assert tv_d < tv_a < tv_d * 1.001
+
+    def bf16(x):
+        u = np.asarray(x, np.float32).view(np.uint32)
+        return ((u + (((u >> 16) & 1) + 0x7FFF)) & 0xFFFF0000).view(np.float32).astype(np.float64)
+
+    v_a, v_d = float(bf16(a_row) @ bf16(q.astype(np.float32))), float(bf16(d_row) @ bf16(q.astype(np.float32)))
+    scale = np.linalg.norm(q) * max(np.linalg.norm(a_row), np.linalg.norm(d_row))
+    assert 2 * 4.0e-3 * scale < v_d - v_a < 2 * 7.8e-3 * scale  # (beyond what 4e-3 covers, within the true bound)
+
+    docs = rng.standard_normal((N, d)).astype(np.float32)
+    docs *= np.float32(0.4) / np.linalg.norm(docs, axis=1, keepdims=True)
+    pos = np.sort(rng.choice(N, 69, replace=False))
+    a_pos = pos[[3, 20, 33, 50, 64]]           # spread over both filter launches
+    d_pos = np.setdiff1d(pos, a_pos)
+    docs[d_pos] = d_row
+    docs[a_pos] = a_row
+    qs = rng.standard_normal((8, d)) * 0.06
+    qs[1] = q
+    qs[6] = q
+    ix = ei.DeviceIndex.from_host(docs)
+    for metric in ("inner_product", "cosine_sim", "sqeuclidean_dist"):
+        out = ix.search(qs, 10, metric)
+        assert int(out[5].sum()) == 0
+        for i in range(len(qs)):
+            check(metric, qs[i], docs, tuple(o[i] for o in out), 10, f"worst case {metric} q={i}")
+    assert list(ix.search(qs, 10, "inner_product")[2][1][:5]) == list(a_pos)
+    ix.close()
