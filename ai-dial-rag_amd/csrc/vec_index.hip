@@ -823,7 +823,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     FinalizeArgs fa;
     fa.part = sb.part; fa.nwg = nwg; fa.qpw = qpw; fa.klist = klist; fa.k = k; fa.b = b; fa.d = d; fa.metric = metric;
     fa.docs = ix->d_orig; fa.docs16 = ix->d_f16; fa.doc_sq = ix->d_docsq; fa.max_norm = ix->d_maxnorm;
-    fa.scan_rel_err = ix->native16 ? kH16RelErr : kScanRelErr;  // the bound of the scan whose values the lists hold
+    fa.scan_rel_err = ix->native16 ? kH16RelErr : scan_rel_err(d);  // the bound of the scan whose values the lists hold
     fa.q = dq; fa.q_sq = sb.q_sq; fa.q_norm = sb.q_norm;
     fa.chunk_ids = ix->d_chunk; fa.doc_ids = ix->d_doc; fa.row_offset = ix->row_offset;
     fa.out_doc = o_doc; fa.out_chunk = o_chunk; fa.out_row = o_row; fa.out_dist = o_dist;

@@ -43,9 +43,10 @@ constexpr int kMaxList = 64;         // per-lane candidate list cap (LDS: 64*256
 constexpr int kListMargin = 8;       // klist = k + margin
 constexpr int kSortN = 8192;         // finalize: LDS bitonic width (64 KiB)
 // bound on |scan dot - exact dot| / (|d||q|) of the three-product scans (hi.hi + hi.lo + lo.hi of x = hi + lo + r, |lo| <= u |x|,
-// |r| <= u^2 |x|, u = 2^-8): the missing lo.lo and the two residuals are 3 u^2 = 4.6e-5, the float32 accumulation of K <= 1024
-// products < 2.4e-5 (until late in round 3: 2e-5, from u = 2^-9)
-constexpr double kScanRelErr = 7e-5;
+// |r| <= u^2 |x|, u = 2^-8): the missing lo.lo and the two residuals are 3 u^2 = 4.6e-5, plus the float32 accumulation of the
+// K products, K * 2^-24 of sum |x_i q_i| at worst (scan_rel_err()).  (Until late in round 3: 2e-5 flat, from u = 2^-9.)
+constexpr double kScanSplitErr = 4.6e-5;
+__host__ __device__ constexpr double scan_rel_err(int d) { return kScanSplitErr + 6.0e-8 * (d < 384 ? 384 : d); }
 
 enum ScanKind { SCAN_IP = 0, SCAN_L2 = 1, SCAN_COS = 2 };
 
@@ -850,7 +851,7 @@ struct FinalizeArgs {
     const _Float16 *docs16; // f16 [n][d] (float16-native index)
     const float *doc_sq;    // f32 [n]
     const float *max_norm;  // 1 float
-    double scan_rel_err;    // bound on |list value's dot - exact dot| / (|d||q|): kScanRelErr, or the hi-only float16 scan's
+    double scan_rel_err;    // bound on |list value's dot - exact dot| / (|d||q|): scan_rel_err(d), or the hi-only float16 scan's
     const double *q;        // [b][d]
     const double *q_sq;     // [b]
     const double *q_norm;   // [b]

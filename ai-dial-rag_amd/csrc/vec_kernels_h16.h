@@ -8,7 +8,7 @@
 // 2^-11 |x||q| (+ the float32 accumulation).  That is useless as a result and fine for a FILTER: every value in the
 // candidate lists is the hi-only value, the thresholds are in the same units, so the lists hold exactly the klist best
 // rows BY THAT VALUE, and finalize_kernel's completeness check runs with the bound that belongs to it (kH16RelErr
-// instead of kScanRelErr): a query whose k-th and klist-th candidates are closer than the bound goes to the exact
+// instead of scan_rel_err(d)): a query whose k-th and klist-th candidates are closer than the bound goes to the exact
 // pass like any other unproven query.  (For float32 rows the same idea with bf16 - bound 1.7e-3 - flagged a query of
 // nearly every batch; at 2^-11 the bound is a tenth of the gap between the 10th and the 18th best of 6.25M x 1024
 // random rows.)  Half the MFMAs of the old kernel per byte, no correction pass, 128 queries per pass instead of 64.

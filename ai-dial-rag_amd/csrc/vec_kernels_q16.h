@@ -13,7 +13,7 @@
 // queries was), so it has the complete hi*hi score in the stage that streams the tile's hi blocks and runs the
 // corrections - in the next stage, which streams the tile's lo blocks - only if some lane's score + margin reaches
 // its threshold (a wave-uniform vote).  Every value that enters a candidate list is still the full bf16x3 sum, so the
-// lists, the completeness check of finalize_kernel and its bound (kScanRelErr) are unchanged.  The 16x16x32 shape also holds a
+// lists, the completeness check of finalize_kernel and its bound (scan_rel_err) are unchanged.  The 16x16x32 shape also holds a
 // higher clock than 32x32x16 under load (MI355X_MICROARCH.md, DVFS give-back item 7).
 //
 // Index image ("layout16", built by pack_split16_f32_kernel for d padded to 128 / 256 / 384): per 32-row tile, first

@@ -148,7 +148,8 @@ def test_overflowing_buffers_take_the_exact_pass(ei):
     ix.close()
     # 2 500 copies: every one of them is within the filter's margin of the k-th value and gets the float64 formula - no exact pass
     docs2 = docs.copy()
-    docs2[same[2500:]] = rng.standard_normal((len(same) - 2500, d)).astype(np.float32)
+    fresh = rng.standard_normal((len(same) - 2500, d)).astype(np.float32)
+    docs2[same[2500:]] = fresh / np.linalg.norm(fresh, axis=1, keepdims=True)  # (unit rows: the margin scales with the index's LARGEST norm)
     ix = ei.DeviceIndex.from_host(docs2)
     ix.scan_stats()
     out = ix.search(qs, 10, "sqeuclidean_dist")
