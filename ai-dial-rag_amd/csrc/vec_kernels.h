@@ -92,6 +92,13 @@ __device__ __forceinline__ double wave_sum(double x) {
     for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
     return x;
 }
+// the same butterfly over aligned groups of W lanes (W = 64: wave_sum)
+template <int W>
+__device__ __forceinline__ double group_sum(double x) {
+#pragma unroll
+    for (int off = W / 2; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
 
 // ---------------------------------------------------------------- index build
 
@@ -654,62 +661,63 @@ __global__ __launch_bounds__(256, 1) void scan_topk_generic_kernel(const uint4 *
 //   cosine_sim       embeddings_metrics.py:28-31  torch: unit doc row rounded to f32
 //                                                 (norm and division in f32), query unit in f64
 // `rank_value` returns the quantity the scan ranks by, in the scan's units.
-template <typename T>
+template <typename T, int W = 64>
 __device__ __forceinline__ double exact_metric_wave(const T *__restrict__ row, const double *__restrict__ q,
                                                     int d, int metric, float doc_sq32, double q_sq,
                                                     double q_norm, int lane, double *rank_value) {
-    // Lane l takes elements l, l + 64, ... in that order.  Eight of them are loaded before the first is used:
+    // W lanes (a whole wave, or an aligned group of 16: `lane` = the lane's index in its group, groups work on different rows)
+    // share a row: lane l takes elements l, l + W, ... in that order.  Eight of them are loaded before the first is used:
     // written load-by-use, every element of a (cold) row was its own exposed HBM round trip.
     constexpr int U = 8;
     if (metric == MIR_METRIC_COSINE_SIM) {
         double s = 0.0;
-        for (int j0 = lane; j0 < d; j0 += 64 * U) {
+        for (int j0 = lane; j0 < d; j0 += W * U) {
             float v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = j0 + 64 * u < d ? (float)row[j0 + 64 * u] : 0.f;
+            for (int u = 0; u < U; ++u) v[u] = j0 + W * u < d ? (float)row[j0 + W * u] : 0.f;
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (j0 + 64 * u < d) {
+                if (j0 + W * u < d) {
                     const double x = (double)v[u];
                     s += x * x;
                 }
         }
-        s = wave_sum(s);
+        s = group_sum<W>(s);
         const float dn = fmaxf((float)sqrt(s), 1e-8f);
         const double qn = fmax(q_norm, 1e-8);
         double c = 0.0;
-        for (int j0 = lane; j0 < d; j0 += 64 * U) {
+        for (int j0 = lane; j0 < d; j0 += W * U) {
             float v[U];
             double qv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool in = j0 + 64 * u < d;
-                v[u] = in ? (float)row[j0 + 64 * u] : 0.f;
-                qv[u] = in ? q[j0 + 64 * u] : 0.0;
+                const bool in = j0 + W * u < d;
+                v[u] = in ? (float)row[j0 + W * u] : 0.f;
+                qv[u] = in ? q[j0 + W * u] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (j0 + 64 * u < d) c += (double)__fdiv_rn(v[u], dn) * (qv[u] / qn);
+                if (j0 + W * u < d) c += (double)__fdiv_rn(v[u], dn) * (qv[u] / qn);
         }
-        c = wave_sum(c);
+        c = group_sum<W>(c);
         *rank_value = c * qn;
         return -c;
     }
     double dot = 0.0;
-    for (int j0 = lane; j0 < d; j0 += 64 * U) {
+    for (int j0 = lane; j0 < d; j0 += W * U) {
         float v[U];
         double qv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool in = j0 + 64 * u < d;
-            v[u] = in ? (float)row[j0 + 64 * u] : 0.f;
-            qv[u] = in ? q[j0 + 64 * u] : 0.0;
+            const bool in = j0 + W * u < d;
+            v[u] = in ? (float)row[j0 + W * u] : 0.f;
+            qv[u] = in ? q[j0 + W * u] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (j0 + 64 * u < d) dot += (double)v[u] * qv[u];
+            if (j0 + W * u < d) dot += (double)v[u] * qv[u];
     }
-    dot = wave_sum(dot);
+    dot = group_sum<W>(dot);
     if (metric == MIR_METRIC_INNER_PRODUCT) {
         *rank_value = dot;
         return -dot;

@@ -51,7 +51,7 @@ namespace mir {
 
 constexpr int kSieveStages = 6;        // LDS-DMA ring: 6 x 24 KiB at d = 384, five stages in flight
 constexpr int kSieveRegion = 8192;     // candidates a workgroup can write per launch (96 KiB of HBM each)
-constexpr int kSieveQueryCap = 8192;   // candidates listed per query (~55 k of them arrive on a 10M-row shard)
+constexpr int kSieveQueryCap = 16384;  // candidates listed per query (~120 k of them arrive on a 10M-row shard; k = 64 lists ~6 600)
 constexpr int kSieveSelectCap = 4096;  // of which at most this many may need the float64 formula (within 2 mg of the k-th largest v):
                                        // a few dozen as a rule; thousands of near-copies of one row cost a query's block ~1 ms, not the exact pass
 constexpr int kSieveMaxK = 64;
@@ -686,16 +686,20 @@ struct SieveSelectArgs {
 // Rows that may be NaN under euclidean_dist (v + mg reaches |q|^2: sqrt of a negative residue, sorts LAST) count for nothing
 // in kv and are always evaluated: a row identical to the query may as well be the best one.
 __host__ __device__ constexpr size_t sieve_select_lds_bytes() {
-    return (size_t)kSieveQueryCap * 8 + 16 + (size_t)kSieveSelectCap * 10;
+    // s_v f32 [QueryCap + 4] | s_d f64 [SelectCap] | s_x f32 [SelectCap] | s_row u32 [SelectCap] | s_fin u16 [SelectCap] | part u32 [16][64]
+    return (size_t)kSieveQueryCap * 4 + 16 + (size_t)kSieveSelectCap * 18 + 16 * 64 * 4;
 }
 constexpr int kSieveSelectThreads = 1024;
 __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(SieveSelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sel_lds[];
+    constexpr size_t kOffD = (size_t)kSieveQueryCap * 4 + 16;
     float *s_v = reinterpret_cast<float *>(sel_lds);                                             // [kSieveQueryCap + 4] -inf: may be NaN / padding
-    uint32_t *s_r = reinterpret_cast<uint32_t *>(sel_lds + (size_t)kSieveQueryCap * 4 + 16);      // [kSieveQueryCap]
-    double *s_d = reinterpret_cast<double *>(sel_lds + (size_t)kSieveQueryCap * 8 + 16);          // [kSieveSelectCap]
-    uint16_t *s_fin = reinterpret_cast<uint16_t *>(sel_lds + (size_t)kSieveQueryCap * 8 + 16 + (size_t)kSieveSelectCap * 8);  // [kSieveSelectCap]
-    __shared__ int s_ns, s_f, s_slot, s_have;
+    double *s_d = reinterpret_cast<double *>(sel_lds + kOffD);                                    // [kSieveSelectCap] reference distances
+    float *s_x = reinterpret_cast<float *>(sel_lds + kOffD + (size_t)kSieveSelectCap * 8);        // [kSieveSelectCap]
+    uint32_t *s_row = reinterpret_cast<uint32_t *>(sel_lds + kOffD + (size_t)kSieveSelectCap * 12);  // [kSieveSelectCap] rows of s_fin's entries
+    uint16_t *s_fin = reinterpret_cast<uint16_t *>(sel_lds + kOffD + (size_t)kSieveSelectCap * 16);  // [kSieveSelectCap] list entries worth evaluating
+    uint32_t *part = reinterpret_cast<uint32_t *>(sel_lds + kOffD + (size_t)kSieveSelectCap * 18);   // [16][64]
+    __shared__ int s_ns, s_f, s_f1, s_slot, s_have, s_nn;
     __shared__ float s_kv;
     constexpr int NT = kSieveSelectThreads;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
     const uint32_t *lr = a.l.row + (size_t)qi * kSieveQueryCap;
     const float *lv = a.l.rv + (size_t)qi * kSieveQueryCap;
     const bool over = a.l.over[qi] != 0;
-    if (tid == 0) { s_ns = 0; s_f = 0; s_have = 0; }
+    if (tid == 0) { s_ns = 0; s_f = 0; s_f1 = 0; s_have = 0; s_nn = 0; }
     __syncthreads();
     auto to_exact_pass = [&]() {  // (whole block)
         if (a.mode != 1) return;
@@ -723,6 +727,29 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
         to_exact_pass();
         return;
     }
+    // the k-th largest of vals[0..m) (entries of -inf do not count; the caller knows at least k count), for the whole block:
+    // every wave extracts the k largest of its share (k rounds of a wave maximum that removes one instance), wave 0 the k
+    // largest of those.  (Counting, for every entry, the entries above it was 23 us for 340 entries and 0.9 ms for 3900 at k = 64.)
+    auto kth_largest = [&](const float *vals, int m) -> float {
+        __syncthreads();
+        if (m <= NT) sieve_wave_topk<1>(vals, m, a.k, tid, NT, part + wave * 64);
+        else sieve_wave_topk<kSieveQueryCap / kSieveSelectThreads>(vals, m, a.k, tid, NT, part + wave * 64);
+        __syncthreads();
+        if (wave == 0) {
+            const int nw = m <= NT ? (m + 63) / 64 : NT / 64;   // waves that held entries
+            uint32_t r[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = j * 64 + lane;  // (wave i / k, its i % k-th largest)
+                r[j] = i < nw * a.k ? part[(i / a.k) * 64 + i % a.k] : 0u;
+            }
+            uint32_t wm = 0;
+            for (int t = 0; t < a.k; ++t) wm = sieve_extract_max<16>(r, lane);
+            if (lane == 0) s_kv = unorderable(wm);
+        }
+        __syncthreads();
+        return s_kv;
+    };
     const float qn = (float)a.q_norm[qi] * (1.0f + 1e-6f);
     const float mg = a.rel_err * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) *
                      (a.metric == MIR_METRIC_INNER_PRODUCT || a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : 2.0f);  // (as the filter's)
@@ -739,37 +766,15 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
             const float v = lv[e];
             safe = v + mg < guard && v > -__builtin_inff();
             s_v[e] = safe ? v : -__builtin_inff();
-            s_r[e] = lr[e];
         }
         const unsigned long long bal = __ballot(safe);
         if (bal && lane == __builtin_ctzll(bal)) atomicAdd(&s_ns, __popcll(bal));
     }
     __syncthreads();
     const int ns = s_ns;
-    // ---- 1. kv = the k-th largest of the safe values, by a tournament: every wave extracts the k largest of its share (k rounds
-    //         of a wave maximum that removes one instance), wave 0 then extracts the k largest of those.  (Counting, for every
-    //         entry, the entries above it was 23 us for 340 entries and 0.9 ms for 3900 at k = 64.)
-    if (ns >= a.k) {
-        uint32_t *part = reinterpret_cast<uint32_t *>(s_d);  // [16][64] (s_d is not in use yet)
-        if (n <= NT) sieve_wave_topk<1>(s_v, n, a.k, tid, NT, part + wave * 64);
-        else sieve_wave_topk<kSieveQueryCap / kSieveSelectThreads>(s_v, n, a.k, tid, NT, part + wave * 64);
-        __syncthreads();
-        if (wave == 0) {
-            const int nw = n <= NT ? (n + 63) / 64 : NT / 64;   // waves that held entries
-            uint32_t r[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int i = j * 64 + lane;  // (wave i / k, its i % k-th largest)
-                r[j] = i < nw * a.k ? part[(i / a.k) * 64 + i % a.k] : 0u;
-            }
-            uint32_t wm = 0;
-            for (int t = 0; t < a.k; ++t) wm = sieve_extract_max<16>(r, lane);
-            if (lane == 0) { s_kv = unorderable(wm); s_have = 1; }
-        }
-    }
-    __syncthreads();
-    const bool have = s_have != 0;
-    const float kv = have ? s_kv : 0.f;
+    // ---- 1. kv = the k-th largest of the safe values
+    const bool have = ns >= a.k;
+    const float kv = have ? kth_largest(s_v, n) : 0.f;
     if (a.mode == 0) {
         if (have && tid == 0) {
             const float thr = kv - mg - 4e-6f * fabsf(kv);
@@ -779,46 +784,130 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
         if (tid == 0) atomicAdd(a.stats + 4, (unsigned long long)n);  // entries listed after launch 1
         return;
     }
-    // ---- 2. the rows that can be among the first k: v >= kv - 2 mg, the ones that may be NaN, everything without a kv
+    // ---- 2. the rows that can be among the first k.  Class 1: v >= kv (at least k of them), the ones that may be NaN, and
+    //         everything when there is no kv - always evaluated.  Class 2: kv - 2 mg <= v < kv - evaluated only if class 1's
+    //         exact values leave them a chance (step 3).  s_fin = class 1, then class 2.
     const float cut = have ? kv - 2.0f * mg - 1e-5f * fabsf(kv) - 1e-6f * mg : -__builtin_inff();
-    for (int e0 = 0; e0 < n; e0 += NT) {
-        const int e = e0 + tid;
-        bool fin = false;
-        if (e < n) {
-            const float v = s_v[e];
-            fin = !(v > -__builtin_inff()) || !(v < cut);
+    auto compact = [&](int cls, int *counter) {
+        for (int e0 = 0; e0 < n; e0 += NT) {
+            const int e = e0 + tid;
+            bool fin = false;
+            if (e < n) {
+                const float v = s_v[e];
+                const bool c1 = !have || !(v > -__builtin_inff()) || !(v < kv);
+                fin = cls == 1 ? c1 : (!c1 && !(v < cut));
+            }
+            const unsigned long long bal = __ballot(fin);
+            int base = 0;
+            if (bal && lane == __builtin_ctzll(bal)) base = atomicAdd(counter, __popcll(bal));
+            base = __shfl(base, bal ? __builtin_ctzll(bal) : 0, 64);
+            const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (fin && slot < kSieveSelectCap) { s_fin[slot] = (uint16_t)e; s_row[slot] = lr[e]; }
         }
-        const unsigned long long bal = __ballot(fin);
-        int base = 0;
-        if (bal && lane == __builtin_ctzll(bal)) base = atomicAdd(&s_f, __popcll(bal));
-        base = __shfl(base, bal ? __builtin_ctzll(bal) : 0, 64);
-        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (fin && slot < kSieveSelectCap) s_fin[slot] = (uint16_t)e;
-    }
-    __syncthreads();
-    const int f = s_f;
+        __syncthreads();
+    };
+    compact(1, &s_f);
+    const int f1 = s_f;
+    if (tid == 0) s_f1 = f1;
+    compact(2, &s_f);
+    int f = s_f;
     if (f > kSieveSelectCap) {  // a mass of rows within the filter's resolution of the cut: the exact pass orders them
         to_exact_pass();
         return;
     }
-    // ---- 3. the reference's float64 formula for those, one wave per row
+    // the reference's float64 formula for s_fin[lo..hi): four rows per wave at a time, 16 lanes each (a row is a chain of
+    // dependent fetches - list -> row index -> row: with one row per wave a clustered corpus's ~1800 rows per query were 112
+    // rounds of that latency).  s_d = the distance, s_x = its ranking value rounded to float
     const double *qv = a.q + (size_t)qi * a.d;
     const double q_sq = a.q_sq[qi], q_norm = a.q_norm[qi];
-    for (int i = wave; i < f; i += NT / 64) {
-        const uint32_t row = s_r[s_fin[i]];
-        double rv;
-        const double dist = a.docs16 ? exact_metric_wave(a.docs16 + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lane, &rv)
-                                     : exact_metric_wave(a.docs + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lane, &rv);
-        if (lane == 0) s_d[i] = dist;
+    constexpr int GW = 16, GPW = 64 / GW;
+    const int sub = lane / GW, lg = lane % GW;
+    auto evaluate = [&](int lo, int hi) {
+        for (int i0 = lo + wave * GPW; i0 < hi; i0 += (NT / 64) * GPW) {
+            const int i = i0 + sub;
+            const bool live = i < hi;
+            const uint32_t row = s_row[live ? i : i0];  // (a group without a row repeats the wave's first: no divergence)
+            double rv;
+            const double dist = a.docs16 ? exact_metric_wave<_Float16, GW>(a.docs16 + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lg, &rv)
+                                         : exact_metric_wave<float, GW>(a.docs + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lg, &rv);
+            if (live && lg == 0) {
+                s_d[i] = dist;
+                s_x[i] = dist == dist ? (float)rv : -__builtin_inff();  // (a NaN distance ranks last whatever its ranking value)
+            }
+        }
+        __syncthreads();
+    };
+    evaluate(0, f1);
+    // ---- 3. class 2 against class 1's exact values: with rk = the k-th largest exact ranking value of class 1 (numeric
+    //         distances only), a row whose v + mg stays below rk is beaten by k rows for certain and is dropped unevaluated
+    if (f > f1) {
+        for (int i0 = 0; i0 < f1; i0 += NT) {
+            const int i = i0 + tid;
+            const bool num = i < f1 && s_x[i] > -__builtin_inff();
+            const unsigned long long bal = __ballot(num);
+            if (bal && lane == __builtin_ctzll(bal)) atomicAdd(&s_nn, __popcll(bal));
+        }
+        __syncthreads();
+        if (s_nn >= a.k) {
+            const float rk = kth_largest(s_x, f1);
+            const float need = rk - 4e-6f * fabsf(rk) - 1e-6f * mg - mg;  // (float)rv rounds to nearest: the slack covers it
+            if (tid == 0) s_f = f1;
+            __syncthreads();
+            // survivors of class 2 move up behind class 1 (in place: a survivor's slot is never beyond its old one)
+            for (int i0 = f1; i0 < f; i0 += NT) {
+                const int i = i0 + tid;
+                uint16_t e = 0;
+                uint32_t er = 0;
+                bool keep = false;
+                if (i < f) {
+                    e = s_fin[i];
+                    er = s_row[i];
+                    keep = !(s_v[e] < need);
+                }
+                __syncthreads();
+                const unsigned long long bal = __ballot(keep);
+                int base = 0;
+                if (bal && lane == __builtin_ctzll(bal)) base = atomicAdd(&s_f, __popcll(bal));
+                base = __shfl(base, bal ? __builtin_ctzll(bal) : 0, 64);
+                const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (keep) { s_fin[slot] = e; s_row[slot] = er; }
+                __syncthreads();
+            }
+            f = s_f;
+        }
+        evaluate(f1, f);
+    }
+    // ---- 4. the reference's order among the evaluated rows: a float pre-filter first (the k-th smallest distance rounded to
+    //         float; rounding is monotone, so every row of the true first k stays), then the exact order among what is left
+    //         (ranking all pairs of ~1800 evaluated rows of a clustered corpus in float64 was half a millisecond)
+    for (int i0 = 0; i0 < f; i0 += NT) {  // s_x = -(float)dist, -inf for NaN
+        const int i = i0 + tid;
+        if (i < f) {
+            const double dd = s_d[i];
+            s_x[i] = dd == dd ? -(float)dd : -__builtin_inff();
+        }
+    }
+    if (tid == 0) s_nn = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < f; i0 += NT) {
+        const int i = i0 + tid;
+        const bool num = i < f && s_x[i] > -__builtin_inff();
+        const unsigned long long bal = __ballot(num);
+        if (bal && lane == __builtin_ctzll(bal)) atomicAdd(&s_nn, __popcll(bal));
     }
     __syncthreads();
-    // ---- 4. the reference's order among them
+    const bool pre = s_nn >= a.k;  // (fewer numeric distances than k: the NaN ones are needed too, everything is ranked)
+    const float kx = pre ? kth_largest(s_x, f) : -__builtin_inff();
     const int kout = a.k < f ? a.k : f;
     for (int i = tid; i < f; i += NT) {
+        if (pre && s_x[i] < kx) continue;
         const double dd = s_d[i];
-        const uint32_t rr = s_r[s_fin[i]];
+        const uint32_t rr = s_row[i];
         int rank = 0;
-        for (int c = 0; c < f; ++c) rank += dist_before(s_d[c], s_r[s_fin[c]], dd, rr) ? 1 : 0;  // (an entry is not before itself)
+        for (int c = 0; c < f; ++c) {
+            if (pre && s_x[c] < kx) continue;
+            rank += dist_before(s_d[c], s_row[c], dd, rr) ? 1 : 0;  // (an entry is not before itself)
+        }
         if (rank < a.k) {
             const size_t o = (size_t)qi * a.k + rank;
             if (a.out_row) a.out_row[o] = a.row_offset + (int64_t)rr;
