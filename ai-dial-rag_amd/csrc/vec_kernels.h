@@ -661,14 +661,13 @@ __global__ __launch_bounds__(256, 1) void scan_topk_generic_kernel(const uint4 *
 //   cosine_sim       embeddings_metrics.py:28-31  torch: unit doc row rounded to f32
 //                                                 (norm and division in f32), query unit in f64
 // `rank_value` returns the quantity the scan ranks by, in the scan's units.
-template <typename T, int W = 64>
+template <typename T, int W = 64, int U = 8>
 __device__ __forceinline__ double exact_metric_wave(const T *__restrict__ row, const double *__restrict__ q,
                                                     int d, int metric, float doc_sq32, double q_sq,
                                                     double q_norm, int lane, double *rank_value) {
     // W lanes (a whole wave, or an aligned group of 16: `lane` = the lane's index in its group, groups work on different rows)
     // share a row: lane l takes elements l, l + W, ... in that order.  Eight of them are loaded before the first is used:
-    // written load-by-use, every element of a (cold) row was its own exposed HBM round trip.
-    constexpr int U = 8;
+    // written load-by-use, every element of a (cold) row was its own exposed HBM round trip.  (U = loads in flight per lane.)
     if (metric == MIR_METRIC_COSINE_SIM) {
         double s = 0.0;
         for (int j0 = lane; j0 < d; j0 += W * U) {

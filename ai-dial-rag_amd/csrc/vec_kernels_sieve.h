@@ -43,6 +43,9 @@
 #ifndef SIEVE_MAX3
 #define SIEVE_MAX3 1  // 0 = the eight-compare form of the filter's common path on every index (measurement builds)
 #endif
+#ifndef SIEVE_SELECT_ABL
+#define SIEVE_SELECT_ABL 0  // timing only: the select kernel's final mode returns 1 = after the compaction, 2 = after the first evaluation
+#endif
 #ifndef SIEVE_PREFETCH
 #define SIEVE_PREFETCH 2  // k-steps a fragment pair is requested from LDS ahead of its MFMAs
 #endif
@@ -649,6 +652,88 @@ __device__ __forceinline__ void sieve_wave_topk(const float *vals, int n, int k,
     }
 }
 
+// exact_metric_wave's arithmetic for an aligned group of 16 lanes sharing a row, with 16-byte loads (d % 4 == 0): lane l takes
+// elements 4l .. 4l + 3, 4l + 64 .., all of a row's loads in flight at once.  (With one dword per lane and load the texture
+// addresser, not the memory, set the pace: 18 us for 47 rows.)
+template <typename T>
+__device__ __forceinline__ void sieve_load4(const T *p, float (&v)[4]);
+template <>
+__device__ __forceinline__ void sieve_load4<float>(const float *p, float (&v)[4]) {
+    const float4 x = *reinterpret_cast<const float4 *>(p);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+}
+template <>
+__device__ __forceinline__ void sieve_load4<_Float16>(const _Float16 *p, float (&v)[4]) {
+    typedef _Float16 __attribute__((ext_vector_type(4))) h4;
+    const h4 x = *reinterpret_cast<const h4 *>(p);
+    v[0] = (float)x[0]; v[1] = (float)x[1]; v[2] = (float)x[2]; v[3] = (float)x[3];
+}
+template <typename T>
+__device__ __forceinline__ double sieve_metric_g16(const T *__restrict__ row, const double *__restrict__ q, int d, int metric,
+                                                   float doc_sq32, double q_sq, double q_norm, int lg, double *rank_value) {
+    constexpr int U = 6;  // 6 x 64 elements per pass: d = 384 in one
+    double dn_inv_dummy = 0.0;
+    (void)dn_inv_dummy;
+    float dn = 1.0f;
+    double qn = 1.0;
+    const bool cosine = metric == MIR_METRIC_COSINE_SIM;
+    if (cosine) {
+        double s = 0.0;
+        for (int j0 = 4 * lg; j0 < d; j0 += 64 * U) {
+            float v[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
+                if (j0 + 64 * u < d) sieve_load4<T>(row + j0 + 64 * u, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double x = (double)v[u][e];
+                    s += x * x;
+                }
+        }
+        s = group_sum<16>(s);
+        dn = fmaxf((float)sqrt(s), 1e-8f);
+        qn = fmax(q_norm, 1e-8);
+    }
+    double dot = 0.0;
+    for (int j0 = 4 * lg; j0 < d; j0 += 64 * U) {
+        float v[U][4];
+        double qv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
+            qv[u][0] = qv[u][1] = qv[u][2] = qv[u][3] = 0.0;
+            if (j0 + 64 * u < d) {
+                sieve_load4<T>(row + j0 + 64 * u, v[u]);
+                const double2 a = *reinterpret_cast<const double2 *>(q + j0 + 64 * u), b = *reinterpret_cast<const double2 *>(q + j0 + 64 * u + 2);
+                qv[u][0] = a.x; qv[u][1] = a.y; qv[u][2] = b.x; qv[u][3] = b.y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (cosine) dot += (double)__fdiv_rn(v[u][e], dn) * (qv[u][e] / qn);
+                else dot += (double)v[u][e] * qv[u][e];
+            }
+    }
+    dot = group_sum<16>(dot);
+    if (cosine) {
+        *rank_value = dot * qn;
+        return -dot;
+    }
+    if (metric == MIR_METRIC_INNER_PRODUCT) {
+        *rank_value = dot;
+        return -dot;
+    }
+    const double sq = ((double)doc_sq32 - 2.0 * dot) + q_sq;
+    *rank_value = 2.0 * dot - (double)doc_sq32;
+    return metric == MIR_METRIC_SQEUCLIDEAN_DIST ? sq : sqrt(sq);
+}
+
 // ---------------------------------------------------------------- select
 struct SieveSelectArgs {
     SieveLists l;
@@ -733,6 +818,8 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
     auto kth_largest = [&](const float *vals, int m) -> float {
         __syncthreads();
         if (m <= NT) sieve_wave_topk<1>(vals, m, a.k, tid, NT, part + wave * 64);
+        else if (m <= 2 * NT) sieve_wave_topk<2>(vals, m, a.k, tid, NT, part + wave * 64);
+        else if (m <= 4 * NT) sieve_wave_topk<4>(vals, m, a.k, tid, NT, part + wave * 64);
         else sieve_wave_topk<kSieveQueryCap / kSieveSelectThreads>(vals, m, a.k, tid, NT, part + wave * 64);
         __syncthreads();
         if (wave == 0) {
@@ -822,14 +909,20 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
     const double q_sq = a.q_sq[qi], q_norm = a.q_norm[qi];
     constexpr int GW = 16, GPW = 64 / GW;
     const int sub = lane / GW, lg = lane % GW;
+    const bool vec4 = (a.d & 3) == 0;  // rows and queries 16-byte aligned (float16 rows: 8)
     auto evaluate = [&](int lo, int hi) {
         for (int i0 = lo + wave * GPW; i0 < hi; i0 += (NT / 64) * GPW) {
             const int i = i0 + sub;
             const bool live = i < hi;
             const uint32_t row = s_row[live ? i : i0];  // (a group without a row repeats the wave's first: no divergence)
-            double rv;
-            const double dist = a.docs16 ? exact_metric_wave<_Float16, GW>(a.docs16 + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lg, &rv)
-                                         : exact_metric_wave<float, GW>(a.docs + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lg, &rv);
+            double rv, dist;
+            if (vec4) {
+                dist = a.docs16 ? sieve_metric_g16<_Float16>(a.docs16 + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lg, &rv)
+                                : sieve_metric_g16<float>(a.docs + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lg, &rv);
+            } else {
+                dist = a.docs16 ? exact_metric_wave<_Float16, GW, 8>(a.docs16 + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lg, &rv)
+                                : exact_metric_wave<float, GW, 8>(a.docs + (size_t)row * a.d, qv, a.d, a.metric, a.doc_sq[row], q_sq, q_norm, lg, &rv);
+            }
             if (live && lg == 0) {
                 s_d[i] = dist;
                 s_x[i] = dist == dist ? (float)rv : -__builtin_inff();  // (a NaN distance ranks last whatever its ranking value)
@@ -837,10 +930,18 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
         }
         __syncthreads();
     };
-    evaluate(0, f1);
+#if SIEVE_SELECT_ABL == 1
+    return;
+#endif
+    // (a handful of class-2 rows - the rule on isotropic data - are not worth the second round and its bookkeeping)
+    const bool two_rounds = f - f1 > 128;
+    evaluate(0, two_rounds ? f1 : f);
+#if SIEVE_SELECT_ABL == 2
+    return;
+#endif
     // ---- 3. class 2 against class 1's exact values: with rk = the k-th largest exact ranking value of class 1 (numeric
     //         distances only), a row whose v + mg stays below rk is beaten by k rows for certain and is dropped unevaluated
-    if (f > f1) {
+    if (two_rounds) {
         for (int i0 = 0; i0 < f1; i0 += NT) {
             const int i = i0 + tid;
             const bool num = i < f1 && s_x[i] > -__builtin_inff();
@@ -880,23 +981,26 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
     // ---- 4. the reference's order among the evaluated rows: a float pre-filter first (the k-th smallest distance rounded to
     //         float; rounding is monotone, so every row of the true first k stays), then the exact order among what is left
     //         (ranking all pairs of ~1800 evaluated rows of a clustered corpus in float64 was half a millisecond)
-    for (int i0 = 0; i0 < f; i0 += NT) {  // s_x = -(float)dist, -inf for NaN
-        const int i = i0 + tid;
-        if (i < f) {
-            const double dd = s_d[i];
-            s_x[i] = dd == dd ? -(float)dd : -__builtin_inff();
+    bool pre = false;
+    if (f > 256) {  // (little to rank: all pairs directly)
+        for (int i0 = 0; i0 < f; i0 += NT) {  // s_x = -(float)dist, -inf for NaN
+            const int i = i0 + tid;
+            if (i < f) {
+                const double dd = s_d[i];
+                s_x[i] = dd == dd ? -(float)dd : -__builtin_inff();
+            }
         }
+        if (tid == 0) s_nn = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < f; i0 += NT) {
+            const int i = i0 + tid;
+            const bool num = i < f && s_x[i] > -__builtin_inff();
+            const unsigned long long bal = __ballot(num);
+            if (bal && lane == __builtin_ctzll(bal)) atomicAdd(&s_nn, __popcll(bal));
+        }
+        __syncthreads();
+        pre = s_nn >= a.k;  // (fewer numeric distances than k: the NaN ones are needed too, everything is ranked)
     }
-    if (tid == 0) s_nn = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < f; i0 += NT) {
-        const int i = i0 + tid;
-        const bool num = i < f && s_x[i] > -__builtin_inff();
-        const unsigned long long bal = __ballot(num);
-        if (bal && lane == __builtin_ctzll(bal)) atomicAdd(&s_nn, __popcll(bal));
-    }
-    __syncthreads();
-    const bool pre = s_nn >= a.k;  // (fewer numeric distances than k: the NaN ones are needed too, everything is ranked)
     const float kx = pre ? kth_largest(s_x, f) : -__builtin_inff();
     const int kout = a.k < f ? a.k : f;
     for (int i = tid; i < f; i += NT) {
