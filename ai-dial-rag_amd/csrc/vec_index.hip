@@ -254,6 +254,7 @@ struct SearchBuffers {
     double *q;       // [b][d]      (host API only)
     uint4 *qsplit;   // [ngroups][ksteps][2][64]
     double *q_sq;    // [b]
+    double *q_err;   // [b] |q - bf16(q)|: what the hi fragments lose on the query's side (layout16; the sieve's margin)
     double *q_norm;  // [b]
     float *qscale;   // [b] 1 / (query scale) of the float16-native scan
     uint64_t *part;  // [ngroups][nwg][qpw][klist]
@@ -300,6 +301,7 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.q = host_api ? c.take<double>((size_t)b * d) : nullptr;
     sb.qsplit = c.take<uint4>((size_t)ngroups * (qpw / 32) * ksteps * 128);
     sb.q_sq = c.take<double>(b);
+    sb.q_err = c.take<double>(b);
     sb.q_norm = c.take<double>(b);
     sb.qscale = c.take<float>((size_t)ngroups * std::max(128, qpw));
     sb.part = c.take<uint64_t>((size_t)ngroups * nwg * qpw * klist);
@@ -470,7 +472,8 @@ static int32_t launch_scan_q16(const mir_index *ix, const uint4 *qsplit_g, const
 
 // the sieve's filter launch over tiles [tile0, tile0 + n_tiles) (vec_kernels_sieve.h); sample = the threshold pre-pass
 template <int KIND>
-static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g, const double *q_norm_g, const double *q_sq_g, int nq, int nwg,
+static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g, const double *q_norm_g, const double *q_sq_g,
+                            const double *q_err_g, int nq, int nwg,
                             uint32_t tile0, uint32_t n_tiles, int nan_guard, const uint64_t *gthr_g, uint64_t *cand, float *candv,
                             uint32_t *ccount, float *part_sample, bool sample, unsigned long long *stat, hipStream_t stream) {
     const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
@@ -482,7 +485,7 @@ static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g,
         auto kern = qpw > 128 ? (sample ? sieve_q16_kernel<KS, KIND, true, 2> : sieve_q16_kernel<KS, KIND, false, 2>)  \
                               : (sample ? sieve_q16_kernel<KS, KIND, true, 1> : sieve_q16_kernel<KS, KIND, false, 1>); \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, q_norm_g, q_sq_g, ix->d_maxnorm, n_rows, tile0, n_tiles, \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, q_norm_g, q_sq_g, q_err_g, ix->d_maxnorm, n_rows, tile0, n_tiles, \
                                                     nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat);    \
         break;                                                                                                         \
     }
@@ -652,7 +655,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     if (ix->layout16 && qpw >= kQ16Queries) {
         const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (qpw / 16);
         prep_queries16_kernel<<<dim3(std::max(ntiles16 * ks32 + b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(
-            dq, b, d, ks32, ntiles16, sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords);
+            dq, b, d, ks32, ntiles16, sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords, sb.q_err);
     } else if (ix->native16) {
         const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (kQ16Queries / 16);
         query_stats_h16_kernel<<<dim3(std::max(b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(dq, b, d, sb.q_sq, sb.q_norm, sb.qscale, gz, gwords);
@@ -688,7 +691,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             // the first k): exact by construction
             uint64_t *gt = sb.gthr + (size_t)g * std::max(128, qpw);
             const int q0 = qpw * g;
-            const double *qn = sb.q_norm + q0, *qsq = sb.q_sq + q0;
+            const double *qn = sb.q_norm + q0, *qsq = sb.q_sq + q0, *qerr = sb.q_err + q0;
             const int guard = metric == MIR_METRIC_EUCLIDEAN_DIST ? 1 : 0;
             const uint4 *qs16 = sb.qsplit + (size_t)g * (kQ16Queries / 16) * (ix->ksteps / 2) * 64;  // native16: hi fragments only
             const float *qsc = sb.qscale + (size_t)g * qpw;
@@ -700,9 +703,9 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                     if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve16<SCAN_COS>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
                     return launch_sieve16<SCAN_L2>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
                 }
-                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve<SCAN_IP>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
-                if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve<SCAN_COS>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
-                return launch_sieve<SCAN_L2>(ix, qpw, qs, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve<SCAN_IP>(ix, qpw, qs, qn, qsq, qerr, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve<SCAN_COS>(ix, qpw, qs, qn, qsq, qerr, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                return launch_sieve<SCAN_L2>(ix, qpw, qs, qn, qsq, qerr, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
             };
             SieveScatterArgs ca;
             ca.q0 = q0; ca.nq = nq; ca.l = sb.sv;
@@ -711,6 +714,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             sa.rel_err = ix->native16 ? (float)kH16RelErr : kHiHiRelErr;
             sa.docs = ix->d_orig; sa.docs16 = ix->d_f16; sa.doc_sq = ix->d_docsq;
             sa.q = dq; sa.q_sq = sb.q_sq; sa.q_norm = sb.q_norm; sa.max_norm = ix->d_maxnorm;
+            sa.q_err = ix->native16 ? nullptr : sb.q_err;
             sa.gthr = reinterpret_cast<unsigned long long *>(gt);
             sa.chunk_ids = ix->d_chunk; sa.doc_ids = ix->d_doc; sa.row_offset = ix->row_offset;
             sa.out_doc = o_doc; sa.out_chunk = o_chunk; sa.out_row = o_row; sa.out_dist = o_dist; sa.out_count = o_count;

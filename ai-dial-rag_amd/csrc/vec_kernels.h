@@ -196,6 +196,20 @@ __device__ __forceinline__ double seq_sum_sq_f64(const T *a, int d) {
     return s;
 }
 
+// |x - bf16(x)|_2 of a row, rounded up: what the hi*hi filter of a float32 index loses on the row's side (Cauchy-Schwarz:
+// |(x - hi) . q| <= that * |q|).  The norm kernels keep its maximum over the rows (word 2 of the norm statistics) and the
+// maximum of its product with the row's inverse norm (word 3, the cosine form).
+template <typename T>
+__device__ __forceinline__ float bf16_residual_norm(const T *a, int d) {
+    double s = 0.0;
+    for (int j = 0; j < d; ++j) {
+        const float x = (float)a[j];
+        const float r = x - bf16_bits_to_float(bf16_rne_bits(x));  // exact in float32
+        s += (double)r * (double)r;
+    }
+    return (float)sqrt(s) * (1.0f + 1e-6f);
+}
+
 // One thread per row: doc_sq (f32, numpy order), inv_norm = 1/max(|d|, 1e-8),
 // and the running maximum row norm (for the scan's error bound).
 // T = float, or _Float16 (a float16 index: the reference up-casts to float32 first, so the values
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const T *__restrict__ sr
                                                         float *__restrict__ inv_norm,
                                                         unsigned int *__restrict__ max_norm_bits) {
     int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float nrm = 0.f;
+    float nrm = 0.f, res = 0.f, rel = 0.f;
     if (row < n) {
         const T *a = src + row * (int64_t)d;
         doc_sq[row] = np_pairwise_sq<12>(a, d);
@@ -214,7 +228,13 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const T *__restrict__ sr
         nrm = (float)sqrt(s);
         nrm = nrm * (1.0f + 1e-6f);  // round up: used as an upper bound
         inv_norm[row] = 1.0f / fmaxf((float)sqrt(s), 1e-8f);
+        if (sizeof(T) == 4) {
+            res = bf16_residual_norm(a, d);
+            rel = res * inv_norm[row] * (1.0f + 1e-6f);
+        }
     }
+    for (int off = 32; off >= 1; off >>= 1) { res = fmaxf(res, __shfl_xor(res, off, 64)); rel = fmaxf(rel, __shfl_xor(rel, off, 64)); }
+    if ((threadIdx.x & 63) == 0 && res > 0.f) { atomicMax(max_norm_bits + 2, __float_as_uint(res)); atomicMax(max_norm_bits + 3, __float_as_uint(rel)); }
     // wave max, then one atomic per wave (positive floats order as uints)
     // word 1: some row holds a NaN or an infinity (fmaxf drops a NaN: the maximum alone would not tell)
     if (__ballot(!(nrm < __builtin_inff())) != 0ull && (threadIdx.x & 63) == 0) atomicOr(max_norm_bits + 1, 1u);
@@ -259,7 +279,7 @@ __global__ __launch_bounds__(256) void row_norms_lds_kernel(const T *__restrict_
     __syncthreads();
     // the two sums of a row are independent: threads [0, rows) of the first half of the workgroup take the float32
     // pairwise sum, threads [128, 128 + rows) the float64 one (rows <= 128 by construction of rows_per_wg)
-    float nrm = 0.f;
+    float nrm = 0.f, res = 0.f, rel = 0.f;
     const int rt = threadIdx.x & 127;
     if (rt < rows) {
         const float *a = norms_lds + rt * stride;
@@ -271,8 +291,14 @@ __global__ __launch_bounds__(256) void row_norms_lds_kernel(const T *__restrict_
             nrm = (float)sqrt(s);
             nrm = nrm * (1.0f + 1e-6f);
             inv_norm[row] = 1.0f / fmaxf((float)sqrt(s), 1e-8f);
+            if (sizeof(T) == 4) {
+                res = bf16_residual_norm(a, d);
+                rel = res * inv_norm[row] * (1.0f + 1e-6f);
+            }
         }
     }
+    for (int off = 32; off >= 1; off >>= 1) { res = fmaxf(res, __shfl_xor(res, off, 64)); rel = fmaxf(rel, __shfl_xor(rel, off, 64)); }
+    if ((threadIdx.x & 63) == 0 && res > 0.f) { atomicMax(max_norm_bits + 2, __float_as_uint(res)); atomicMax(max_norm_bits + 3, __float_as_uint(rel)); }
     // word 1: some row holds a NaN or an infinity (fmaxf drops a NaN: the maximum alone would not tell)
     if (__ballot(!(nrm < __builtin_inff())) != 0ull && (threadIdx.x & 63) == 0) atomicOr(max_norm_bits + 1, 1u);
     for (int off = 32; off >= 1; off >>= 1) nrm = fmaxf(nrm, __shfl_xor(nrm, off, 64));

@@ -44,6 +44,21 @@ typedef float __attribute__((ext_vector_type(4))) f32x4;
 #endif
 constexpr float kHiHiRelErr = MIR_HIHI_REL_ERR;
 
+// The sieve's margin, from what THIS index and THIS query actually lose to bfloat16 instead of the worst case: with
+// x = hx + dx, q = hq + dq:  x.q - hx.hq = dx.q + hx.dq, so |x.q - hx.hq| <= |dx||q| + (|x| + |dx|)|dq| (Cauchy-Schwarz) - rigorous
+// for every row once |dx| is replaced by its maximum over the rows (norm statistics word 2, bf16_residual_norm) and |x| by
+// the largest norm (word 0); cosine ranks x.q / |x|: |dx| / |x| at its maximum (word 3).  Round-to-nearest errors are about
+// uniform, so |dx| ~ 0.45 * 2^-8 |x| on ordinary data and the margin is ~2.3 x tighter than kHiHiRelErr - and exactly as wide
+// as it must be on the data of test_worst_case_bf16_rounding.  The float32 accumulation of <= 384 exact products adds
+// < 2.5e-5 |x||q|.  Returned in the ranking units of `l2` (2 x.q - |x|^2) / cosine / inner product.
+__device__ __forceinline__ float hihi_margin(bool cosine, bool l2, float qn, float eq, const float *__restrict__ stats) {
+    const float slop = 3.0e-5f;
+    float m = cosine ? stats[3] * qn + (1.0f + stats[3]) * eq + slop * qn
+                     : stats[2] * qn + (stats[0] + stats[2]) * eq + slop * stats[0] * qn;
+    m *= 1.0f + 1e-5f;
+    return l2 ? 2.0f * m : m;
+}
+
 // f32 [n][d] row-major -> layout16.  One thread per (tile, block of a half, lane); ks32*32 >= d; columns past d and
 // rows past n are 0.
 __global__ __launch_bounds__(256) void pack_split16_f32_kernel(const float *__restrict__ src, int64_t n, int d, int ks32,
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(256) void pack_split16_f32_kernel(const float *__re
 __global__ __launch_bounds__(64) void prep_queries16_kernel(const double *__restrict__ q, int b, int d, int ks32, int ntiles16,
                                                             uint4 *__restrict__ qsplit, double *__restrict__ q_sq,
                                                             double *__restrict__ q_norm, unsigned long long *__restrict__ gthr,
-                                                            int gthr_words) {
+                                                            int gthr_words, double *__restrict__ q_err = nullptr) {
     const int lane = threadIdx.x, blk = blockIdx.x;
     if (gthr && blk * 64 + lane < gthr_words) gthr[blk * 64 + lane] = 0;
     if (blk < ntiles16 * ks32) {
@@ -99,15 +114,19 @@ __global__ __launch_bounds__(64) void prep_queries16_kernel(const double *__rest
     } else {
         const int qi = blk - ntiles16 * ks32;
         if (qi >= b) return;
-        double s = 0.0;
+        double s = 0.0, e2 = 0.0;
         for (int j = lane; j < d; j += 64) {
             const double x = q[(int64_t)qi * d + j];
             s += x * x;
+            const double r = x - (double)bf16_bits_to_float(bf16_rne_bits((float)x));  // what the hi fragment loses of this component
+            e2 += r * r;
         }
         s = wave_sum(s);
+        e2 = wave_sum(e2);
         if (lane == 0) {
             q_sq[qi] = s;
             q_norm[qi] = sqrt(s);
+            if (q_err) q_err[qi] = sqrt(e2);
         }
     }
 }

@@ -68,7 +68,8 @@ __host__ __device__ constexpr size_t sieve_lds_bytes(int ks32) { return (size_t)
 template <int KS32, int KIND, bool SAMPLE, int QT>
 __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
                                                            const uint4 *__restrict__ qsplit, const double *__restrict__ q_norm,
-                                                           const double *__restrict__ q_sq, const float *__restrict__ max_norm,
+                                                           const double *__restrict__ q_sq, const double *__restrict__ q_err,
+                                                           const float *__restrict__ max_norm,
                                                            uint32_t n_rows, uint32_t tile0, uint32_t n_tiles, int nq, int nan_guard,
                                                            const uint64_t *__restrict__ gthr, uint64_t *__restrict__ cand,
                                                            float *__restrict__ candv, uint32_t *__restrict__ ccount,
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         mg[u] = 0.f; bound[u] = -__builtin_inff(); guard[u] = __builtin_inff(); best[u] = -__builtin_inff();
         if (lane_live[u]) {
             const float qn = (float)q_norm[qloc[u]] * (1.0f + 1e-6f);
-            mg[u] = kHiHiRelErr * qn * (KIND == SCAN_COS ? 1.0f : max_norm[0]) * (KIND == SCAN_L2 ? 2.0f : 1.0f);
+            const float eq = (float)q_err[qloc[u]] * (1.0f + 1e-6f);
+            mg[u] = hihi_margin(KIND == SCAN_COS, KIND == SCAN_L2, qn, eq, max_norm);
             if (!SAMPLE) {
                 const uint64_t key = gthr[qloc[u]];
                 if (key != 0) {
@@ -739,7 +741,8 @@ struct SieveSelectArgs {
     SieveLists l;
     int q0, nq, k, metric, mode;   // mode 0: thresholds for the next launch; 1: the result
     int d, nan_guard;
-    float rel_err;                 // the filter's bound: kHiHiRelErr / kH16RelErr
+    float rel_err;                 // the float16 filter's bound (kH16RelErr); a float32 index: the margin of hihi_margin()
+    const double *q_err;           // [b] |q - bf16(q)| (float32 index), or null
     const float *docs;             // f32 [n][d], or null with
     const _Float16 *docs16;        // f16 [n][d] (float16-native index)
     const float *doc_sq;
@@ -838,8 +841,9 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
         return s_kv;
     };
     const float qn = (float)a.q_norm[qi] * (1.0f + 1e-6f);
-    const float mg = a.rel_err * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) *
-                     (a.metric == MIR_METRIC_INNER_PRODUCT || a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : 2.0f);  // (as the filter's)
+    const bool l2 = !(a.metric == MIR_METRIC_INNER_PRODUCT || a.metric == MIR_METRIC_COSINE_SIM);
+    const float mg = a.q_err ? hihi_margin(a.metric == MIR_METRIC_COSINE_SIM, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm)
+                             : a.rel_err * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) * (l2 ? 2.0f : 1.0f);  // (as the filter's)
     float guard = __builtin_inff();
     if (a.nan_guard) {
         const float qs = (float)a.q_sq[qi];
