@@ -484,12 +484,11 @@ __global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_
 // touched documents and their count; bm25_merge_kernel flags the queries that need the dense pass.
 constexpr int kBm25QcMax = 64;
 
-__global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms,
-                                                          const int32_t *__restrict__ q_ptr, int b, int qc, int k,
-                                                          const int32_t *__restrict__ hlist,
-                                                          double *__restrict__ part_score,
-                                                          int32_t *__restrict__ part_idx,
-                                                          int32_t *__restrict__ part_cnt) {
+__device__ __forceinline__ void bm25_sparse_body(const Bm25Dev &m, const int32_t *__restrict__ q_terms,
+                                                 const int32_t *__restrict__ q_ptr, int b, int qc, int k,
+                                                 const int32_t *__restrict__ hlist, double *__restrict__ part_score,
+                                                 int32_t *__restrict__ part_idx, int32_t *__restrict__ part_cnt, int block_x,
+                                                 int block_y) {
     __shared__ double sc[kBm25Tile];
     __shared__ double red_s[4];
     __shared__ int64_t red_i[4];
@@ -506,10 +505,10 @@ __global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32
     __shared__ TopkLds L;
     __shared__ int s_cnt;
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
+    const int tile = block_x;
     // this workgroup walks heavy queries hlist[q0 .. q0 + nq) (bm25_plan_kernel; the light ones are bm25_wave_kernel's)
     const int nheavy = hlist[b];
-    const int q0 = blockIdx.y * qc;
+    const int q0 = block_y * qc;
     if (q0 >= nheavy) return;
     const int nq = (nheavy - q0) < qc ? (nheavy - q0) : qc;
     const int base = tile * kBm25Tile;
@@ -839,8 +838,8 @@ __device__ __forceinline__ void wave_pair(const Bm25Dev &m, WaveLds &L, int lane
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(64 * kWvWaves) void bm25_wave_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms,
-                                                                  const int32_t *__restrict__ q_ptr, int b, WavePool pool) {
+__device__ __forceinline__ void bm25_wave_body(const Bm25Dev &m, const int32_t *__restrict__ q_terms, const int32_t *__restrict__ q_ptr,
+                                               int b, const WavePool &pool, int block_x, int grid_x) {
     __shared__ WaveLds lds[kWvWaves];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -849,8 +848,8 @@ __global__ __launch_bounds__(64 * kWvWaves) void bm25_wave_kernel(Bm25Dev m, con
     for (int i = lane; i < kWvSlots; i += 64) L.sc[i] = 0.0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const long long npairs = (long long)b * m.ntiles;
-    const long long stride = (long long)gridDim.x * kWvWaves;
-    for (long long p = (long long)blockIdx.x * kWvWaves + wave; p < npairs; p += stride) {
+    const long long stride = (long long)grid_x * kWvWaves;
+    for (long long p = (long long)block_x * kWvWaves + wave; p < npairs; p += stride) {
         const int q = (int)(p / m.ntiles), tile = (int)(p - (long long)q * m.ntiles);
         const int base = tile * kBm25Tile;
         const int qb = q_ptr[q], len = q_ptr[q + 1] - qb;
@@ -890,6 +889,31 @@ __global__ __launch_bounds__(64 * kWvWaves) void bm25_wave_kernel(Bm25Dev m, con
         const int c_off = push(incl - (valid ? n : 0));  // lane j < nt: offset of term j's first posting among the pair's
         if (total <= 128) wave_pair<2>(m, L, lane, nt, total, base, c_idf, c_lo_hi, c_lo_lo, c_off, pool, q);
         else wave_pair<12>(m, L, lane, nt, total, base, c_idf, c_lo_hi, c_lo_lo, c_off, pool, q);
+    }
+}
+
+__global__ __launch_bounds__(64 * kWvWaves) void bm25_wave_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms,
+                                                                  const int32_t *__restrict__ q_ptr, int b, WavePool pool) {
+    bm25_wave_body(m, q_terms, q_ptr, b, pool, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(256) void bm25_sparse_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms,
+                                                          const int32_t *__restrict__ q_ptr, int b, int qc, int k,
+                                                          const int32_t *__restrict__ hlist, double *__restrict__ part_score,
+                                                          int32_t *__restrict__ part_idx, int32_t *__restrict__ part_cnt) {
+    bm25_sparse_body(m, q_terms, q_ptr, b, qc, k, hlist, part_score, part_idx, part_cnt, (int)blockIdx.x, (int)blockIdx.y);
+}
+// A handful of queries (b <= 8, the live path's one): both fast passes in ONE dispatch - workgroups [0, wgs_wave) take the light
+// queries' (tile, query) pairs, the others the heavy queries' tiles.  A dispatch that finds nothing to do is ~4.5 us of a
+// single query's ~44; the occupancy this kernel's combined LDS costs does not matter at this size.
+__global__ __launch_bounds__(256) void bm25_small_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms, const int32_t *__restrict__ q_ptr,
+                                                         int b, int qc, int k, WavePool pool, int wgs_wave, double *__restrict__ part_score,
+                                                         int32_t *__restrict__ part_idx, int32_t *__restrict__ part_cnt) {
+    const int bx = (int)blockIdx.x;
+    if (bx < wgs_wave) {
+        bm25_wave_body(m, q_terms, q_ptr, b, pool, bx, wgs_wave);
+    } else {
+        const int r = bx - wgs_wave;
+        bm25_sparse_body(m, q_terms, q_ptr, b, qc, k, pool.hlist, part_score, part_idx, part_cnt, r % m.ntiles, r / m.ntiles);
     }
 }
 
@@ -1448,19 +1472,23 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     //    selection per query; the others on the tile kernel + merge
     bm25_plan_kernel<<<dim3(1), dim3(1024), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
     MIR_HIP(hipGetLastError());
-    {
-        const long long npairs = (long long)b * T;
-        const int wgs = (int)std::max<long long>(1, std::min<long long>((npairs + kWvWaves - 1) / kWvWaves, (long long)h->num_cus * 5));
-        bm25_wave_kernel<<<dim3(wgs), dim3(64 * kWvWaves), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
-        MIR_HIP(hipGetLastError());
-    }
     //    tile kernel: queries per workgroup: as many as still leave ~8 workgroups per CU of parallelism
     int qc = (int)((int64_t)b * T / 2048);
     qc = qc < 1 ? 1 : (qc > kBm25QcMax ? kBm25QcMax : qc);
     if (h->qc_pin > 0) qc = h->qc_pin;  // tests pin the pipeline depth (short pipelines x long query queues)
-    bm25_sparse_kernel<<<dim3(T, (b + qc - 1) / qc), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, b, qc, k, pool.hlist, part_score,
-                                                                        part_idx, part_cnt);
-    MIR_HIP(hipGetLastError());
+    const long long npairs = (long long)b * T;
+    const int wgs = (int)std::max<long long>(1, std::min<long long>((npairs + kWvWaves - 1) / kWvWaves, (long long)h->num_cus * 5));
+    if (b <= 8 && h->qc_pin <= 0) {
+        bm25_small_kernel<<<dim3(wgs + T * ((b + qc - 1) / qc)), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, b, qc, k, pool, wgs, part_score,
+                                                                                  part_idx, part_cnt);
+        MIR_HIP(hipGetLastError());
+    } else {
+        bm25_wave_kernel<<<dim3(wgs), dim3(64 * kWvWaves), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
+        MIR_HIP(hipGetLastError());
+        bm25_sparse_kernel<<<dim3(T, (b + qc - 1) / qc), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, b, qc, k, pool.hlist, part_score,
+                                                                            part_idx, part_cnt);
+        MIR_HIP(hipGetLastError());
+    }
     bm25_finish_kernel<<<dim3(b), dim3(256), 0, s>>>(pool, part_score, part_idx, part_cnt, T, k, h->doc_offset, h->n_docs, need, d_out_idx,
                                                      d_out_score, d_out_count);
     MIR_HIP(hipGetLastError());
