@@ -40,9 +40,12 @@ typedef float __attribute__((ext_vector_type(4))) f32x4;
 // was 4e-3 - u taken as 2^-9: true of random data many times over, not of the worst case; tests/test_gpu_sieve.py
 // ::test_worst_case_bf16_rounding builds the input that needs the whole bound.)
 #ifndef MIR_HIHI_REL_ERR
-#define MIR_HIHI_REL_ERR 8.0e-3f  // (a build with 4.0e-3f must FAIL test_worst_case_bf16_rounding: that is what the test is for)
+#define MIR_HIHI_REL_ERR 8.0e-3f  // (the q16 list scan's constant margin; the sieve's is hihi_margin() below)
 #endif
 constexpr float kHiHiRelErr = MIR_HIHI_REL_ERR;
+#ifndef MIR_MARGIN_SCALE
+#define MIR_MARGIN_SCALE 1.0f  // (a build with 0.5f must FAIL test_worst_case_bf16_rounding: tools/worst_case_margin_check.sh)
+#endif
 
 // The sieve's margin, from what THIS index and THIS query actually lose to bfloat16 instead of the worst case: with
 // x = hx + dx, q = hq + dq:  x.q - hx.hq = dx.q + hx.dq, so |x.q - hx.hq| <= |dx||q| + (|x| + |dx|)|dq| (Cauchy-Schwarz) - rigorous
@@ -55,7 +58,7 @@ __device__ __forceinline__ float hihi_margin(bool cosine, bool l2, float qn, flo
     const float slop = 3.0e-5f;
     float m = cosine ? stats[3] * qn + (1.0f + stats[3]) * eq + slop * qn
                      : stats[2] * qn + (stats[0] + stats[2]) * eq + slop * stats[0] * qn;
-    m *= 1.0f + 1e-5f;
+    m *= (1.0f + 1e-5f) * MIR_MARGIN_SCALE;
     return l2 ? 2.0f * m : m;
 }
 
