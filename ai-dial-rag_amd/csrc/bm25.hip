@@ -423,10 +423,10 @@ __global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_
     __shared__ long long s_scan[1024];
     __shared__ long long s_base;
     __shared__ int s_nheavy;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthreads = (int)blockDim.x;  // 1024, or 64 for b <= 64
     if (tid == 0) { s_base = 0; s_nheavy = 0; }
     __syncthreads();
-    for (int q0 = 0; q0 < b; q0 += 1024) {
+    for (int q0 = 0; q0 < b; q0 += nthreads) {
         const int q = q0 + tid;
         long long need = 0;
         bool fits = false;
@@ -451,16 +451,27 @@ __global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_
                 if (sdf <= (long long)kWvHeavy * m.ntiles) { need = sdf; fits = true; }
             }
         }
-        // inclusive scan of `need` over the 1024 queries of this round
-        s_scan[tid] = need;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const long long o = tid >= off ? s_scan[tid - off] : 0;
+        // inclusive scan of `need` over the queries of this round: 1024 of them through LDS, or - the block is ONE wave for
+        // batches of at most 64 queries - a wave scan (the LDS form's twenty block barriers were 5 us of a single query's 42)
+        long long incl = need;
+        if (nthreads == 64) {
+            for (int off = 1; off < 64; off <<= 1) {
+                const long long o = ((long long)__shfl_up((int)(incl >> 32), off, 64) << 32) | (unsigned int)__shfl_up((int)(unsigned int)incl, off, 64);
+                if (tid >= off) incl += o;
+            }
+            s_scan[tid] = incl;
+        } else {
+            s_scan[tid] = need;
             __syncthreads();
-            s_scan[tid] += o;
-            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) {
+                const long long o = tid >= off ? s_scan[tid - off] : 0;
+                __syncthreads();
+                s_scan[tid] += o;
+                __syncthreads();
+            }
+            incl = s_scan[tid];
         }
-        const long long at = s_base + s_scan[tid] - need;
+        const long long at = s_base + incl - need;
         const bool light = fits && at + need <= pool.capacity;  // (a query that does not fit leaves a hole: harmless)
         if (q < b) {
             pool.light[q] = light ? 1 : 0;
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_
             if (!light) pool.hlist[atomicAdd(&s_nheavy, 1)] = q;  // (any order: a heavy query's tiles are merged by bm25_merge_kernel)
         }
         __syncthreads();
-        if (tid == 1023) s_base += s_scan[1023];
+        if (tid == nthreads - 1) s_base += s_scan[nthreads - 1];
         __syncthreads();
     }
     if (tid == 0) pool.hlist[b] = s_nheavy;
@@ -1470,7 +1481,7 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     }
     // 1. fast passes: positives among touched documents.  Light queries (bm25_plan_kernel) one wave per (tile, query) and one
     //    selection per query; the others on the tile kernel + merge
-    bm25_plan_kernel<<<dim3(1), dim3(1024), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
+    bm25_plan_kernel<<<dim3(1), dim3(b <= 64 ? 64 : 1024), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
     MIR_HIP(hipGetLastError());
     //    tile kernel: queries per workgroup: as many as still leave ~8 workgroups per CU of parallelism
     int qc = (int)((int64_t)b * T / 2048);
