@@ -18,7 +18,7 @@ METRIC_CODES = {"cosine_sim": 0, "euclidean_dist": 1, "sqeuclidean_dist": 2, "in
 DTYPE_F32, DTYPE_F16 = 0, 1
 FLAG_UNCERTAIN = 1  # never returned since ABI 2
 FLAG_EXACT_PASS = 2  # the query was answered by the exact pass (exact_topk_kernel)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NativeLibraryMissing(ImportError):
@@ -77,6 +77,9 @@ def _load():
         "mir_bm25_create": ([vp, vp, i64, i32, C.c_double, C.c_double, C.c_double, vp, C.c_double, i32, i64, vp], i32),
         "mir_compact_term_ids": ([vp, i64, i32, vp, vp, vp], i32),
         "mir_stem_english": ([vp, i64, C.c_char, vp, vp], i32),
+        "mir_keywords_preprocess": ([vp, vp, i32, i32, i32, vp], i32),
+        "mir_kwp_result_data": ([vp, vp, vp, vp, vp, vp], i32),
+        "mir_kwp_result_free": ([vp], i32),
         "mir_bm25_destroy": ([vp], i32),
         "mir_bm25_tune": ([vp, i32], i32),
         "mir_bm25_corpus_stats": ([vp, vp, vp, vp, vp], i32),

@@ -22,6 +22,11 @@ namespace {
 #define ENC_PASS_TILES 12288
 #endif
 constexpr int kMaxTilesPerPass = ENC_PASS_TILES;
+// the throughput path's attention kernel: 3 = attention3_kernel (persistent waves, LDS-DMA ring), 2 = attention2_kernel (one wave
+// per two query tiles), 1 = attention_kernel (one wave per query tile; the latency path's kernel)
+#ifndef ENC_ATT
+#define ENC_ATT 3
+#endif
 
 // Pack a Hugging Face Linear weight W[out][in] (y = x W^T + b) into MFMA A-fragment
 // order for out^T = W x^T: block (nt, ks) = 64 lanes x 8 halfs, lane (row = l&31,
@@ -50,6 +55,7 @@ struct Layer {
 
 struct mir_encoder {
     int device = 0;
+    int n_cus = 256;
     int layers = 0;
     int vocab = 0, max_pos = 0;
     float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
@@ -97,21 +103,40 @@ struct Batch {
     std::vector<int32_t> ids;        // [n_tiles*32], 0-padded
     std::vector<TileInfo> tiles;     // [n_tiles]
     std::vector<int32_t> seq_first;  // [n_seq]
+    std::vector<int32_t> units;      // attention units, 4 ints each: first tile | (tiles - 1) << 24, key tiles, sequence length, the sequence's first tile
 };
 
 // Sequences [s0, s1) -> padded tiles.
 void build_batch(const int32_t *token_ids, const int64_t *offs, const int32_t *lens, int s0, int s1, Batch &b) {
-    b.ids.clear(); b.tiles.clear(); b.seq_first.clear();
+    b.ids.clear(); b.tiles.clear(); b.seq_first.clear(); b.units.clear();
     for (int s = s0; s < s1; ++s) {
         const int len = lens[s];
         const int nt = (len + 31) / 32;
         const int first = (int)b.tiles.size();
         b.seq_first.push_back(first);
         for (int t = 0; t < nt; ++t) b.tiles.push_back(TileInfo{first, nt, len, s - s0});
+        for (int t = 0; t < nt; t += 2) b.units.insert(b.units.end(), {(first + t) | ((t + 1 < nt ? 1 : 0) << 24), nt, len, first});
         const size_t base = b.ids.size();
         b.ids.resize(base + (size_t)nt * 32, 0);
         std::memcpy(b.ids.data() + base, token_ids + offs[s], sizeof(int32_t) * len);
     }
+#if ENC_ATT == 3
+    // attention3_kernel deals the units to its persistent waves with a stride: sorted by key tiles (descending, stable - a
+    // sequence's units stay together, for the L2), every wave gets a cross-section of lengths instead of a random draw
+    {
+        const size_t nu = b.units.size() / 4;
+        std::vector<int32_t> sorted(b.units.size());
+        size_t start[18] = {0};
+        for (size_t u = 0; u < nu; ++u) ++start[17 - std::min(b.units[4 * u + 1], 16)];  // bucket 17 - n_kt -> descending
+        size_t acc = 0;
+        for (int k = 0; k < 18; ++k) { const size_t c = start[k]; start[k] = acc; acc += c; }
+        for (size_t u = 0; u < nu; ++u) {
+            const size_t d = start[17 - std::min(b.units[4 * u + 1], 16)]++;
+            std::memcpy(&sorted[4 * d], &b.units[4 * u], 16);
+        }
+        b.units.swap(sorted);
+    }
+#endif
 }
 
 }  // namespace
@@ -132,10 +157,12 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
     MIR_REQUIRE(layers >= 1 && layers <= 64 && vocab >= 1 && max_pos >= 1, "bad encoder shape");
     MIR_REQUIRE(word_emb && pos_emb && type_emb && emb_ln_gamma && emb_ln_beta && layer_tensors, "NULL weight pointer");
     for (int i = 0; i < layers * 16; ++i) MIR_REQUIRE(layer_tensors[i] != nullptr, "layer tensor %d is NULL", i);
-    int32_t rc = use_device(device, nullptr);
+    int cus = 0;
+    int32_t rc = use_device(device, &cus);
     if (rc != MIR_OK) return rc;
     mir_encoder *e = new (std::nothrow) mir_encoder();
     MIR_REQUIRE(e != nullptr, "out of host memory");
+    e->n_cus = cus > 0 ? cus : 256;
     e->device = device; e->layers = layers; e->vocab = vocab; e->max_pos = max_pos;
     auto fail = [&](int32_t code) { free_encoder(e); return code; };
 #define MIR_TRY(call)                                                                              \
@@ -210,6 +237,7 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[0], hipEventDisableTiming));
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[1], hipEventDisableTiming));
     if (ffn_prepare() != MIR_OK) return fail(MIR_ERR_HIP);
+    if (attention3_prepare() != MIR_OK) return fail(MIR_ERR_HIP);
     {
         auto kern = qkv_kernel;
         MIR_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS_BYTES));
@@ -288,6 +316,7 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
         const size_t o_ids = take(b.ids.size() * 4), o_ti = take(b.tiles.size() * sizeof(TileInfo)), o_sf = take(b.seq_first.size() * 4);
+        const size_t o_un = take(b.units.size() * 4);
         const size_t o_a = take(act_b), o_b = take(act_b), o_q = take(act_b), o_k = take(act_b), o_v = take(act_b);
         // latency path (<= kSmallTiles tiles): Y float32 [tile][384][32] and the FFN's h fragments [tile][96][64] x 16 B
         const bool small = nt <= kSmallTiles;
@@ -304,7 +333,8 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         // pinned mirror of the small host<->device regions: [ids | tiles | seq_first | out | hidden]
         const size_t p_ids = 0, p_ti = p_ids + ((b.ids.size() * 4 + 255) & ~(size_t)255);
         const size_t p_sf = p_ti + ((b.tiles.size() * sizeof(TileInfo) + 255) & ~(size_t)255);
-        const size_t p_out = p_sf + ((b.seq_first.size() * 4 + 255) & ~(size_t)255);
+        const size_t p_un = p_sf + ((b.seq_first.size() * 4 + 255) & ~(size_t)255);
+        const size_t p_out = p_un + ((b.units.size() * 4 + 255) & ~(size_t)255);
         const size_t p_hid = p_out + (((size_t)(s1 - s0) * H * 4 + 255) & ~(size_t)255);
         const size_t p_need = p_hid + (hidden_out ? (size_t)nt * 32 * H * 4 : 0);
         if (e->pin_cap[slot] < p_need) {
@@ -317,9 +347,10 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         std::memcpy(pn + p_ids, b.ids.data(), b.ids.size() * 4);
         std::memcpy(pn + p_ti, b.tiles.data(), b.tiles.size() * sizeof(TileInfo));
         std::memcpy(pn + p_sf, b.seq_first.data(), b.seq_first.size() * 4);
-        // [ids | tiles | seq_first] have the same 256-aligned offsets on both sides: one copy
-        MIR_REQUIRE(o_ids == p_ids && o_ti == p_ti && o_sf == p_sf, "staging layout mismatch");
-        MIR_HIP(hipMemcpyAsync(w + o_ids, pn + p_ids, p_sf + b.seq_first.size() * 4, hipMemcpyHostToDevice, s));
+        std::memcpy(pn + p_un, b.units.data(), b.units.size() * 4);
+        // [ids | tiles | seq_first | units] have the same 256-aligned offsets on both sides: one copy
+        MIR_REQUIRE(o_ids == p_ids && o_ti == p_ti && o_sf == p_sf && o_un == p_un, "staging layout mismatch");
+        MIR_HIP(hipMemcpyAsync(w + o_ids, pn + p_ids, p_un + b.units.size() * 4, hipMemcpyHostToDevice, s));
         const int32_t *d_ids = reinterpret_cast<int32_t *>(w + o_ids);
         const TileInfo *d_ti = reinterpret_cast<TileInfo *>(w + o_ti);
         uint4 *a0 = reinterpret_cast<uint4 *>(w + o_a), *a1 = reinterpret_cast<uint4 *>(w + o_b);
@@ -361,7 +392,13 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
             const Layer &l = e->L[li];
             qkv_kernel<<<dim3((nt + QKV_WAVES * QKV_G - 1) / (QKV_WAVES * QKV_G)), dim3(64 * QKV_WAVES), QKV_LDS_BYTES, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
             {
-                const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);  // a1 = context
+#if ENC_ATT == 3
+                const int32_t arc = launch_attention3(qf, kf, vf, reinterpret_cast<const int32_t *>(w + o_un), (int)b.units.size() / 4, a1, e->n_cus, s);  // a1 = context
+#elif ENC_ATT == 2
+                const int32_t arc = launch_attention2(qf, kf, vf, reinterpret_cast<const int32_t *>(w + o_un), (int)b.units.size() / 4, a1, s);
+#else
+                const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);
+#endif
                 if (arc != MIR_OK) return arc;
             }
             oproj_ln_kernel<<<dim3(std::min((nt + 3) / 4, OPROJ_MAX_GRID)), dim3(512), OPROJ_LDS_BYTES, s>>>(a1, nt, l.wo, l.attn_params, l.attn_params + H, l.attn_params + 2 * H,

@@ -9,46 +9,166 @@ namespace enc {
 // The running state of one (head, query tile) and one key tile's worth of attention: S^T = K Q^T - ref, P = exp2,
 // O^T += V^T P^T, lsum += 1 P^T (the lazy softmax reference is described at attention_kernel).  Shared by the throughput /
 // general kernel and the single-tile fused kernel of the latency path, so both round alike.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 struct AttnState {
-    f32x16 o = {0}, lsum = {0}, nref = {0};  // lsum: every register holds the lane's query's running sum
+    f32x16 o = {0}, nref = {0};
+    f32x4 lsum = {0};  // every register holds the lane's query's running sum
 };
-__device__ __forceinline__ void attn_step(AttnState &st, const uint4 &q0, const uint4 &q1, const uint4 &kc0, const uint4 &kc1,
-                                          const uint4 &vc0, const uint4 &vc1, bool first, bool last, int key0, int seq_len, int h) {
-    constexpr float kSlack = 6.0f;
-    const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
+// Row sums of P on the matrix pipe: a 16x16x32 product of a 0 / 1 SELECTOR with the P^T fragment as it stands.  As that
+// instruction's B operand the fragment's lane l is "column l & 15, k-slice l >> 4"; it really holds query l & 31, keys
+// 8 (l >> 5) ..: lanes n, n + 32 are query n's two key halves, lanes n + 16, n + 48 query n + 16's.  The selector's row i takes
+// the k-slices g with g & 1 == (i >> 2) & 1, and lane l reads back rows 4 (l >> 4) ..: its OWN query's sum over the fragment's
+// 16 keys, four times.  (Round 3 multiplied ones by P^T on the 32x32x16 shape: 16 identical registers per query tile and
+// twice the matrix cycles; two query tiles per wave need the registers.)
+__device__ __forceinline__ uint4 attn_sum_selector(int lane) {
+    const uint32_t w = (((lane >> 4) & 1) == ((lane >> 2) & 1)) ? 0x3C003C00u : 0u;
+    return make_uint4(w, w, w, w);
+}
+__device__ __forceinline__ f32x4 mfma_sum(uint4 sel, uint4 p, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sel), __builtin_bit_cast(f16x8, p), c, 0, 0, 0);
+}
+constexpr float kAttnSlack = 6.0f;
+// The pieces of one (query tile, key tile) step; attn_step_t strings them together for one query tile, attn_step2_t for the
+// two query tiles of a wave (same operations on the same values in the same order per query tile: both round alike).
+// FIRST / LAST are compile-time: the kernels peel a sequence's first and last key tile out of their loops, so the steady state
+// carries no masking code and no branch but the rare reference move.
+//
+// Padding (only a sequence's LAST key tile can hold it) is masked through the score MFMA's C operand: -inf in the rows of
+// keys past the sequence's end instead of -ref (x - inf = -inf: the same value the old select wrote after the MFMAs).
+template <bool LAST>
+__device__ __forceinline__ f32x16 attn_scores(const AttnState &st, const uint4 &q0, const uint4 &q1, const uint4 &kc0, const uint4 &kc1,
+                                              int key0, int seq_len, int h) {
+#if defined(ATTN_MASK_AFTER)
     f32x16 s = mfma(kc0, q0, st.nref);
     s = mfma(kc1, q1, s);
-    if (last) {  // only the sequence's last key tile can hold padding
+    if (LAST) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = (key0 + fi(r, h) < seq_len) ? s[r] : -__builtin_inff();
     }
+    return s;
+#else
+    f32x16 c = st.nref;
+    if (LAST) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = (key0 + fi(r, h) < seq_len) ? c[r] : -__builtin_inff();
+    }
+    f32x16 s = mfma(kc0, q0, c);
+    return mfma(kc1, q1, s);
+#endif
+}
+__device__ __forceinline__ float attn_lane_max(const f32x16 &s) {  // this lane's half of the keys
+    // (fmaxf: each MFMA output comes with a canonicalising v_max x, x.  An inline-asm v_max3_f32 does not - and is WRONG here:
+    // hipcc's hazard recogniser does not look into inline asm, so the wait states between an MFMA and a VALU read of its
+    // result are not inserted; measured: garbage scores.  The VALU count is not what bounds this kernel anyway.)
     const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]), a2 = fmaxf(fmaxf(s[6], s[7]), s[8]);
     const float a3 = fmaxf(fmaxf(s[9], s[10]), s[11]), a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
-    const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(a4, s[15]));  // this lane's half of the keys
-    if (first || __any(mx > kSlack)) {  // wave-uniform; rare after the first tile
-        const float mq = half_max(mx);
-        const float delta = first ? mq : fmaxf(mq, 0.f);  // the reference only rises after the first tile
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
+    return fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(a4, s[15]));
+}
+// move the reference by delta (0 leaves every value as it is, bit for bit: x - 0, x * exp2(-0))
+__device__ __forceinline__ void attn_rescale(AttnState &st, f32x16 &s, float delta) {
+    const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] -= delta;
-            st.nref[r] -= delta;
-            st.o[r] *= alpha;
-            st.lsum[r] *= alpha;
-        }
+    for (int r = 0; r < 16; ++r) {
+        s[r] -= delta;
+        st.nref[r] -= delta;
+        st.o[r] *= alpha;
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st.lsum[r] *= alpha;
+}
+__device__ __forceinline__ void attn_pv(AttnState &st, f32x16 &s, const uint4 &vc0, const uint4 &vc1) {
+    const uint4 sel = attn_sum_selector((int)(threadIdx.x & 63));
     // v_exp_f32 directly: exp2f() wraps it in a compare / select / ldexp to keep results below 2^-126 exact, ~4 extra
     // instructions per value; a softmax term that small is zero next to the row's largest term either way
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
     // P to float16 with the packed convert (two values per instruction; the scalar casts cost three)
-    const uint4 p0 = make_uint4(pack2_rn(s[0], s[1]), pack2_rn(s[2], s[3]), pack2_rn(s[4], s[5]), pack2_rn(s[6], s[7]));
-    const uint4 p1 = make_uint4(pack2_rn(s[8], s[9]), pack2_rn(s[10], s[11]), pack2_rn(s[12], s[13]), pack2_rn(s[14], s[15]));
+    // (pack2_cv, not the inline-asm pack2_rn: these registers are MFMA operands - see pack2_cv)
+    const uint4 p0 = make_uint4(pack2_cv(s[0], s[1]), pack2_cv(s[2], s[3]), pack2_cv(s[4], s[5]), pack2_cv(s[6], s[7]));
+    const uint4 p1 = make_uint4(pack2_cv(s[8], s[9]), pack2_cv(s[10], s[11]), pack2_cv(s[12], s[13]), pack2_cv(s[14], s[15]));
     st.o = mfma(vc0, p0, st.o);
-    st.lsum = mfma(ones, p0, st.lsum);
+    st.lsum = mfma_sum(sel, p0, st.lsum);
     st.o = mfma(vc1, p1, st.o);
-    st.lsum = mfma(ones, p1, st.lsum);
+    st.lsum = mfma_sum(sel, p1, st.lsum);
 }
+template <bool FIRST, bool LAST>
+__device__ __forceinline__ void attn_step_t(AttnState &st, const uint4 &q0, const uint4 &q1, const uint4 &kc0, const uint4 &kc1,
+                                            const uint4 &vc0, const uint4 &vc1, int key0, int seq_len, int h) {
+    f32x16 s = attn_scores<LAST>(st, q0, q1, kc0, kc1, key0, seq_len, h);
+    const float mx = attn_lane_max(s);
+    if (FIRST || __any(mx > kAttnSlack)) {  // wave-uniform; rare after the first tile
+        const float mq = half_max(mx);
+        attn_rescale(st, s, FIRST ? mq : fmaxf(mq, 0.f));  // the reference only rises after the first tile
+    }
+    attn_pv(st, s, vc0, vc1);
+}
+// the single-tile kernels' step (first and last at once)
+__device__ __forceinline__ void attn_step(AttnState &st, const uint4 &q0, const uint4 &q1, const uint4 &kc0, const uint4 &kc1,
+                                          const uint4 &vc0, const uint4 &vc1, bool first, bool last, int key0, int seq_len, int h) {
+    if (first && last) attn_step_t<true, true>(st, q0, q1, kc0, kc1, vc0, vc1, key0, seq_len, h);
+    else if (first) attn_step_t<true, false>(st, q0, q1, kc0, kc1, vc0, vc1, key0, seq_len, h);
+    else if (last) attn_step_t<false, true>(st, q0, q1, kc0, kc1, vc0, vc1, key0, seq_len, h);
+    else attn_step_t<false, false>(st, q0, q1, kc0, kc1, vc0, vc1, key0, seq_len, h);
+}
+// Two query tiles of one (sequence, head) against the same key tile: the K / V fragments are fetched once for both, and the
+// two tiles' chains are independent, so one's exponentials issue beside the other's MFMAs.  The rare branch is shared: a tile
+// whose own condition is false gets delta = 0, which changes nothing (attn_rescale), so each tile's values are exactly
+// attn_step_t's.
+template <bool FIRST, bool LAST>
+__device__ __forceinline__ void attn_step2_t(AttnState &sa, AttnState &sb, const uint4 (&qa)[2], const uint4 (&qb)[2], const uint4 &kc0,
+                                             const uint4 &kc1, const uint4 &vc0, const uint4 &vc1, int key0, int seq_len, int h) {
+    f32x16 s0 = attn_scores<LAST>(sa, qa[0], qa[1], kc0, kc1, key0, seq_len, h);
+    f32x16 s1 = attn_scores<LAST>(sb, qb[0], qb[1], kc0, kc1, key0, seq_len, h);
+    const float mx0 = attn_lane_max(s0), mx1 = attn_lane_max(s1);
+    const bool any0 = FIRST || __any(mx0 > kAttnSlack), any1 = FIRST || __any(mx1 > kAttnSlack);
+    if (any0 || any1) {
+        const float mq0 = half_max(mx0), mq1 = half_max(mx1);
+        attn_rescale(sa, s0, FIRST ? mq0 : any0 ? fmaxf(mq0, 0.f) : 0.f);
+        attn_rescale(sb, s1, FIRST ? mq1 : any1 ? fmaxf(mq1, 0.f) : 0.f);
+    }
+    attn_pv(sa, s0, vc0, vc1);
+    attn_pv(sb, s1, vc0, vc1);
+}
+// attn_step2_t with run-time flags (ONE body; the A/B partner of the peeled loop: -DATTN_PEEL=0)
+__device__ __forceinline__ void attn_step2_rt(AttnState &sa, AttnState &sb, const uint4 (&qa)[2], const uint4 (&qb)[2], const uint4 &kc0,
+                                              const uint4 &kc1, const uint4 &vc0, const uint4 &vc1, bool first, bool last, int key0,
+                                              int seq_len, int h) {
+    f32x16 s0 = attn_scores<false>(sa, qa[0], qa[1], kc0, kc1, key0, seq_len, h);
+    f32x16 s1 = attn_scores<false>(sb, qb[0], qb[1], kc0, kc1, key0, seq_len, h);
+    if (last) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = key0 + fi(r, h) < seq_len;
+            s0[r] = ok ? s0[r] : -__builtin_inff();
+            s1[r] = ok ? s1[r] : -__builtin_inff();
+        }
+    }
+    const float mx0 = attn_lane_max(s0), mx1 = attn_lane_max(s1);
+    const bool any0 = first || __any(mx0 > kAttnSlack), any1 = first || __any(mx1 > kAttnSlack);
+    if (any0 || any1) {
+        const float mq0 = half_max(mx0), mq1 = half_max(mx1);
+        attn_rescale(sa, s0, first ? mq0 : any0 ? fmaxf(mq0, 0.f) : 0.f);
+        attn_rescale(sb, s1, first ? mq1 : any1 ? fmaxf(mq1, 0.f) : 0.f);
+    }
+    attn_pv(sa, s0, vc0, vc1);
+    attn_pv(sb, s1, vc0, vc1);
+}
+// One-body step with run-time flags for ONE query tile (attn_step's four instantiations cost attention3_kernel code size)
+__device__ __forceinline__ void attn_step1_rt(AttnState &st, const uint4 (&q)[2], const uint4 &kc0, const uint4 &kc1, const uint4 &vc0,
+                                              const uint4 &vc1, bool first, bool last, int key0, int seq_len, int h) {
+    f32x16 s = attn_scores<false>(st, q[0], q[1], kc0, kc1, key0, seq_len, h);
+    if (last) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = (key0 + fi(r, h) < seq_len) ? s[r] : -__builtin_inff();
+    }
+    const float mx = attn_lane_max(s);
+    if (first || __any(mx > kAttnSlack)) {
+        const float mq = half_max(mx);
+        attn_rescale(st, s, first ? mq : fmaxf(mq, 0.f));
+    }
+    attn_pv(st, s, vc0, vc1);
+}
+
 // normalise and write the context fragments of the (head, query tile)
 __device__ __forceinline__ void attn_store(AttnState &st, uint4 *__restrict__ out) {
     const float inv = 1.0f / st.lsum[0];
@@ -97,8 +217,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict_
     //   * P stays <= 2^kSlack: float16 holds it with the same relative precision as values <= 1.
     // (~110 -> ~50 VALU instructions per key tile, tools/run_enc_pmc.sh.)
     AttnState st;
+    const uint4 qq[2] = {q0, q1};
     auto step = [&](int kt, const uint4 &kc0, const uint4 &kc1, const uint4 &vc0, const uint4 &vc1) {
-        attn_step(st, q0, q1, kc0, kc1, vc0, vc1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
+        attn_step1_rt(st, qq, kc0, kc1, vc0, vc1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
     };
     // Two key tiles per trip, each in its own registers: a tile's K/V are requested one step ahead.  vmcnt counts in
     // order, so the wait for the older buffer leaves the younger one's loads in flight.  (The requests are unconditional -
@@ -119,6 +240,218 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict_
         }
     }
     attn_store(st, ctx + (size_t)tt * (NFB * 2 * 64) + (size_t)(head * 2) * 64 + lane);
+}
+
+
+// The throughput form (round 4): one wave per (head, UNIT), a unit = two consecutive query tiles of one sequence (its last unit
+// one tile when the sequence has an odd number).  `units[u]` = {first tile | (tiles - 1) << 24, key tiles, sequence length, the sequence's first tile}, built on the host.
+// By the counters the one-tile kernel above drew 24 B/clk per CU from L2 - each (query tile, key tile) step re-reads 4 KiB of
+// K / V - which is what a CU can draw (26-29 B/clk); two query tiles per fetch halve that.
+template <int NQ>
+__device__ __forceinline__ void attn_unit(const uint4 *__restrict__ qf, const uint4 *__restrict__ kf, const uint4 *__restrict__ vf,
+                                          int tt, int n_kt, int seq_len, int seq_first_tile, int head, int lane, uint4 *__restrict__ ctx) {
+    const int h = lane >> 5;
+    uint4 qa[2], qb[2];
+    {
+        const uint4 *qp = qf + ((size_t)(tt * NH + head) * 2) * 64 + lane;
+        qa[0] = enc_load_nt(qp); qa[1] = enc_load_nt(qp + 64);
+        if (NQ == 2) { qb[0] = enc_load_nt(qp + NH * 2 * 64); qb[1] = enc_load_nt(qp + NH * 2 * 64 + 64); }
+    }
+    const size_t kv0 = ((size_t)(seq_first_tile * NH + head) * 2) * 64 + lane;
+    AttnState sa, sb;
+    struct KV { uint4 k0, k1, v0, v1; };
+    auto load = [&](int kt, KV &d) {
+        const size_t kb = kv0 + (size_t)kt * (NH * 2 * 64);
+        d.k0 = kf[kb]; d.k1 = kf[kb + 64]; d.v0 = vf[kb]; d.v1 = vf[kb + 64];
+    };
+#define ATTN_STEP(FIRST, LAST, kt, b)                                                                              \
+    do {                                                                                                           \
+        if (NQ == 2) attn_step2_t<FIRST, LAST>(sa, sb, qa, qb, b.k0, b.k1, b.v0, b.v1, 32 * (kt), seq_len, h);     \
+        else attn_step_t<FIRST, LAST>(sa, qa[0], qa[1], b.k0, b.k1, b.v0, b.v1, 32 * (kt), seq_len, h);           \
+    } while (0)
+    // The first and the last key tile are peeled (attn_step_t); in between two key tiles per trip, each in its own registers,
+    // a tile's K / V requested one step ahead: vmcnt counts in order, so the wait for the older buffer leaves the younger one's
+    // loads in flight.
+#ifndef ATTN_PEEL
+#define ATTN_PEEL 1
+#endif
+    KV A, B;
+    load(0, A);
+#if !ATTN_PEEL
+    for (int kt = 0; kt < n_kt; kt += 2) {
+        load(min(kt + 1, n_kt - 1), B);
+        if (NQ == 2) attn_step2_rt(sa, sb, qa, qb, A.k0, A.k1, A.v0, A.v1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
+        else attn_step(sa, qa[0], qa[1], A.k0, A.k1, A.v0, A.v1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
+        if (kt + 1 < n_kt) {
+            load(min(kt + 2, n_kt - 1), A);
+            if (NQ == 2) attn_step2_rt(sa, sb, qa, qb, B.k0, B.k1, B.v0, B.v1, false, kt + 1 == n_kt - 1, 32 * (kt + 1), seq_len, h);
+            else attn_step(sa, qa[0], qa[1], B.k0, B.k1, B.v0, B.v1, false, kt + 1 == n_kt - 1, 32 * (kt + 1), seq_len, h);
+        }
+    }
+#else
+    if (n_kt == 1) {
+        ATTN_STEP(true, true, 0, A);
+    } else {
+        load(1, B);
+        ATTN_STEP(true, false, 0, A);
+        int kt = 1;  // B holds tile kt
+        while (kt + 2 < n_kt) {
+            load(kt + 1, A);
+            ATTN_STEP(false, false, kt, B);
+            load(kt + 2, B);
+            ATTN_STEP(false, false, kt + 1, A);
+            kt += 2;
+        }
+        if (kt + 1 < n_kt) {
+            load(kt + 1, A);
+            ATTN_STEP(false, false, kt, B);
+            ATTN_STEP(false, true, kt + 1, A);
+        } else {
+            ATTN_STEP(false, true, kt, B);
+        }
+    }
+#endif
+#undef ATTN_STEP
+    uint4 *out = ctx + (size_t)tt * (NFB * 2 * 64) + (size_t)(head * 2) * 64 + lane;
+    attn_store(sa, out);
+    if (NQ == 2) attn_store(sb, out + NFB * 2 * 64);
+}
+__global__ __launch_bounds__(256) void attention2_kernel(const uint4 *__restrict__ qf, const uint4 *__restrict__ kf,
+                                                         const uint4 *__restrict__ vf, const int4 *__restrict__ units, int n_units,
+                                                         uint4 *__restrict__ ctx) {
+    const int lane = threadIdx.x & 63;
+    // XCD x takes the x-th eighth of the (head, unit) list, as attention_kernel: the units of one (head, sequence) meet in one L2
+    const int n_wg = gridDim.x, per_xcd = (n_wg + 7) >> 3;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int w = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));  // wave-uniform: scalar arithmetic, scalar descriptor load
+    if ((blockIdx.x >> 3) >= per_xcd || w >= n_units * NH) return;
+    const int head = w / n_units, u = w - head * n_units;
+    // the unit's descriptor in ONE wave-uniform (scalar) load: {first tile | (tiles - 1) << 24, key tiles, sequence length,
+    // the sequence's first tile} - a wave lives for a handful of key tiles, so every dependent hop in front of its first
+    // MFMA (descriptor -> tile info -> Q / K addresses were three) is a large share of its life
+    typedef int __attribute__((ext_vector_type(4))) i32x4;
+    const i32x4 d = *reinterpret_cast<const __attribute__((address_space(4))) i32x4 *>(reinterpret_cast<uintptr_t>(units + u));
+    const int tt = d.x & 0xffffff;
+    if (d.x >> 24) attn_unit<2>(qf, kf, vf, tt, d.y, d.z, d.w, head, lane, ctx);
+    else attn_unit<1>(qf, kf, vf, tt, d.y, d.z, d.w, head, lane, ctx);
+}
+
+
+// PERSISTENT form (round 4, ENC_ATT = 3): one 8-wave workgroup per CU; every wave walks its own list of (head, unit) items
+// and never meets another wave (no barrier).  What the counters said about the one-wave-per-item kernels above: a wave lives
+// for a handful of key tiles, and in front of its first MFMA stand two or three DEPENDENT memory hops (descriptor -> Q / K
+// addresses -> data); with one key tile requested ahead in registers its s_waitcnt share was a third of its cycles, and two
+// waves per SIMD cannot hide that.  Here a wave's memory requests run AHEAD of its arithmetic through a private LDS ring:
+//   * the items' Q tiles and K / V tiles form one flat sequence of 4-KiB ENTRIES: Q(item), KV(item, 0), KV(item, 1), ...,
+//     Q(next item), KV(next item, 0), ...; each entry is four 1-KiB LDS-DMA pieces (global_load_lds_dwordx4: no registers);
+//   * a prefetch cursor issues entry e + ATT3_AHEAD while entry e is computed on - across item boundaries, so the next
+//     item's descriptor, Q and first keys arrive during this item's last steps;
+//   * vmcnt counts in issue order and every entry is exactly four pieces, so "entry e has landed" is s_waitcnt
+//     vmcnt(4 * ATT3_AHEAD) (the context stores of an item's end sit in the same queue: the wait is then a little early, never late).
+// Items are sorted by key tiles (descending, stable: a sequence's units stay together) on the host and dealt to the waves of
+// an XCD with a stride, so every wave gets a cross-section of lengths; XCD x takes the x-th eighth of the (head-major) list,
+// as the kernels above, so a (sequence, head)'s K / V meet in one L2.
+#ifndef ATT3_AHEAD
+#define ATT3_AHEAD 2
+#endif
+constexpr int ATT3_SLOTS = ATT3_AHEAD + 1;
+constexpr int ATT3_WAVES = 8;
+constexpr int ATT3_WAVE_LDS = ATT3_SLOTS * 4096;
+constexpr int ATT3_LDS_BYTES = ATT3_WAVES * ATT3_WAVE_LDS;
+
+__global__ __launch_bounds__(64 * ATT3_WAVES, 1) void attention3_kernel(const uint4 *__restrict__ qf, const uint4 *__restrict__ kf,
+                                                                        const uint4 *__restrict__ vf, const int4 *__restrict__ units,
+                                                                        int n_units, uint4 *__restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef int __attribute__((ext_vector_type(4))) i32x4;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    const uint32_t ring = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)(wave * ATT3_WAVE_LDS));
+    // this wave's items: XCD x = blockIdx.x & 7 owns items [x * per, (x + 1) * per) of the head-major list, its waves take
+    // them with stride (waves of the XCD)
+    const int total = n_units * NH, per = (total + 7) >> 3;
+    const int xcd = blockIdx.x & 7, n_xw = (((int)gridDim.x - xcd + 7) >> 3) * ATT3_WAVES;
+    const int lw = ((int)blockIdx.x >> 3) * ATT3_WAVES + wave;
+    const int lo = xcd * per, hi = min(total, lo + per);
+
+    struct Item { int tt, two, n_kt, seq_len, first, head; };  // all wave-uniform
+    auto fetch = [&](int j, Item &it) {  // (a scalar load: the descriptor table is read-only for the launch)
+        const int head = j / n_units, u = j - head * n_units;
+        const i32x4 d = *reinterpret_cast<const __attribute__((address_space(4))) i32x4 *>(reinterpret_cast<uintptr_t>(units + u));
+        it.tt = d.x & 0xffffff; it.two = d.x >> 24; it.n_kt = d.y; it.seq_len = d.z; it.first = d.w; it.head = head;
+    };
+    // entry `ph` of an item: -1 = its Q tile(s), kt >= 0 = key tile kt; four pieces into ring slot `slot`
+    auto issue = [&](const Item &it, int ph, int slot) {
+        const uint32_t dst = ring + (uint32_t)slot * 4096u;
+        if (ph < 0) {
+            const uint4 *q0 = qf + ((size_t)(it.tt * NH + it.head) * 2) * 64;
+            const uint4 *q1 = it.two ? q0 + NH * 2 * 64 : q0;  // a one-tile unit fetches its tile twice: every entry is four pieces
+            enc_glds16_s_nt(q0, lane16, dst);
+            enc_glds16_s_nt(q0 + 64, lane16, dst + 1024);
+            enc_glds16_s_nt(q1, lane16, dst + 2048);
+            enc_glds16_s_nt(q1 + 64, lane16, dst + 3072);
+        } else {
+            const size_t o = ((size_t)((it.first + ph) * NH + it.head) * 2) * 64;
+            enc_glds16_s(kf + o, lane16, dst);
+            enc_glds16_s(kf + o + 64, lane16, dst + 1024);
+            enc_glds16_s(vf + o, lane16, dst + 2048);
+            enc_glds16_s(vf + o + 64, lane16, dst + 3072);
+        }
+    };
+    int j = lo + lw;
+    if (j >= hi) return;
+    // prefetch cursor: item pf (index pj), entry pph; `e_issued` entries issued so far, `e_done` consumed
+    Item cur, pf;
+    fetch(j, cur);
+    pf = cur;
+    int pj = j, pph = -1, e_issued = 0, e_done = 0;
+    bool pf_live = true;
+    auto advance = [&]() {  // issue the cursor's entry and move the cursor
+        if (!pf_live) return;
+        issue(pf, pph, e_issued % ATT3_SLOTS);
+        ++e_issued;
+        if (++pph == pf.n_kt) {
+            pj += n_xw;
+            pph = -1;
+            if (pj < hi) fetch(pj, pf);
+            else pf_live = false;
+        }
+    };
+    auto landed = [&]() {  // entry e_done is in LDS (every entry older than the ATT3_AHEAD youngest ones)
+        if (e_issued - e_done > ATT3_AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * ATT3_AHEAD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail: fewer entries behind it than the ring holds
+    };
+#pragma unroll
+    for (int i = 0; i < ATT3_AHEAD; ++i) advance();
+    for (;;) {
+        // ---- the item's Q entry ----
+        advance();
+        landed();
+        const uint4 *qs = reinterpret_cast<const uint4 *>(smem + (size_t)wave * ATT3_WAVE_LDS + (size_t)(e_done % ATT3_SLOTS) * 4096) + lane;
+        uint4 qa[2], qb[2];
+        qa[0] = qs[0]; qa[1] = qs[64]; qb[0] = qs[128]; qb[1] = qs[192];
+        ++e_done;
+        AttnState sa, sb;
+        const int n_kt = cur.n_kt, seq_len = cur.seq_len;
+        const bool two = cur.two != 0;
+        for (int kt = 0; kt < n_kt; ++kt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous entry's fragments are in registers: its slot may be refilled
+            advance();
+            landed();
+            const uint4 *kv = reinterpret_cast<const uint4 *>(smem + (size_t)wave * ATT3_WAVE_LDS + (size_t)(e_done % ATT3_SLOTS) * 4096) + lane;
+            const uint4 k0 = kv[0], k1 = kv[64], v0 = kv[128], v1 = kv[192];
+            ++e_done;
+            if (two) attn_step2_rt(sa, sb, qa, qb, k0, k1, v0, v1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
+            else attn_step1_rt(sa, qa, k0, k1, v0, v1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
+        }
+        uint4 *out = ctx + (size_t)cur.tt * (NFB * 2 * 64) + (size_t)(cur.head * 2) * 64 + lane;
+        attn_store(sa, out);
+        if (two) attn_store(sb, out + NFB * 2 * 64);
+        j += n_xw;
+        if (j >= hi) break;
+        fetch(j, cur);  // (the cursor fetched the same descriptor earlier: a scalar-cache hit)
+    }
 }
 
 
@@ -219,6 +552,27 @@ int32_t launch_ln_qkv_attention_single(const float *Y, const uint4 *resid, const
                                        uint4 *act_out, const uint4 *wqkv, const float *bqkv, const TileInfo *ti, int n_tiles,
                                        uint4 *ctx, hipStream_t stream) {
     ln_qkv_attention_single_kernel<<<dim3(NH, n_tiles), dim3(256), 0, stream>>>(Y, resid, bias, gamma, beta, act_out, wqkv, bqkv, ti, ctx);
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
+int32_t launch_attention2(const uint4 *qf, const uint4 *kf, const uint4 *vf, const int32_t *units, int n_units, uint4 *ctx,
+                          hipStream_t stream) {
+    const int n_wg = (n_units * NH + 3) / 4;
+    attention2_kernel<<<dim3((n_wg + 7) / 8 * 8), dim3(256), 0, stream>>>(qf, kf, vf, reinterpret_cast<const int4 *>(units), n_units, ctx);
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
+int32_t attention3_prepare() {
+    auto kern = attention3_kernel;
+    MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ATT3_LDS_BYTES));
+    return MIR_OK;
+}
+// units: n_units x int4 sorted by key tiles, descending (see attention3_kernel); n_cus workgroups
+int32_t launch_attention3(const uint4 *qf, const uint4 *kf, const uint4 *vf, const int32_t *units, int n_units, uint4 *ctx, int n_cus,
+                          hipStream_t stream) {
+    attention3_kernel<<<dim3(n_cus), dim3(64 * ATT3_WAVES), ATT3_LDS_BYTES, stream>>>(qf, kf, vf, reinterpret_cast<const int4 *>(units), n_units, ctx);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }

@@ -61,7 +61,19 @@ constexpr int FFN_PARAM_FLOATS = FF + 3 * H;
 __device__ __forceinline__ int fi(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+#if defined(ENC_ABL_1616)
+    // TIMING-ONLY ablation (results wrong by design): the same operands, flops and matrix-pipe cycles as two
+    // v_mfma_f32_16x16x32_f16 - what the chip's clock does with that shape in these kernels (MI355X_MICROARCH.md, DVFS 7)
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b), __builtin_bit_cast(f16x8, a), c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
@@ -78,6 +90,17 @@ __device__ __forceinline__ uint32_t pack2_rn(float a, float b) {
     uint32_t r;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+}
+// The same conversion (v_cvt_pk_f16_f32, round to nearest even) in a form hipcc can SEE: for values that feed an MFMA operand.
+// An MFMA that reads a register a vector instruction has just written needs wait states in between; hipcc pads them for
+// instructions it knows, never around inline asm (cdna_hip_programming.md 3: "hipcc pads nothing inside asm") - with
+// pack2_rn in front of the attention's P x V products the padding was a matter of what the scheduler happened to put in
+// between (rounds 1-3: two unrelated instructions; round 4's restructured loop: one, and the MFMA read stale operands).
+__device__ __forceinline__ uint32_t pack2_cv(float a, float b) {
+    typedef float __attribute__((ext_vector_type(2))) f32x2v;
+    typedef _Float16 __attribute__((ext_vector_type(2))) f16x2v;
+    const f32x2v v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2v));
 }
 // registers 8*s2 .. 8*s2+7 of an accumulator -> one float16 fragment
 __device__ __forceinline__ uint4 acc_to_frag(const f32x16 &a, int s2) {

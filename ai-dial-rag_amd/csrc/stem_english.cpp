@@ -14,6 +14,7 @@
 #include <string>
 
 #include "common.h"
+#include "text_common.h"
 
 namespace {
 
@@ -279,9 +280,10 @@ void decode(const unsigned char *p, size_t n, U &out) {
         i += len;
     }
 }
-size_t encode(const U &w, unsigned char *dst) {
+size_t encode_n(const char32_t *w, size_t n, unsigned char *dst) {
     size_t o = 0;
-    for (char32_t v : w) {
+    for (size_t i = 0; i < n; ++i) {
+        const char32_t v = w[i];
         if (v >= 0x110000u) dst[o++] = (unsigned char)(v - 0x110000u);
         else if (v < 0x80) dst[o++] = (unsigned char)v;
         else if (v < 0x800) { dst[o++] = 0xC0 | (v >> 6); dst[o++] = 0x80 | (v & 0x3F); }
@@ -290,8 +292,17 @@ size_t encode(const U &w, unsigned char *dst) {
     }
     return o;
 }
+size_t encode(const U &w, unsigned char *dst) { return encode_n(w.data(), w.size(), dst); }
 
 }  // namespace
+
+namespace mir {
+namespace text {
+void snowball_english(U &word, U &r1, U &r2) { stem(word, r1, r2); }
+void utf8_decode(const unsigned char *p, size_t n, U &out) { decode(p, n, out); }
+size_t utf8_encode(const char32_t *w, size_t n, unsigned char *dst) { return encode_n(w, n, dst); }
+}  // namespace text
+}  // namespace mir
 
 extern "C" {
 

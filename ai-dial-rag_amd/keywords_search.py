@@ -176,10 +176,13 @@ def front_end_info() -> dict:
             "stopwords": "179-word list restated from memory (unpinned)", "stemmer": "native Snowball (pinned)"}
 
 
+_MAYBE_MULTI = re.compile(r"[.?!][\"'\u201d\u2019)\]]*\s")  # cheap necessary condition of _SENT_END (not a full split per call)
+
+
 def _note_multi_sentence(text: str) -> None:
     """The one place the approximation can change tokens: a text the restated splitter cuts into several sentences."""
     global _warned_multi_sentence
-    if FRONT_END == "restated" and not _warned_multi_sentence and len(split_sentences(text)) > 1:
+    if FRONT_END == "restated" and not _warned_multi_sentence and _MAYBE_MULTI.search(text) and len(split_sentences(text)) > 1:
         _warned_multi_sentence = True
         logger.warning("keywords_preprocess: tokenising multi-sentence text with the approximate sentence splitter (NLTK data absent); "
                        "sentence-final periods may be attached differently from the reference's word_tokenize.  Pass stored "
@@ -188,6 +191,57 @@ def _note_multi_sentence(text: str) -> None:
 
 def word_tokenize(text: str) -> List[str]:
     return _front_end()[1](text)
+
+
+def _native_batch(texts: Sequence[str], mode: int, threads: int) -> List[List[str]]:
+    """``mir_keywords_preprocess`` over a batch: one call, all host cores, the GIL released for its duration.  The Python
+    side is what is left on one thread (a str object per token is the product's own format), so it is kept lean: one
+    encode of the joined batch when it is pure ASCII, one decode + split per chunk on the way back."""
+    import numpy as np
+
+    from . import _native as nat
+
+    n = len(texts)
+    if n == 0:
+        return []
+    blob = "".join(texts).encode("utf-8", "surrogatepass")
+    offsets = np.zeros(n + 1, dtype=np.int64)  # byte offsets: a text's character count when it is ASCII (the common case)
+    np.cumsum([len(t) if t.isascii() else len(t.encode("utf-8", "surrogatepass")) for t in texts], out=offsets[1:])
+    assert int(offsets[-1]) == len(blob)
+    res = C.c_void_p()
+    nat.check(nat.lib.mir_keywords_preprocess(blob, offsets.ctypes.data, n, threads, mode, C.byref(res)))
+    try:
+        ptr, nbytes, counts_p, ends_p, ntok = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        nat.check(nat.lib.mir_kwp_result_data(res, C.byref(ptr), C.byref(nbytes), C.byref(counts_p), C.byref(ends_p), C.byref(ntok)))
+        raw = C.string_at(ptr.value, nbytes.value) if nbytes.value else b""
+        ends = np.ctypeslib.as_array(C.cast(ends_p, C.POINTER(C.c_int64)), shape=(n,)).tolist()
+    finally:
+        nat.lib.mir_kwp_result_free(res)
+    out, a = [], 0
+    for b in ends:  # every token is FOLLOWED by a NUL: [a, b - 1) holds a text's tokens, NUL-separated
+        out.append(raw[a : b - 1].decode("utf-8", "surrogatepass").split(_SEP) if b > a else [])
+        a = b
+    return out
+
+
+def keywords_preprocess_batch(texts: Sequence[str], threads: int = 0) -> List[List[str]]:
+    """``[keywords_preprocess(t) for t in texts]`` (keywords_search.py:13-18 per chunk, bm25_retriever.py:30-39,112) in ONE
+    native call on all host cores (`threads` <= 0) - csrc/keywords_preprocess.cpp.  With NLTK and its data installed the
+    tokenizer and the stopword list are NLTK's (exact by construction; only the stemmer is native then)."""
+    stop, tokenize = _front_end()
+    if FRONT_END == "nltk":
+        return [stem_tokens([t for t in tokenize(text) if t not in stop]) for text in texts]
+    return _native_batch(texts, 0, threads)
+
+
+def word_tokenize_batch(texts: Sequence[str], threads: int = 0) -> List[List[str]]:
+    """``[word_tokenize(t) for t in texts]`` of the RESTATED front end, natively."""
+    return _native_batch(texts, 1, threads)
+
+
+def treebank_tokenize_batch(sentences: Sequence[str], threads: int = 0) -> List[List[str]]:
+    """``[NLTKWordTokenizer().tokenize(s) for s in sentences]`` natively (what the pinned fixture checks)."""
+    return _native_batch(sentences, 2, threads)
 
 
 def keywords_preprocess(text: str) -> List[str]:

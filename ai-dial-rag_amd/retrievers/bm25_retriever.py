@@ -13,6 +13,7 @@ launch); a single query is the B = 1 case of the same kernels.
 """
 
 import asyncio
+from concurrent.futures import ThreadPoolExecutor
 import ctypes as C
 import threading
 from typing import Callable, Dict, Hashable, Iterable, List, Optional, Sequence, Tuple
@@ -135,9 +136,34 @@ class TextIndexItem:
         self.tokenized_text = tokenized_text
 
 
-def _build_text_index_chunks(chunks, preprocess: Callable[[str], List[str]]) -> List[TextIndexItem]:
-    # bm25_retriever.py:30-39
-    return [TextIndexItem(chunk_index=i, tokenized_text=preprocess(chunk.text)) for i, chunk in enumerate(chunks)]
+# chunks per native call: large enough to occupy every host core (32 texts per work item), small enough that the Python
+# side's token lists of one call stay cache-sized
+_PREPROCESS_BATCH = 4096
+
+
+def _build_text_index_chunks(chunks, preprocess: Optional[Callable[[str], List[str]]]) -> List[TextIndexItem]:
+    # bm25_retriever.py:30-39.  Upstream maps keywords_preprocess over the chunks on a CPU pool, pure Python per token;
+    # here the default preprocess is ONE native call per _PREPROCESS_BATCH chunks on all host cores with the GIL released
+    # (keywords_search.keywords_preprocess_batch -> mir_keywords_preprocess), a caller's own callable is mapped as upstream.
+    if preprocess is not None:
+        return [TextIndexItem(chunk_index=i, tokenized_text=preprocess(chunk.text)) for i, chunk in enumerate(chunks)]
+    from ..keywords_search import keywords_preprocess_batch
+
+    out: List[TextIndexItem] = []
+    starts = range(0, len(chunks), _PREPROCESS_BATCH)
+    one = lambda b0: keywords_preprocess_batch([c.text for c in chunks[b0 : b0 + _PREPROCESS_BATCH]])
+    if len(starts) <= 1:
+        batches = map(one, starts)
+    else:
+        # two batches in flight: the native call of one (GIL released, all cores) runs beside the Python side of the other
+        # (a str object per token and a list per chunk: single-threaded by nature)
+        pool = ThreadPoolExecutor(2, thread_name_prefix="mir-kwp")
+        batches = pool.map(one, starts)
+    for b0, toks in zip(starts, batches):
+        out.extend(TextIndexItem(chunk_index=b0 + i, tokenized_text=t) for i, t in enumerate(toks))
+    if len(starts) > 1:
+        pool.shutdown(wait=False)
+    return out
 
 
 # str -> term id for every token this process has indexed (ids are dense in first-seen order; never reused)
@@ -287,6 +313,4 @@ class BM25Retriever:
     @staticmethod
     async def build_index(chunks, stageio=None, preprocess: Optional[Callable[[str], List[str]]] = None) -> List[TextIndexItem]:
         # bm25_retriever.py:106-114 (runs on the indexing CPU pool upstream; tokenisation is host work)
-        if preprocess is None:
-            from ..keywords_search import keywords_preprocess as preprocess
-        return await asyncio.get_running_loop().run_in_executor(None, _build_text_index_chunks, chunks, preprocess)
+        return await asyncio.get_running_loop().run_in_executor(None, _build_text_index_chunks, list(chunks), preprocess)

@@ -31,6 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md; never the 2:1-sparsity figure)
+MAIN_LEG_CHECK_QUERIES = 2
 CHUNK_ROWS = 500_000   # corpus is generated in fixed global chunks so every N sees the same rows
 PRECONDITION_STEPS = 12  # untimed launches before timing starts (W of them are the warm-up steps), see main()
 
@@ -203,7 +205,7 @@ def c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex,
         "ms_per_step": round(1e3 * elapsed / steps, 4),
         "qps": round(B * steps / elapsed, 1),
         "index_hbm_bytes_per_gpu": hbm,
-        "roofline": {"bound": "hbm", "kernel": "sieve_h16_kernel: two filter launches over the float16 image with sieve_verify_kernel + sieve_select_kernel between them (round 2: scan_topk_h16_kernel with candidate lists; MIR_NO_SIEVE16=1 selects it)", "bytes_per_launch": bytes_pass,
+        "roofline": {"bound": "hbm", "kernel": "sieve_h16_kernel: two filter launches over the float16 image with sieve_scatter_kernel + sieve_select_kernel between them (round 2: scan_topk_h16_kernel with candidate lists; MIR_NO_SIEVE16=1 selects it)", "bytes_per_launch": bytes_pass,
                      "avg_launch_ms": round(avg_ms, 4), "achieved": round(bytes_pass / (avg_ms * 1e-3) / 1e9, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_pass / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "launches": launches},
@@ -314,17 +316,17 @@ def variant_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher, kind)
         same &= bool(np.array_equal(got_rows[i, : got_cnt[i]], want))
     t_oracle = time.perf_counter() - t0
     del host
-    bytes_launch = n * d * 4 + (0 if args.metric == "inner_product" else 4 * n) + B * d * 4 + B * k * 12
+    d_pad = (d + 127) // 128 * 128
+    bytes_launch = n * d_pad * 2 + (0 if args.metric == "inner_product" else 4 * n) + B * d * 4 + B * k * 12  # what the sieve moves
     avg_ms = scan_ms / max(launches, 1)
     res = {"workload": f"{kind}: {n} x {d} float32 unit rows, {args.metric}, k={k}, {B} queries per step, {steps} steps of fresh queries",
            "ms_per_step": round(1e3 * el / steps, 4), "qps": round(B * steps / el, 1),
            "scan_bracket_ms": round(avg_ms, 4),
-           "roofline_frac": round(bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "hbm_frac": round(bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "mfma_frac": round(2.0 * n * d_pad * B / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS_BF16, 4),
            "exact_pass_queries": exact, "exact_pass_share": round(exact / (steps * B), 4),
            "queries_aimed_at_clusters_share": round(aimed / pool, 2),
            "ids_identical_to_cpu_oracle_on_2_queries": same, "oracle_s": round(t_oracle, 1)}
-    res["frac_streamed_bytes"] = round((n * ((d + 127) // 128 * 128) * 2 + (0 if args.metric == "inner_product" else 4 * n))
-                                       / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if stats:
         res["scan_stats"] = stats
     return res
@@ -528,15 +530,92 @@ def build_embeddings_leg(np, torch, args, local_rank, tmpdir):
         t1 = time.perf_counter()
         ids = tok(texts[:1024], add_special_tokens=True, truncation=True, max_length=512)["input_ids"]
         t_tok = (time.perf_counter() - t1) / 1024
-        return {"chunks_per_s": rates[-1], "chunks_per_s_each_run": rates, "chunks": n, "outer_batch": emb.EMBEDDINGS_BATCH_SIZE,
-                "shared_encoder_passes": enc._doc_commit().passes - p0,
-                "mean_tokens_per_chunk": round(float(np.mean([len(x) for x in ids])), 1),
-                "host_tokenise_us_per_chunk_1thread": round(t_tok * 1e6, 1),
-                "note": "texts in, List[np.ndarray] out; includes WordPiece tokenisation (native, mir_wordpiece_encode) and result hand-over",
-                "ok": bool(len(out) == n)}
+        res = {"chunks_per_s": rates[-1], "chunks_per_s_each_run": rates, "chunks": n, "outer_batch": emb.EMBEDDINGS_BATCH_SIZE,
+               "shared_encoder_passes": enc._doc_commit().passes - p0,
+               "mean_tokens_per_chunk": round(float(np.mean([len(x) for x in ids])), 1),
+               "host_tokenise_us_per_chunk_1thread": round(t_tok * 1e6, 1),
+               "note": "texts in, List[np.ndarray] out; includes WordPiece tokenisation (native, mir_wordpiece_encode) and result hand-over",
+               "ok": bool(len(out) == n)}
+        res["both_builders"] = both_builders_leg(np, asyncio, emb, words, rng, n)
+        return res
     finally:
         emb.set_bge_embedding_impl(None)
         enc.close()
+
+
+def prose_chunks(np, words, rng, n):
+    """Synthetic chunk TEXTS for the keyword builder (and, in the combined leg, for the encoder too): sentences of 6-22 words of
+    the synthetic vocabulary with capitals, commas, periods, a few contractions, quotes and stopwords, ~1000 characters per
+    chunk (the product's chunk size) - prose-shaped input for word_tokenize; the words themselves mean nothing."""
+    stop = ["the", "of", "and", "a", "to", "in", "is", "that", "it", "was", "for", "on", "are", "as", "with", "his", "they", "be", "at", "this"]
+    extra = ["isn't", "don't", "it's", "we're", "cannot", "U.S.", "e.g.", "1,000", "3.5%", "(see", "above)", '"quoted"', "--"]
+    out = []
+    for _ in range(n):
+        parts, length, target = [], 0, int(rng.integers(800, 1100))
+        while length < target:
+            k = int(rng.integers(6, 23))
+            ws = [str(w) for w in rng.choice(words, k)]
+            for i in range(k):
+                r = rng.random()
+                if r < 0.30:
+                    ws[i] = stop[int(rng.integers(len(stop)))]
+                elif r < 0.33:
+                    ws[i] = extra[int(rng.integers(len(extra)))]
+                if rng.random() < 0.08 and i + 1 < k:
+                    ws[i] += ","
+            ws[0] = ws[0][:1].upper() + ws[0][1:]
+            sent = " ".join(ws) + (".", ".", ".", "?", "!")[int(rng.integers(5))]
+            parts.append(sent)
+            length += len(sent) + 1
+        out.append(" ".join(parts))
+    return out
+
+
+def both_builders_leg(np, asyncio, emb, words, rng, n):
+    """Index build through BOTH builders of the product surface, as load_document_impl runs them in one TaskGroup
+    (documents.py:188-198): `BM25Retriever.build_index` (bm25_retriever.py:106-114: keywords_preprocess per chunk ->
+    `tokenized_text`) and `build_embeddings` (embeddings.py:102-108) over the same chunk texts - each alone, then together."""
+    from aidial_rag_amd import keywords_search as ks
+    from aidial_rag_amd.retrievers.bm25_retriever import BM25Retriever
+
+    class Chunk:  # what the builders read of a chunk (document_loaders' Chunk.text)
+        __slots__ = ("text",)
+
+        def __init__(self, t):
+            self.text = t
+
+    texts = prose_chunks(np, words, rng, n)
+    chunks = [Chunk(t) for t in texts]
+    asyncio.run(BM25Retriever.build_index(chunks[:512]))  # warm-up (front-end choice, thread start)
+    rates = {"bm25": [], "embeddings": [], "together": []}
+    items = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        items = asyncio.run(BM25Retriever.build_index(chunks))
+        rates["bm25"].append(round(n / (time.perf_counter() - t0), 1))
+        t0 = time.perf_counter()
+        embs = asyncio.run(emb.build_embeddings(texts))
+        rates["embeddings"].append(round(n / (time.perf_counter() - t0), 1))
+
+        async def both():
+            return await asyncio.gather(BM25Retriever.build_index(chunks), emb.build_embeddings(texts))
+
+        t0 = time.perf_counter()
+        it2, em2 = asyncio.run(both())
+        rates["together"].append(round(n / (time.perf_counter() - t0), 1))
+    t0 = time.perf_counter()
+    ref = [ks.keywords_preprocess(t) for t in texts[:64]]  # the per-chunk Python mirror (what round 3's build_index ran, one thread)
+    t_py = (time.perf_counter() - t0) / 64
+    return {"through_bm25_build_index_chunks_per_s": rates["bm25"][-1], "through_build_embeddings_chunks_per_s": rates["embeddings"][-1],
+            "both_builders_together_chunks_per_s": rates["together"][-1], "each_run": rates, "chunks": n,
+            "mean_characters_per_chunk": round(float(np.mean([len(t) for t in texts])), 1),
+            "mean_keyword_tokens_per_chunk": round(float(np.mean([len(i.tokenized_text) for i in items])), 1),
+            "host_threads": os.cpu_count(), "front_end": ks.front_end_info()["front_end"],
+            "python_mirror_one_thread_chunks_per_s": round(1.0 / t_py, 1),
+            "native_equals_python_mirror_on_64_chunks": bool(all(a == b.tokenized_text for a, b in zip(ref, items))),
+            "note": "texts in -> TextIndexItem.tokenized_text (List[str]) out; mir_keywords_preprocess on all host cores, "
+                    "two batches in flight; what is left on one Python thread is a str object per token",
+            "ok": bool(len(items) == n and len(embs) == n and len(it2) == n and len(em2) == n)}
 
 
 def bm25_grouping_on_device(np, torch, device, indptr, toks, vocab):
@@ -807,6 +886,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     flags_total = flags_all[n_warm:].sum(dtype=torch.int64).reshape(())
+    # the LAST timed step's own answers (not a separate index): compared with the CPU oracle over ALL rows further down
+    last_s = ((n_warm + args.steps - 1) * B) % (nq_pool - B + 1)
+    last_rows, last_cnt = out[1][:MAIN_LEG_CHECK_QUERIES].cpu().numpy(), out[2][:MAIN_LEG_CHECK_QUERIES].cpu().numpy()
+    last_q = queries[last_s : last_s + MAIN_LEG_CHECK_QUERIES].cpu().numpy()
     launches, scan_ms = index.profile_read(reset=True)
     sieve_stats = index.scan_stats(reset=True)
     bracket_over = "the timed region"
@@ -831,12 +914,13 @@ def main():
     qps = B * args.steps / elapsed
 
     # ---- roofline of the dominant kernel, per shard pass ----
-    # `achieved` / `frac` follow the contract: SURVEY.md 8(d)'s ALGORITHMIC bytes of a pass - shard rows * d * 4 + 4 B/row norm column
-    # (sqeuclid/cosine) + the query tile + its results - over the measured duration.  Since round 3 a float32 shard of >= 32K rows at
-    # d <= 384 is searched by the sieve (csrc/vec_kernels_sieve.h), which STREAMS only the bf16 hi blocks of the index image - half of
-    # those bytes (`traffic`, from the PMC counters, shows it: 0.51 x the algorithmic bytes): `streamed_bytes_per_launch` /
-    # `frac_streamed_bytes` price what actually crosses the HBM interface, side by side.  At 256 queries per pass the filter is as much
-    # matrix-bound as stream-bound (`mfma_*`: the hi*hi products of a pass against the dense bf16 peak).
+    # `bytes_per_launch` = what the dominant kernel's ALGORITHM moves per shard pass.  Since round 3 a float32 shard of >= 32K rows at
+    # d <= 384 is searched by the sieve (csrc/vec_kernels_sieve.h), whose filter streams only the bf16 hi blocks of the index image:
+    # rows * d_pad * 2 + the norm column + the query tile + its results (`traffic`, from the PMC counters, confirms it: 1.002 x).
+    # SURVEY.md 8(d)'s figure for a float32 pass (rows * d * 4 + ...) is kept beside it as `survey_bytes`; the ratio of the two rates
+    # is `speedup_vs_f32_stream_at_peak` (how many times faster the pass is than a float32 stream at 8 TB/s could be - NOT a fraction
+    # of any peak).  At 256 queries per pass the filter is as much matrix-bound as stream-bound, so both fractions are computed and
+    # `bound` / `achieved` / `peak` / `unit` / `frac` are those of whichever roof the launch is closer to; neither can exceed 1.
     n_loc = hi - lo
     aux = 0 if args.metric == "inner_product" else 4 * n_loc
     wide = d <= 384 and d > 64 and k <= 52
@@ -844,11 +928,11 @@ def main():
     qpl = (256 if B > 128 else 128) if sieve else 128 if wide else 32
     q_launch = min(B, qpl)  # queries actually riding one launch
     passes = -(-B // qpl)   # launches groups per step (1 at the default batch)
-    bytes_launch = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
+    survey_bytes = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
     d_pad = (d + 127) // 128 * 128
-    streamed = (n_loc * d_pad * 2 + aux + q_launch * d * 4 + q_launch * k * 12) if sieve else bytes_launch
+    bytes_launch = (n_loc * d_pad * 2 + aux + q_launch * d * 4 + q_launch * k * 12) if sieve else survey_bytes
     avg_ms = scan_ms / max(launches, 1)
-    achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+    hbm_gbs = bytes_launch / (avg_ms * 1e-3) / 1e9
     # HBM traffic per launch comes from PMC counters, which cannot be collected inside this run (rocprofv3 --pmc
     # serialises kernels and needs its own passes): it is READ from the tracked summary of the last counter run on
     # the same shape and labelled as such (`traffic_source`); null when no summary matches.
@@ -861,12 +945,16 @@ def main():
             traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run): " + str(tj.get("command", ""))
     if sieve:
         kernel_name = ("sieve_q16_kernel: two filter launches over the bf16 hi blocks (first 1/16 of the tiles, then the rest) with "
-                       "sieve_verify_kernel + sieve_select_kernel between them (the exact k-th best so far = the second launch's threshold)")
+                       "sieve_scatter_kernel + sieve_select_kernel between them (the k-th largest filter value so far, less the margin = "
+                       "the second launch's threshold)")
     elif wide:
         kernel_name = "scan_topk_q16_kernel (2 launches per shard + list_threshold_kernel)"
     else:
         kernel_name = "scan_topk_kernel"
     mfma_tflops = 2.0 * n_loc * d_pad * q_launch / (avg_ms * 1e-3) / 1e12 if sieve else None
+    hbm_frac = hbm_gbs / HBM_PEAK_GBS
+    mfma_frac = None if mfma_tflops is None else mfma_tflops / MFMA_PEAK_TFLOPS_BF16
+    by_mfma = mfma_frac is not None and mfma_frac > hbm_frac
 
     result = {
         "metric": "retrieval_qps_10Mx384",
@@ -889,31 +977,34 @@ def main():
             "parallelism": f"row-shard x{world}, all-gather of partial top-k",
         },
         "roofline": {
-            "bound": "hbm",
+            "bound": "mfma" if by_mfma else "hbm",
             # HIP events on the launch stream bracket the shard pass: both filter launches and what runs between them.  The
-            # 32K-row sample launch before them and the verify / select kernels after the second launch are outside the
-            # bracket and inside `step_frac`.
+            # 32K-row sample launch before them and the scatter / select kernels after the second launch are outside the
+            # bracket and inside `step_hbm_frac`.
             "kernel": kernel_name,
             "queries_per_launch": qpl,
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "achieved": round(mfma_tflops if by_mfma else hbm_gbs, 1),
+            "peak": MFMA_PEAK_TFLOPS_BF16 if by_mfma else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if by_mfma else "GB/s",
+            "frac": round(mfma_frac if by_mfma else hbm_frac, 4),
+            "hbm_gbs": round(hbm_gbs, 1),
+            "hbm_frac": round(hbm_frac, 4),
+            "mfma_tflops_hi_hi": None if mfma_tflops is None else round(mfma_tflops, 1),
+            "mfma_frac": None if mfma_frac is None else round(mfma_frac, 4),
             "bytes_per_launch": bytes_launch,
-            "bytes_per_launch_is": "SURVEY.md 8(d) algorithmic bytes of one shard pass",
+            "bytes_per_launch_is": ("what the sieve's algorithm moves per shard pass: rows * d_pad * 2 (bf16 hi blocks) + norm column + "
+                                    "queries + results" if sieve else "SURVEY.md 8(d) algorithmic bytes of one shard pass"),
+            "flops_per_launch": None if mfma_tflops is None else 2.0 * n_loc * d_pad * q_launch,
+            "survey_bytes": survey_bytes,
+            "survey_bytes_is": "SURVEY.md 8(d): rows * d * 4 + norm column + queries + results (a float32 stream of the shard)",
+            "speedup_vs_f32_stream_at_peak": round(survey_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": traffic,
             "traffic_source": traffic_source,
-            "streamed_bytes_per_launch": streamed,
-            "streamed_bytes_is": ("what the sieve moves: rows * d_pad * 2 (bf16 hi blocks) + norm column + queries + results" if sieve
-                                  else "the algorithmic bytes"),
-            "frac_streamed_bytes": round(streamed / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "mfma_tflops_hi_hi": None if mfma_tflops is None else round(mfma_tflops, 1),
-            "mfma_frac_of_2500_tflops_bf16": None if mfma_tflops is None else round(mfma_tflops / 2500.0, 4),
             "avg_launch_ms": round(avg_ms, 4),
             "launches": launches,
             "measured_over": bracket_over,
-            # the same bytes over the whole step (prep, threshold pre-pass, filter, verify, select, exact-pass gate, merge)
-            "step_frac": round(passes * bytes_launch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            # the same bytes over the whole step (prep, threshold pre-pass, filter, scatter, select, exact-pass gate, merge)
+            "step_hbm_frac": round(passes * bytes_launch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         },
         "sieve": sieve_stats if sieve else None,  # candidates per query and filter launch, queries handed to the exact pass (rank 0's shard)
         "exact_pass_queries": int(flags_total.item()) // 2,  # queries the filter could not prove (flag bit 2), recomputed exactly
@@ -946,8 +1037,9 @@ def main():
             el = float(tm.item())
             a_ms = ms / max(ln, 1)
             sweep.append({"queries_per_step": Bs, "qps": round(Bs * 10 / el, 1), "ms_per_step": round(1e3 * el / 10, 4),
-                          "scan_launch_ms": round(a_ms, 4), "roofline_frac": round(bytes_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                          "frac_streamed_bytes": round(streamed / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+                          "scan_launch_ms": round(a_ms, 4), "hbm_frac": round(bytes_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "mfma_frac": (None if not sieve else
+                                        round(2.0 * n_loc * d_pad * min(Bs, qpl) / (a_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS_BF16, 4))})
         result["batch_sweep"] = sweep
         # the other metrics of embeddings_metrics.py at the headline batch (north_star names cosine; the index is the same image)
         others = []
@@ -969,6 +1061,9 @@ def main():
             others.append({"metric": mt, "queries_per_step": B, "qps": round(B * 10 / el, 1), "ms_per_step": round(1e3 * el / 10, 4)})
         result["metric_sweep"] = others
     index.close()  # release the shard before the other legs allocate theirs
+    if world == 1 and rank == 0 and args.cpu_legs:
+        # (after the timed region and the sweeps: the oracle is the checker, never the thing measured)
+        result["timed_leg_check"] = timed_leg_check(np, torch, device, n, d, args, last_q, last_rows, last_cnt)
     if args.variants and world == 1:
         for kind in ("clustered", "near_duplicate"):
             result[kind] = variant_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher, kind)
@@ -1001,6 +1096,22 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def timed_leg_check(np, torch, device, n, d, args, qs, got_rows, got_cnt):
+    """The first MAIN_LEG_CHECK_QUERIES queries of the LAST TIMED STEP (the headline shape: one 256-query launch over all
+    --rows rows) against the CPU oracle over all rows, regenerated from the same seed."""
+    from oracle import embeddings_index as oracle_index
+
+    host = gen_rows(torch, device, 0, n, d).cpu().numpy()
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    same = True
+    for i in range(len(qs)):
+        want, _ = oracle_index.find_flat(qs[i], host, args.metric, args.k)
+        same &= bool(np.array_equal(got_rows[i, : got_cnt[i]], want))
+    return {"queries_of_the_last_timed_step_checked": len(qs), "rows": n, "ids_identical_to_cpu_oracle": same,
+            "oracle_s": round(time.perf_counter() - t0, 1)}
 
 
 def cpu_baseline(np, sample, qs, args, DeviceIndex):

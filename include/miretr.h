@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define MIR_ABI_VERSION 3 /* 2: results always exact (exact pass), any k; mir_bm25_tune / _corpus_stats / _idf_from_stats /
+#define MIR_ABI_VERSION 4 /* 4: mir_keywords_preprocess / mir_kwp_result_*;
+                            3: 2: results always exact (exact pass), any k; mir_bm25_tune / _corpus_stats / _idf_from_stats /
                              _set_global_stats, mir_rrf_fuse_batch, mir_wordpiece_* added
                              3: mir_index_scan_stats added; mir_bm25_search[_device] take any k (no MIR_ERR_UNSUPPORTED past 64);
                                 mir_bm25_workspace_bytes grew (candidate pool of the wave-grain fast pass) */
@@ -221,6 +222,24 @@ int32_t mir_bm25_create(const int64_t *indptr_host, const int32_t *term_ids_host
  * EnglishStemmer including its quirks (csrc/stem_english.cpp).  tokens: n_bytes of UTF-8 separated by `sep`
  * (no trailing separator); out: >= n_bytes bytes, receives the stems in the same form. */
 int32_t mir_stem_english(const char *tokens, int64_t n_bytes, char sep, char *out, int64_t *out_bytes);
+
+/* Host utility (ABI 4): keywords_preprocess (aidial_rag/keywords_search.py:13-18) for a BATCH of chunk texts on all
+ * host cores - word_tokenize -> drop stopwords (compared before lower-casing) -> Snowball stem of the lower-cased
+ * token - what BM25Retriever.build_index runs per chunk on a CPU pool next to the encoder
+ * (retrievers/bm25_retriever.py:30-39,106-114; documents.py:188-198).  csrc/keywords_preprocess.cpp: NLTK's
+ * Treebank word tokenizer restated rule by rule (pinned), the mirror's rule-based sentence splitter and stopword
+ * list (both unpinned approximations of nltk_data), str.lower() from generated Unicode tables.
+ * texts: n_texts UTF-8 texts back to back, text i = [offsets[i], offsets[i + 1]); n_threads <= 0 = all cores;
+ * mode 0 = keywords_preprocess, 1 = word_tokenize only, 2 = the Treebank rules alone (the text is one sentence).
+ * A text holding a NUL byte -> MIR_ERR_INVALID.
+ * The result owns its buffers: `bytes` = every token followed by a NUL, text after text; counts[n_texts] tokens
+ * per text; byte_ends[n_texts]: text i's tokens are bytes [byte_ends[i - 1], byte_ends[i]). */
+typedef struct mir_kwp_result mir_kwp_result;
+int32_t mir_keywords_preprocess(const char *texts, const int64_t *offsets, int32_t n_texts, int32_t n_threads,
+                                int32_t mode, mir_kwp_result **out);
+int32_t mir_kwp_result_data(const mir_kwp_result *r, const char **bytes, int64_t *n_bytes, const int32_t **counts,
+                            const int64_t **byte_ends, int64_t *n_tokens);
+int32_t mir_kwp_result_free(mir_kwp_result *r);
 
 /* Host utility: term ids written in a vocabulary larger than this corpus (e.g. a process-wide str -> id map
  * shared by every document the process has tokenised) -> ids 0..n_used-1 in order of first appearance, which is
