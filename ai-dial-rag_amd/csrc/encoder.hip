@@ -22,10 +22,12 @@ namespace {
 #define ENC_PASS_TILES 12288
 #endif
 constexpr int kMaxTilesPerPass = ENC_PASS_TILES;
-// the throughput path's attention kernel: 3 = attention3_kernel (persistent waves, LDS-DMA ring), 2 = attention2_kernel (one wave
-// per two query tiles), 1 = attention_kernel (one wave per query tile; the latency path's kernel)
+// the throughput path's attention kernel: 1 = attention_kernel (one wave per query tile, four waves per SIMD; also the latency
+// path's kernel), 2 = attention2_kernel (one wave per TWO query tiles: half the K / V fetches, two waves per SIMD) - within 4 % of
+// each other (what bounds them differs); a third, persistent form with an LDS-DMA ring was slower and is
+// in the history only (commit "Encoder attention: fix a latent MFMA operand hazard ...")
 #ifndef ENC_ATT
-#define ENC_ATT 3
+#define ENC_ATT 1
 #endif
 
 // Pack a Hugging Face Linear weight W[out][in] (y = x W^T + b) into MFMA A-fragment
@@ -55,7 +57,6 @@ struct Layer {
 
 struct mir_encoder {
     int device = 0;
-    int n_cus = 256;
     int layers = 0;
     int vocab = 0, max_pos = 0;
     float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
@@ -120,23 +121,6 @@ void build_batch(const int32_t *token_ids, const int64_t *offs, const int32_t *l
         b.ids.resize(base + (size_t)nt * 32, 0);
         std::memcpy(b.ids.data() + base, token_ids + offs[s], sizeof(int32_t) * len);
     }
-#if ENC_ATT == 3
-    // attention3_kernel deals the units to its persistent waves with a stride: sorted by key tiles (descending, stable - a
-    // sequence's units stay together, for the L2), every wave gets a cross-section of lengths instead of a random draw
-    {
-        const size_t nu = b.units.size() / 4;
-        std::vector<int32_t> sorted(b.units.size());
-        size_t start[18] = {0};
-        for (size_t u = 0; u < nu; ++u) ++start[17 - std::min(b.units[4 * u + 1], 16)];  // bucket 17 - n_kt -> descending
-        size_t acc = 0;
-        for (int k = 0; k < 18; ++k) { const size_t c = start[k]; start[k] = acc; acc += c; }
-        for (size_t u = 0; u < nu; ++u) {
-            const size_t d = start[17 - std::min(b.units[4 * u + 1], 16)]++;
-            std::memcpy(&sorted[4 * d], &b.units[4 * u], 16);
-        }
-        b.units.swap(sorted);
-    }
-#endif
 }
 
 }  // namespace
@@ -157,12 +141,10 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
     MIR_REQUIRE(layers >= 1 && layers <= 64 && vocab >= 1 && max_pos >= 1, "bad encoder shape");
     MIR_REQUIRE(word_emb && pos_emb && type_emb && emb_ln_gamma && emb_ln_beta && layer_tensors, "NULL weight pointer");
     for (int i = 0; i < layers * 16; ++i) MIR_REQUIRE(layer_tensors[i] != nullptr, "layer tensor %d is NULL", i);
-    int cus = 0;
-    int32_t rc = use_device(device, &cus);
+    int32_t rc = use_device(device, nullptr);
     if (rc != MIR_OK) return rc;
     mir_encoder *e = new (std::nothrow) mir_encoder();
     MIR_REQUIRE(e != nullptr, "out of host memory");
-    e->n_cus = cus > 0 ? cus : 256;
     e->device = device; e->layers = layers; e->vocab = vocab; e->max_pos = max_pos;
     auto fail = [&](int32_t code) { free_encoder(e); return code; };
 #define MIR_TRY(call)                                                                              \
@@ -237,7 +219,6 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[0], hipEventDisableTiming));
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[1], hipEventDisableTiming));
     if (ffn_prepare() != MIR_OK) return fail(MIR_ERR_HIP);
-    if (attention3_prepare() != MIR_OK) return fail(MIR_ERR_HIP);
     {
         auto kern = qkv_kernel;
         MIR_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS_BYTES));
@@ -392,9 +373,7 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
             const Layer &l = e->L[li];
             qkv_kernel<<<dim3((nt + QKV_WAVES * QKV_G - 1) / (QKV_WAVES * QKV_G)), dim3(64 * QKV_WAVES), QKV_LDS_BYTES, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
             {
-#if ENC_ATT == 3
-                const int32_t arc = launch_attention3(qf, kf, vf, reinterpret_cast<const int32_t *>(w + o_un), (int)b.units.size() / 4, a1, e->n_cus, s);  // a1 = context
-#elif ENC_ATT == 2
+#if ENC_ATT == 2
                 const int32_t arc = launch_attention2(qf, kf, vf, reinterpret_cast<const int32_t *>(w + o_un), (int)b.units.size() / 4, a1, s);
 #else
                 const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);

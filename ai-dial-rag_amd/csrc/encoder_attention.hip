@@ -28,6 +28,12 @@ __device__ __forceinline__ f32x4 mfma_sum(uint4 sel, uint4 p, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sel), __builtin_bit_cast(f16x8, p), c, 0, 0, 0);
 }
 constexpr float kAttnSlack = 6.0f;
+// ATTN_ABL: TIMING-ONLY ablations (results wrong by design; tools/run_enc_variants.sh): bit 0 no exponentials, bit 1 no reference
+// check (no max tree, no vote), bit 2 no P x V / row-sum MFMAs, bit 3 no score MFMAs, bit 4 every key tile is the sequence's first
+// (K / V from the caches), bit 5 no context store
+#ifndef ATTN_ABL
+#define ATTN_ABL 0
+#endif
 // The pieces of one (query tile, key tile) step; attn_step_t strings them together for one query tile, attn_step2_t for the
 // two query tiles of a wave (same operations on the same values in the same order per query tile: both round alike).
 // FIRST / LAST are compile-time: the kernels peel a sequence's first and last key tile out of their loops, so the steady state
@@ -52,8 +58,14 @@ __device__ __forceinline__ f32x16 attn_scores(const AttnState &st, const uint4 &
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = (key0 + fi(r, h) < seq_len) ? c[r] : -__builtin_inff();
     }
+#if ATTN_ABL & 8
+    f32x16 s = c;
+    s[0] += __uint_as_float(kc0.x & q0.x & 0xffu) + __uint_as_float(kc1.x & q1.x & 0xffu);
+    return s;
+#else
     f32x16 s = mfma(kc0, q0, c);
     return mfma(kc1, q1, s);
+#endif
 #endif
 }
 __device__ __forceinline__ float attn_lane_max(const f32x16 &s) {  // this lane's half of the keys
@@ -80,16 +92,23 @@ __device__ __forceinline__ void attn_pv(AttnState &st, f32x16 &s, const uint4 &v
     const uint4 sel = attn_sum_selector((int)(threadIdx.x & 63));
     // v_exp_f32 directly: exp2f() wraps it in a compare / select / ldexp to keep results below 2^-126 exact, ~4 extra
     // instructions per value; a softmax term that small is zero next to the row's largest term either way
+#if !(ATTN_ABL & 1)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+#endif
     // P to float16 with the packed convert (two values per instruction; the scalar casts cost three)
     // (pack2_cv, not the inline-asm pack2_rn: these registers are MFMA operands - see pack2_cv)
     const uint4 p0 = make_uint4(pack2_cv(s[0], s[1]), pack2_cv(s[2], s[3]), pack2_cv(s[4], s[5]), pack2_cv(s[6], s[7]));
     const uint4 p1 = make_uint4(pack2_cv(s[8], s[9]), pack2_cv(s[10], s[11]), pack2_cv(s[12], s[13]), pack2_cv(s[14], s[15]));
+#if ATTN_ABL & 4
+    st.o[0] += __uint_as_float((p0.x ^ p1.y ^ vc0.x ^ vc1.x ^ p0.z ^ p1.w ^ p0.y ^ p1.x ^ p0.w ^ p1.z ^ sel.x) & 0xffu);
+    st.lsum[0] += 1.0f;
+#else
     st.o = mfma(vc0, p0, st.o);
     st.lsum = mfma_sum(sel, p0, st.lsum);
     st.o = mfma(vc1, p1, st.o);
     st.lsum = mfma_sum(sel, p1, st.lsum);
+#endif
 }
 template <bool FIRST, bool LAST>
 __device__ __forceinline__ void attn_step_t(AttnState &st, const uint4 &q0, const uint4 &q1, const uint4 &kc0, const uint4 &kc1,
@@ -153,7 +172,7 @@ __device__ __forceinline__ void attn_step2_rt(AttnState &sa, AttnState &sb, cons
     attn_pv(sa, s0, vc0, vc1);
     attn_pv(sb, s1, vc0, vc1);
 }
-// One-body step with run-time flags for ONE query tile (attn_step's four instantiations cost attention3_kernel code size)
+// One-body step with run-time flags for ONE query tile (attn_step's four instantiations cost attention_kernel a wave per SIMD: 147 VGPRs)
 __device__ __forceinline__ void attn_step1_rt(AttnState &st, const uint4 (&q)[2], const uint4 &kc0, const uint4 &kc1, const uint4 &vc0,
                                               const uint4 &vc1, bool first, bool last, int key0, int seq_len, int h) {
     f32x16 s = attn_scores<false>(st, q[0], q[1], kc0, kc1, key0, seq_len, h);
@@ -161,11 +180,15 @@ __device__ __forceinline__ void attn_step1_rt(AttnState &st, const uint4 (&q)[2]
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = (key0 + fi(r, h) < seq_len) ? s[r] : -__builtin_inff();
     }
+#if ATTN_ABL & 2
+    if (first) attn_rescale(st, s, half_max(s[0]));
+#else
     const float mx = attn_lane_max(s);
     if (first || __any(mx > kAttnSlack)) {
         const float mq = half_max(mx);
         attn_rescale(st, s, first ? mq : fmaxf(mq, 0.f));
     }
+#endif
     attn_pv(st, s, vc0, vc1);
 }
 
@@ -174,8 +197,13 @@ __device__ __forceinline__ void attn_store(AttnState &st, uint4 *__restrict__ ou
     const float inv = 1.0f / st.lsum[0];
 #pragma unroll
     for (int r = 0; r < 16; ++r) st.o[r] *= inv;
+#if ATTN_ABL & 32
+    if (st.o[0] == 1234.5f && st.o[9] == 77.25f)
+#endif
+    {
     enc_store_nt(out, acc_to_frag(st.o, 0));  // the context is read once, by the output projection (measured: within noise
     enc_store_nt(out + 64, acc_to_frag(st.o, 1));  // for this kernel, 361 vs 364 us; the projection after it 197 vs 202 us)
+    }
 }
 
 // One wave per (head, query tile): light on registers, so several waves share a SIMD and
@@ -226,7 +254,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint4 *__restrict_
     // past the end they re-read the last tile: behind a branch that may or may not have issued loads, hipcc waits for
     // vmcnt(0).)
     auto load = [&](int kt, uint4 &k0, uint4 &k1, uint4 &v0, uint4 &v1) {
-        const size_t kb = kv0 + (size_t)kt * (NH * 2 * 64);
+        const size_t kb = kv0 + (size_t)((ATTN_ABL & 16) ? 0 : kt) * (NH * 2 * 64);
         k0 = kf[kb]; k1 = kf[kb + 64]; v0 = vf[kb]; v1 = vf[kb + 64];
     };
     uint4 ka0, ka1, va0, va1, kb0, kb1, vb0, vb1;
@@ -337,124 +365,6 @@ __global__ __launch_bounds__(256) void attention2_kernel(const uint4 *__restrict
 }
 
 
-// PERSISTENT form (round 4, ENC_ATT = 3): one 8-wave workgroup per CU; every wave walks its own list of (head, unit) items
-// and never meets another wave (no barrier).  What the counters said about the one-wave-per-item kernels above: a wave lives
-// for a handful of key tiles, and in front of its first MFMA stand two or three DEPENDENT memory hops (descriptor -> Q / K
-// addresses -> data); with one key tile requested ahead in registers its s_waitcnt share was a third of its cycles, and two
-// waves per SIMD cannot hide that.  Here a wave's memory requests run AHEAD of its arithmetic through a private LDS ring:
-//   * the items' Q tiles and K / V tiles form one flat sequence of 4-KiB ENTRIES: Q(item), KV(item, 0), KV(item, 1), ...,
-//     Q(next item), KV(next item, 0), ...; each entry is four 1-KiB LDS-DMA pieces (global_load_lds_dwordx4: no registers);
-//   * a prefetch cursor issues entry e + ATT3_AHEAD while entry e is computed on - across item boundaries, so the next
-//     item's descriptor, Q and first keys arrive during this item's last steps;
-//   * vmcnt counts in issue order and every entry is exactly four pieces, so "entry e has landed" is s_waitcnt
-//     vmcnt(4 * ATT3_AHEAD) (the context stores of an item's end sit in the same queue: the wait is then a little early, never late).
-// Items are sorted by key tiles (descending, stable: a sequence's units stay together) on the host and dealt to the waves of
-// an XCD with a stride, so every wave gets a cross-section of lengths; XCD x takes the x-th eighth of the (head-major) list,
-// as the kernels above, so a (sequence, head)'s K / V meet in one L2.
-#ifndef ATT3_AHEAD
-#define ATT3_AHEAD 2
-#endif
-constexpr int ATT3_SLOTS = ATT3_AHEAD + 1;
-constexpr int ATT3_WAVES = 8;
-constexpr int ATT3_WAVE_LDS = ATT3_SLOTS * 4096;
-constexpr int ATT3_LDS_BYTES = ATT3_WAVES * ATT3_WAVE_LDS;
-
-__global__ __launch_bounds__(64 * ATT3_WAVES, 1) void attention3_kernel(const uint4 *__restrict__ qf, const uint4 *__restrict__ kf,
-                                                                        const uint4 *__restrict__ vf, const int4 *__restrict__ units,
-                                                                        int n_units, uint4 *__restrict__ ctx) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef int __attribute__((ext_vector_type(4))) i32x4;
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t lane16 = (uint32_t)lane * 16u;
-    const uint32_t ring = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)(wave * ATT3_WAVE_LDS));
-    // this wave's items: XCD x = blockIdx.x & 7 owns items [x * per, (x + 1) * per) of the head-major list, its waves take
-    // them with stride (waves of the XCD)
-    const int total = n_units * NH, per = (total + 7) >> 3;
-    const int xcd = blockIdx.x & 7, n_xw = (((int)gridDim.x - xcd + 7) >> 3) * ATT3_WAVES;
-    const int lw = ((int)blockIdx.x >> 3) * ATT3_WAVES + wave;
-    const int lo = xcd * per, hi = min(total, lo + per);
-
-    struct Item { int tt, two, n_kt, seq_len, first, head; };  // all wave-uniform
-    auto fetch = [&](int j, Item &it) {  // (a scalar load: the descriptor table is read-only for the launch)
-        const int head = j / n_units, u = j - head * n_units;
-        const i32x4 d = *reinterpret_cast<const __attribute__((address_space(4))) i32x4 *>(reinterpret_cast<uintptr_t>(units + u));
-        it.tt = d.x & 0xffffff; it.two = d.x >> 24; it.n_kt = d.y; it.seq_len = d.z; it.first = d.w; it.head = head;
-    };
-    // entry `ph` of an item: -1 = its Q tile(s), kt >= 0 = key tile kt; four pieces into ring slot `slot`
-    auto issue = [&](const Item &it, int ph, int slot) {
-        const uint32_t dst = ring + (uint32_t)slot * 4096u;
-        if (ph < 0) {
-            const uint4 *q0 = qf + ((size_t)(it.tt * NH + it.head) * 2) * 64;
-            const uint4 *q1 = it.two ? q0 + NH * 2 * 64 : q0;  // a one-tile unit fetches its tile twice: every entry is four pieces
-            enc_glds16_s_nt(q0, lane16, dst);
-            enc_glds16_s_nt(q0 + 64, lane16, dst + 1024);
-            enc_glds16_s_nt(q1, lane16, dst + 2048);
-            enc_glds16_s_nt(q1 + 64, lane16, dst + 3072);
-        } else {
-            const size_t o = ((size_t)((it.first + ph) * NH + it.head) * 2) * 64;
-            enc_glds16_s(kf + o, lane16, dst);
-            enc_glds16_s(kf + o + 64, lane16, dst + 1024);
-            enc_glds16_s(vf + o, lane16, dst + 2048);
-            enc_glds16_s(vf + o + 64, lane16, dst + 3072);
-        }
-    };
-    int j = lo + lw;
-    if (j >= hi) return;
-    // prefetch cursor: item pf (index pj), entry pph; `e_issued` entries issued so far, `e_done` consumed
-    Item cur, pf;
-    fetch(j, cur);
-    pf = cur;
-    int pj = j, pph = -1, e_issued = 0, e_done = 0;
-    bool pf_live = true;
-    auto advance = [&]() {  // issue the cursor's entry and move the cursor
-        if (!pf_live) return;
-        issue(pf, pph, e_issued % ATT3_SLOTS);
-        ++e_issued;
-        if (++pph == pf.n_kt) {
-            pj += n_xw;
-            pph = -1;
-            if (pj < hi) fetch(pj, pf);
-            else pf_live = false;
-        }
-    };
-    auto landed = [&]() {  // entry e_done is in LDS (every entry older than the ATT3_AHEAD youngest ones)
-        if (e_issued - e_done > ATT3_AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * ATT3_AHEAD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail: fewer entries behind it than the ring holds
-    };
-#pragma unroll
-    for (int i = 0; i < ATT3_AHEAD; ++i) advance();
-    for (;;) {
-        // ---- the item's Q entry ----
-        advance();
-        landed();
-        const uint4 *qs = reinterpret_cast<const uint4 *>(smem + (size_t)wave * ATT3_WAVE_LDS + (size_t)(e_done % ATT3_SLOTS) * 4096) + lane;
-        uint4 qa[2], qb[2];
-        qa[0] = qs[0]; qa[1] = qs[64]; qb[0] = qs[128]; qb[1] = qs[192];
-        ++e_done;
-        AttnState sa, sb;
-        const int n_kt = cur.n_kt, seq_len = cur.seq_len;
-        const bool two = cur.two != 0;
-        for (int kt = 0; kt < n_kt; ++kt) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous entry's fragments are in registers: its slot may be refilled
-            advance();
-            landed();
-            const uint4 *kv = reinterpret_cast<const uint4 *>(smem + (size_t)wave * ATT3_WAVE_LDS + (size_t)(e_done % ATT3_SLOTS) * 4096) + lane;
-            const uint4 k0 = kv[0], k1 = kv[64], v0 = kv[128], v1 = kv[192];
-            ++e_done;
-            if (two) attn_step2_rt(sa, sb, qa, qb, k0, k1, v0, v1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
-            else attn_step1_rt(sa, qa, k0, k1, v0, v1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
-        }
-        uint4 *out = ctx + (size_t)cur.tt * (NFB * 2 * 64) + (size_t)(cur.head * 2) * 64 + lane;
-        attn_store(sa, out);
-        if (two) attn_store(sb, out + NFB * 2 * 64);
-        j += n_xw;
-        if (j >= hi) break;
-        fetch(j, cur);  // (the cursor fetched the same descriptor earlier: a scalar-cache hit)
-    }
-}
-
-
 // Latency path, batches whose sequences all fit one token tile (queries): QKV projection and attention of one (head,
 // tile) in ONE dispatch.  Three waves compute the head's Q, K and V fragments exactly as qkv_small_kernel does (same
 // chains, same bias / scale arithmetic), hand them over through LDS, and the first wave runs the one attention step:
@@ -560,19 +470,6 @@ int32_t launch_attention2(const uint4 *qf, const uint4 *kf, const uint4 *vf, con
                           hipStream_t stream) {
     const int n_wg = (n_units * NH + 3) / 4;
     attention2_kernel<<<dim3((n_wg + 7) / 8 * 8), dim3(256), 0, stream>>>(qf, kf, vf, reinterpret_cast<const int4 *>(units), n_units, ctx);
-    MIR_HIP(hipGetLastError());
-    return MIR_OK;
-}
-
-int32_t attention3_prepare() {
-    auto kern = attention3_kernel;
-    MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ATT3_LDS_BYTES));
-    return MIR_OK;
-}
-// units: n_units x int4 sorted by key tiles, descending (see attention3_kernel); n_cus workgroups
-int32_t launch_attention3(const uint4 *qf, const uint4 *kf, const uint4 *vf, const int32_t *units, int n_units, uint4 *ctx, int n_cus,
-                          hipStream_t stream) {
-    attention3_kernel<<<dim3(n_cus), dim3(64 * ATT3_WAVES), ATT3_LDS_BYTES, stream>>>(qf, kf, vf, reinterpret_cast<const int4 *>(units), n_units, ctx);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }

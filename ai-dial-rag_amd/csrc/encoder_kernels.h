@@ -194,9 +194,6 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void qkv_kernel(const uint4 *__r
 // the separate file.
 int32_t launch_attention2(const uint4 *qf, const uint4 *kf, const uint4 *vf, const int32_t *units, int n_units, uint4 *ctx,
                           hipStream_t stream);  // units: n_units x int4, see attention2_kernel
-int32_t attention3_prepare();  // once per process: dynamic-LDS attribute
-int32_t launch_attention3(const uint4 *qf, const uint4 *kf, const uint4 *vf, const int32_t *units, int n_units, uint4 *ctx, int n_cus,
-                          hipStream_t stream);  // units sorted by key tiles, descending
 int32_t launch_attention(const uint4 *qf, const uint4 *kf, const uint4 *vf, const TileInfo *ti, int n_tiles,
                          uint4 *ctx, hipStream_t stream);
 // latency path, every sequence of the batch a single tile: QKV projection + attention in one dispatch (encoder_attention.hip)

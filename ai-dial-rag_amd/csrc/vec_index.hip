@@ -95,6 +95,7 @@ struct mir_index {
     _Float16 *d_f16 = nullptr;   // float16-native index: the rows as given (re-scoring)
     bool native16 = false;       // float16 storage scanned as 2-byte fragments (vec_kernels_f16.h)
     bool layout16 = false;       // float32, d padded to 128 / 256 / 384: the 16x16x32 image of vec_kernels_q16.h
+    bool hi_only = false;        // layout16 shard that only the sieve ever scans (>= 32K rows): the image holds the bf16 hi blocks alone
     uint4 *d_split = nullptr;    // bf16 hi/lo fragments, or the float16 fragments of a native16 index
     float *d_docsq = nullptr;    // padded to n_tiles*32
     float *d_invnorm = nullptr;  // padded to n_tiles*32
@@ -157,6 +158,10 @@ static void free_index(mir_index *ix) {
     delete ix;
 }
 
+// Threshold pre-pass of the wide scans: kSampleWgs workgroups x up to kSampleTilesPerWg tiles (32K rows)
+constexpr int kSampleWgs = 256;
+constexpr int kSampleTilesPerWg = 4;  // (8 / 16 / 32 tiles per workgroup measured within 0.5 % on 10M x 384, 1-4 % slower on 6.25M x 1024 float16)
+
 // Build the derived device state from ix->d_orig (already filled) on `stream`.
 // doc_sq / inv_norm / max norm: rows staged through LDS when at least 32 of them fit (d <= 511), else one thread
 // per row (measured at d = 1024: 15 rows per workgroup, 37 ms per 6.25M rows against ~18 ms direct)
@@ -179,7 +184,12 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
     ix->ksteps = ix->native16 ? (d + 511) / 512 * 32 : pad_ksteps(d);  // native16: whole 32-k-step stages
     ix->layout16 = !ix->native16 && (ix->ksteps == 8 || ix->ksteps == 16 || ix->ksteps == 24);  // d padded to 128 / 256 / 384
     ix->n_tiles = (uint32_t)((n + kTileRows - 1) / kTileRows);
-    const size_t split_bytes = (size_t)ix->n_tiles * ix->ksteps * (ix->native16 ? 1024 : 2048);
+    // A layout16 shard of >= 32K rows is scanned by the sieve alone (plan(): k <= 64 -> sieve, beyond -> the exact pass), and the
+    // sieve reads only the hi blocks: no lo blocks are stored for it - 7.68 GB at 10M x 384 - and a tile's
+    // hi blocks follow the previous tile's directly, so the filter's stream is contiguous.  (MIR_NO_SIEVE - the A/B switch back to
+    // round 2's scan, which does read lo blocks - is read at build time too.)
+    ix->hi_only = ix->layout16 && ix->n_tiles >= 4u * kSampleWgs && getenv("MIR_NO_SIEVE") == nullptr;
+    const size_t split_bytes = (size_t)ix->n_tiles * ix->ksteps * ((ix->native16 || ix->hi_only) ? 1024 : 2048);
     const size_t aux_bytes = (size_t)ix->n_tiles * kTileRows * sizeof(float);
     MIR_HIP(hipMalloc(&ix->d_split, std::max<size_t>(split_bytes, 16)));
     MIR_HIP(hipMalloc(&ix->d_docsq, std::max<size_t>(aux_bytes, 16)));
@@ -204,7 +214,7 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
         } else if (ix->layout16) {
             const int64_t lanes16 = total_lanes;  // tiles x (ks32 * 2) blocks x 64 lanes; one thread writes a hi and a lo block
             pack_split16_f32_kernel<<<dim3((unsigned)((lanes16 + 255) / 256)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ksteps / 2,
-                                                                                                   lanes16, ix->d_split);
+                                                                                                   lanes16, ix->d_split, ix->hi_only);
             MIR_HIP(hipGetLastError());
             launch_row_norms(ix->d_orig, n, d, ix, stream);
         } else {
@@ -233,9 +243,6 @@ static int32_t check_create_args(int64_t n, int32_t d, int32_t dtype, mir_index 
     return MIR_OK;
 }
 
-// Threshold pre-pass of the wide scans: kSampleWgs workgroups x up to kSampleTilesPerWg tiles (32K rows)
-constexpr int kSampleWgs = 256;
-constexpr int kSampleTilesPerWg = 4;  // (8 / 16 / 32 tiles per workgroup measured within 0.5 % on 10M x 384, 1-4 % slower on 6.25M x 1024 float16)
 
 // carve helper
 struct Carver {
@@ -304,7 +311,7 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.q_err = c.take<double>(b);
     sb.q_norm = c.take<double>(b);
     sb.qscale = c.take<float>((size_t)ngroups * std::max(128, qpw));
-    sb.part = c.take<uint64_t>((size_t)ngroups * nwg * qpw * klist);
+    sb.part = c.take<uint64_t>(pl.sieve ? 0 : (size_t)ngroups * nwg * qpw * klist);  // per-workgroup lists of the list scans (the sieve has its own regions: 33.5 MB per launch group saved)
     // one zeroed control block: gthr | nflag | arrive[b] | sieve over[b] | sieve count[b][32]  (u32 arrays padded to u64)
     const size_t gthr_words = (size_t)ngroups * std::max(128, qpw), arrive_words = ((size_t)b + 1) / 2;
     const size_t count_words = pl.sieve ? (size_t)b * kSieveCountStride / 2 : 0;
@@ -486,7 +493,8 @@ static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g,
                               : (sample ? sieve_q16_kernel<KS, KIND, true, 1> : sieve_q16_kernel<KS, KIND, false, 1>); \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, q_norm_g, q_sq_g, q_err_g, ix->d_maxnorm, n_rows, tile0, n_tiles, \
-                                                    nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat);    \
+                                                    nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat,     \
+                                                    (uint32_t)(ks32 * 2 * 64 * (ix->hi_only ? 1 : 2)));               \
         break;                                                                                                         \
     }
     switch (ks32) {

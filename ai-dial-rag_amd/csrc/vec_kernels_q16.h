@@ -64,8 +64,9 @@ __device__ __forceinline__ float hihi_margin(bool cosine, bool l2, float qn, flo
 
 // f32 [n][d] row-major -> layout16.  One thread per (tile, block of a half, lane); ks32*32 >= d; columns past d and
 // rows past n are 0.
+// hi_only: a tile is its nb hi blocks alone (shards only the sieve scans), else nb hi blocks followed by nb lo blocks.
 __global__ __launch_bounds__(256) void pack_split16_f32_kernel(const float *__restrict__ src, int64_t n, int d, int ks32,
-                                                               int64_t total_lanes, uint4 *__restrict__ dst) {
+                                                               int64_t total_lanes, uint4 *__restrict__ dst, bool hi_only = false) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total_lanes) return;
     const int lane = (int)(gid & 63);
@@ -89,6 +90,10 @@ __global__ __launch_bounds__(256) void pack_split16_f32_kernel(const float *__re
     uint32_t hi[8], lo[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) split_bf16(x[j], hi[j], lo[j]);
+    if (hi_only) {
+        dst[(tile * nb + b) * 64 + lane] = pack8(hi);
+        return;
+    }
     dst[(tile * (2 * nb) + b) * 64 + lane] = pack8(hi);
     dst[(tile * (2 * nb) + nb + b) * 64 + lane] = pack8(lo);
 }

@@ -73,12 +73,13 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
                                                            uint32_t n_rows, uint32_t tile0, uint32_t n_tiles, int nq, int nan_guard,
                                                            const uint64_t *__restrict__ gthr, uint64_t *__restrict__ cand,
                                                            float *__restrict__ candv, uint32_t *__restrict__ ccount,
-                                                           float *__restrict__ part_sample, unsigned long long *__restrict__ stat) {
+                                                           float *__restrict__ part_sample, unsigned long long *__restrict__ stat,
+                                                           uint32_t tile_u4) {  // uint4s from one tile's hi blocks to the next tile's
     static_assert(QT == 1 || QT == 2, "query tiles per wave");
     constexpr int NS = kSieveStages;
     constexpr int SB = KS32 * 2;          // 1-KiB blocks per stage = a tile's hi blocks
     constexpr int STAGE_U4 = SB * 64;
-    constexpr int TILE_U4 = 2 * STAGE_U4;  // layout16: a tile's hi blocks, then its lo blocks (not read here)
+    // (tile_u4: STAGE_U4 on a hi-only image, 2 * STAGE_U4 where a tile's lo blocks follow its hi blocks - never read here)
     constexpr int PPW = SB / 8;           // 1-KiB DMA pieces per wave per stage
     constexpr bool AUX = KIND != SCAN_IP; // the tile's 32 norms travel with it: 16 bytes per wave, one more DMA
     constexpr int PW = PPW + (AUX ? 1 : 0);  // vector-memory operations per wave per stage
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
 
     auto issue = [&](uint32_t g) {
         const uint32_t tile = tile0 + blockIdx.x + g * G;
-        const uint4 *src = docs + (size_t)tile * TILE_U4 + (wave8 * PPW) * 64 + lane;
+        const uint4 *src = docs + (size_t)tile * tile_u4 + (wave8 * PPW) * 64 + lane;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave8 * PPW) * 64) * 16);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);

@@ -43,6 +43,12 @@ def test_hidden_states_vs_transformers(setup, layers, note):
     _, hidden = enc.debug_hidden(seqs, layers)
     want = oe.hidden_states(model, seqs, layers)
     tol = {0: 2e-3, 1: 1.5e-2, 2: 2e-2, 12: 3e-2}[layers]
+    if layers == 0:
+        # The embedding LayerNorm's output is stored as float16: the error IS that rounding - half a float16 ulp at the largest
+        # magnitude (2^-11 x 2^ceil(log2 |x|): 1.953e-3 for |x| in [4, 8), which is what 1.948e-3 was) plus the float32
+        # arithmetic of the LayerNorm itself (~1e-5).  The gate follows the data instead of sitting 2.6 % above one instance.
+        top = max(float(np.abs(w).max()) for w in want)
+        tol = float(np.spacing(np.float16(top * 1.01))) / 2 * 1.001 + 2e-5  # (1.01: a value just under a power of two may round across it)
     worst = 0.0
     for got, w, s in zip(split_hidden(hidden, seqs), want, seqs):
         err = np.abs(got - w).max()

@@ -109,9 +109,10 @@ def test_sharded_hybrid_one_rank_equals_oracle_pipeline(corpus, metric):
     kw.close()
 
 
-@pytest.mark.parametrize("cuts", [(0, N // 2, N), (0, 8192, 30_001, N)])
+@pytest.mark.parametrize("cuts", [(0, N // 2, N), (0, 8192, 30_001, N),
+                                  (0, 4_000, 9_999, 15_000, N // 2, 24_000, 31_000, 36_000, N)])  # 8-way, uneven: BASELINE C4 / C5's shard count
 def test_world_gt1_branch_shards_of_one_gpu_equal_unsharded_oracle(corpus, cuts):
-    """Two (three) shards on ONE GPU, each with its own ShardedHybrid, exchanging blobs through LoopbackCollective."""
+    """Two / three / eight shards on ONE GPU, each with its own ShardedHybrid, exchanging blobs through LoopbackCollective."""
     import torch
 
     from aidial_rag_amd.retrievers.bm25_retriever import DeviceBM25

