@@ -79,6 +79,8 @@ def _load():
         "mir_stem_english": ([vp, i64, C.c_char, vp, vp], i32),
         "mir_keywords_preprocess": ([vp, vp, i32, i32, i32, vp], i32),
         "mir_kwp_result_data": ([vp, vp, vp, vp, vp, vp], i32),
+        "mir_kwp_result_dedupe": ([vp, i32], i32),
+        "mir_kwp_result_unique": ([vp, vp, vp, vp, vp], i32),
         "mir_kwp_result_free": ([vp], i32),
         "mir_bm25_destroy": ([vp], i32),
         "mir_bm25_tune": ([vp, i32], i32),

@@ -416,8 +416,45 @@ __host__ __device__ inline long long wave_pool_capacity(int b, int ntiles) {
     return c > one ? c : one;
 }
 
+// a query's postings (the sum of its terms' document frequencies) if the wave kernel can take it - at most 64 terms and at
+// most kWvHeavy postings per tile on average - else -1
+__device__ __forceinline__ long long bm25_query_need(const Bm25Dev &m, const int32_t *__restrict__ q_terms, const int32_t *__restrict__ q_ptr, int q) {
+    const int qb = q_ptr[q], len = q_ptr[q + 1] - qb;
+    if (len > kBm25Chunk) return -1;
+    long long sdf = 0;
+    for (int j0 = 0; j0 < len; j0 += 8) {  // eight terms' two dependent loads in flight at once (one by one: 59 us at b = 4096)
+        int t[8];
+        int64_t a[8], e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = j0 + u < len ? q_terms[qb + j0 + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = t[u] >= 0 && t[u] < m.vocab;
+            a[u] = ok ? m.t_ptr[t[u]] : 0;
+            e[u] = ok ? m.t_ptr[t[u] + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sdf += e[u] - a[u];
+    }
+    return sdf <= (long long)kWvHeavy * m.ntiles ? sdf : -1;
+}
+// Large batches (b > 1024): the three dependent loads per query (its slice, its terms, their posting ranges) spread over the
+// chip instead of waiting in ONE workgroup (59 us at b = 4096, 91 % of it waiting: profiles/r03_bm25_pmc.md); the need lands
+// in pool.off (it fits 32 bits: <= kWvHeavy * tiles), "does not fit" in pool.light, and bm25_plan_kernel only scans.
+__global__ __launch_bounds__(256) void bm25_plan_need_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms, const int32_t *__restrict__ q_ptr,
+                                                             int b, WavePool pool) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= b) return;
+    const long long need = bm25_query_need(m, q_terms, q_ptr, q);
+    pool.light[q] = need >= 0 ? 1 : 0;
+    pool.off[q] = need >= 0 ? (uint32_t)need : 0u;
+}
+
 // One block of 1024 threads: which queries are light (at most 64 terms, at most kWvHeavy postings per tile on average, and
 // room left in the candidate pool - in query order), where their candidates go, and their counters zeroed.
+// PRE: the needs were computed by bm25_plan_need_kernel (pool.light / pool.off); each thread then takes b / 1024 CONSECUTIVE
+// queries and the block scans once.
+template <bool PRE>
 __global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_t *__restrict__ q_terms, const int32_t *__restrict__ q_ptr,
                                                          int b, WavePool pool) {
     __shared__ long long s_scan[1024];
@@ -426,30 +463,43 @@ __global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_
     const int tid = threadIdx.x, nthreads = (int)blockDim.x;  // 1024, or 64 for b <= 64
     if (tid == 0) { s_base = 0; s_nheavy = 0; }
     __syncthreads();
+    if (PRE) {
+        // one round: thread t owns queries [t * per, (t + 1) * per): their needs summed, one block scan of the sums, then the
+        // queries' own offsets in order (same `at`, same holes as the round-by-round form below)
+        const int per = (b + 1023) / 1024, qa = tid * per, qe = min(b, qa + per);
+        long long sum = 0;
+        for (int q = qa; q < qe; ++q) sum += pool.light[q] ? (long long)pool.off[q] : 0;
+        s_scan[tid] = sum;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const long long o = tid >= off ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += o;
+            __syncthreads();
+        }
+        long long at = s_scan[tid] - sum;
+        for (int q = qa; q < qe; ++q) {
+            const bool fits = pool.light[q] != 0;
+            const long long need = fits ? (long long)pool.off[q] : 0;
+            const bool light = fits && at + need <= pool.capacity;
+            pool.light[q] = light ? 1 : 0;
+            pool.off[q] = light ? (uint32_t)at : 0u;
+            pool.count[(size_t)q * kWvCountStride] = 0;
+            pool.arrive[q] = 0;
+            if (!light) pool.hlist[atomicAdd(&s_nheavy, 1)] = q;
+            at += need;
+        }
+        __syncthreads();
+        if (tid == 0) pool.hlist[b] = s_nheavy;
+        return;
+    }
     for (int q0 = 0; q0 < b; q0 += nthreads) {
         const int q = q0 + tid;
         long long need = 0;
         bool fits = false;
         if (q < b) {
-            const int qb = q_ptr[q], len = q_ptr[q + 1] - qb;
-            if (len <= kBm25Chunk) {
-                long long sdf = 0;
-                for (int j0 = 0; j0 < len; j0 += 8) {  // eight terms' two dependent loads in flight at once (one by one: 59 us at b = 4096)
-                    int t[8];
-                    int64_t a[8], e[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = j0 + u < len ? q_terms[qb + j0 + u] : -1;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const bool ok = t[u] >= 0 && t[u] < m.vocab;
-                        a[u] = ok ? m.t_ptr[t[u]] : 0;
-                        e[u] = ok ? m.t_ptr[t[u] + 1] : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) sdf += e[u] - a[u];
-                }
-                if (sdf <= (long long)kWvHeavy * m.ntiles) { need = sdf; fits = true; }
-            }
+            const long long nd = bm25_query_need(m, q_terms, q_ptr, q);
+            if (nd >= 0) { need = nd; fits = true; }
         }
         // inclusive scan of `need` over the queries of this round: 1024 of them through LDS, or - the block is ONE wave for
         // batches of at most 64 queries - a wave scan (the LDS form's twenty block barriers were 5 us of a single query's 42)
@@ -1481,7 +1531,12 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     }
     // 1. fast passes: positives among touched documents.  Light queries (bm25_plan_kernel) one wave per (tile, query) and one
     //    selection per query; the others on the tile kernel + merge
-    bm25_plan_kernel<<<dim3(1), dim3(b <= 64 ? 64 : 1024), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
+    if (b > 1024) {
+        bm25_plan_need_kernel<<<dim3((b + 255) / 256), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
+        bm25_plan_kernel<true><<<dim3(1), dim3(1024), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
+    } else {
+        bm25_plan_kernel<false><<<dim3(1), dim3(b <= 64 ? 64 : 1024), 0, s>>>(dev_view(h), d_terms, d_ptr, b, pool);
+    }
     MIR_HIP(hipGetLastError());
     //    tile kernel: queries per workgroup: as many as still leave ~8 workgroups per CU of parallelism
     int qc = (int)((int64_t)b * T / 2048);

@@ -29,6 +29,13 @@ constexpr int kMaxTilesPerPass = ENC_PASS_TILES;
 #ifndef ENC_ATT
 #define ENC_ATT 1
 #endif
+// fused_qkv_attention_kernel for the sequences of at most kFqaTiles token tiles (throughput path): OFF by default - correct
+// (bit-identical to the other kernels, tests/test_gpu_encoder.py runs it) but 5 % SLOWER on its share than qkv_kernel +
+// attention_kernel (427 against 405 us per pass: DESIGN.md 4b, round 4); MIR_ENC_FUSED_QKV_ATTENTION=1 at mir_encoder_create, or
+// -DENC_FQA=1, selects it
+#ifndef ENC_FQA
+#define ENC_FQA 0
+#endif
 
 // Pack a Hugging Face Linear weight W[out][in] (y = x W^T + b) into MFMA A-fragment
 // order for out^T = W x^T: block (nt, ks) = 64 lanes x 8 halfs, lane (row = l&31,
@@ -57,6 +64,7 @@ struct Layer {
 
 struct mir_encoder {
     int device = 0;
+    bool fused_qkv_attention = ENC_FQA != 0;
     int layers = 0;
     int vocab = 0, max_pos = 0;
     float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
@@ -105,22 +113,79 @@ struct Batch {
     std::vector<TileInfo> tiles;     // [n_tiles]
     std::vector<int32_t> seq_first;  // [n_seq]
     std::vector<int32_t> units;      // attention units, 4 ints each: first tile | (tiles - 1) << 24, key tiles, sequence length, the sequence's first tile
+    std::vector<int32_t> bins;       // fused QKV + attention: kFqaTiles slots of 4 ints per bin (encoder_attention.hip)
+    std::vector<int32_t> tile_pos;   // [n_tiles] a tile's position in INPUT order (the debug hidden states are returned in it)
+    int n_long_tiles = 0;            // tiles [0, n_long_tiles): the sequences that stay on qkv_kernel + attention_kernel
 };
 
-// Sequences [s0, s1) -> padded tiles.
-void build_batch(const int32_t *token_ids, const int64_t *offs, const int32_t *lens, int s0, int s1, Batch &b) {
-    b.ids.clear(); b.tiles.clear(); b.seq_first.clear(); b.units.clear();
-    for (int s = s0; s < s1; ++s) {
+// Sequences [s0, s1) -> padded tiles.  `fused`: the pass will run the fused QKV + attention kernel (throughput path): the
+// sequences of more than kFqaTiles tiles come FIRST (their tiles are qkv_kernel's and attention_kernel's), the others after
+// them, packed - whole sequences, longest first, first fit - into bins of at most kFqaTiles tiles.  Every per-sequence result
+// is addressed through seq_first, so the order of the tiles inside a pass is free.
+void build_batch(const int32_t *token_ids, const int64_t *offs, const int32_t *lens, int s0, int s1, bool fused, Batch &b) {
+    b.ids.clear(); b.tiles.clear(); b.seq_first.clear(); b.units.clear(); b.bins.clear(); b.tile_pos.clear();
+    b.n_long_tiles = 0;
+    const int ns = s1 - s0;
+    b.seq_first.assign((size_t)ns, 0);
+    std::vector<int32_t> in_pos((size_t)ns);  // a sequence's first tile in input order
+    {
+        int p = 0;
+        for (int s = s0; s < s1; ++s) { in_pos[s - s0] = p; p += (lens[s] + 31) / 32; }
+    }
+    auto place = [&](int s) {  // the sequence's tiles, token ids and attention units at the end of the pass
         const int len = lens[s];
         const int nt = (len + 31) / 32;
         const int first = (int)b.tiles.size();
-        b.seq_first.push_back(first);
-        for (int t = 0; t < nt; ++t) b.tiles.push_back(TileInfo{first, nt, len, s - s0});
-        for (int t = 0; t < nt; t += 2) b.units.insert(b.units.end(), {(first + t) | ((t + 1 < nt ? 1 : 0) << 24), nt, len, first});
+        b.seq_first[s - s0] = first;
+        for (int t = 0; t < nt; ++t) {
+            b.tiles.push_back(TileInfo{first, nt, len, s - s0});
+            b.tile_pos.push_back(in_pos[s - s0] + t);
+        }
         const size_t base = b.ids.size();
         b.ids.resize(base + (size_t)nt * 32, 0);
         std::memcpy(b.ids.data() + base, token_ids + offs[s], sizeof(int32_t) * len);
+        return first;
+    };
+    if (!fused) {
+        for (int s = s0; s < s1; ++s) {
+            const int nt = (lens[s] + 31) / 32, first = place(s);
+            for (int t = 0; t < nt; t += 2) b.units.insert(b.units.end(), {(first + t) | ((t + 1 < nt ? 1 : 0) << 24), nt, lens[s], first});
+        }
+        b.n_long_tiles = (int)b.tiles.size();
+        return;
     }
+    for (int s = s0; s < s1; ++s) {
+        const int nt = (lens[s] + 31) / 32;
+        if (nt <= kFqaTiles) continue;
+        const int first = place(s);
+        for (int t = 0; t < nt; t += 2) b.units.insert(b.units.end(), {(first + t) | ((t + 1 < nt ? 1 : 0) << 24), nt, lens[s], first});
+    }
+    b.n_long_tiles = (int)b.tiles.size();
+    // the short sequences by tiles, descending (counting sort, stable), then first fit: open[r] = bins with r free slots
+    std::vector<int32_t> by_len[kFqaTiles + 1];
+    for (int s = s0; s < s1; ++s) {
+        const int nt = (lens[s] + 31) / 32;
+        if (nt <= kFqaTiles) by_len[nt].push_back(s);
+    }
+    std::vector<int32_t> open[kFqaTiles + 1];
+    for (int nt = kFqaTiles; nt >= 1; --nt)
+        for (int32_t s : by_len[nt]) {
+            int bin = -1, room = 0;
+            for (int r = nt; r <= kFqaTiles && bin < 0; ++r)
+                if (!open[r].empty()) { bin = open[r].back(); open[r].pop_back(); room = r; }
+            if (bin < 0) {
+                bin = (int)(b.bins.size() / (4 * kFqaTiles));
+                b.bins.resize(b.bins.size() + 4 * kFqaTiles, 0);
+                for (int i = 0; i < kFqaTiles; ++i) b.bins[(size_t)(bin * kFqaTiles + i) * 4] = -1;
+                room = kFqaTiles;
+            }
+            const int slot0 = kFqaTiles - room, first = place(s);
+            for (int t = 0; t < nt; ++t) {
+                int32_t *sl = &b.bins[(size_t)(bin * kFqaTiles + slot0 + t) * 4];
+                sl[0] = first + t; sl[1] = slot0 | (nt << 8); sl[2] = lens[s]; sl[3] = 0;
+            }
+            if (room - nt > 0) open[room - nt].push_back(bin);
+        }
 }
 
 }  // namespace
@@ -146,6 +211,7 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
     mir_encoder *e = new (std::nothrow) mir_encoder();
     MIR_REQUIRE(e != nullptr, "out of host memory");
     e->device = device; e->layers = layers; e->vocab = vocab; e->max_pos = max_pos;
+    if (const char *fq = getenv("MIR_ENC_FUSED_QKV_ATTENTION")) e->fused_qkv_attention = atoi(fq) != 0;
     auto fail = [&](int32_t code) { free_encoder(e); return code; };
 #define MIR_TRY(call)                                                                              \
     do {                                                                                           \
@@ -218,7 +284,7 @@ int32_t mir_encoder_create(int32_t hidden, int32_t layers, int32_t heads, int32_
     MIR_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[0], hipEventDisableTiming));
     MIR_TRY(hipEventCreateWithFlags(&e->ws_done[1], hipEventDisableTiming));
-    if (ffn_prepare() != MIR_OK) return fail(MIR_ERR_HIP);
+    if (ffn_prepare() != MIR_OK || fqa_prepare() != MIR_OK) return fail(MIR_ERR_HIP);
     {
         auto kern = qkv_kernel;
         MIR_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS_BYTES));
@@ -291,13 +357,14 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         // device buffers are reused; the pass in between keeps the GPU busy meanwhile
         rc = retire(slot);
         if (rc != MIR_OK) return rc;
-        build_batch(token_ids, offs.data(), seq_lens, s0, s1, b);
+        build_batch(token_ids, offs.data(), seq_lens, s0, s1, e->fused_qkv_attention && tiles > kSmallTiles, b);
         const int nt = (int)b.tiles.size();
         const size_t act_b = (size_t)nt * NFB * 2 * 64 * 16;
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
         const size_t o_ids = take(b.ids.size() * 4), o_ti = take(b.tiles.size() * sizeof(TileInfo)), o_sf = take(b.seq_first.size() * 4);
         const size_t o_un = take(b.units.size() * 4);
+        const size_t o_bn = take(b.bins.size() * 4), o_tp = take(b.tile_pos.size() * 4);
         const size_t o_a = take(act_b), o_b = take(act_b), o_q = take(act_b), o_k = take(act_b), o_v = take(act_b);
         // latency path (<= kSmallTiles tiles): Y float32 [tile][384][32] and the FFN's h fragments [tile][96][64] x 16 B
         const bool small = nt <= kSmallTiles;
@@ -315,7 +382,9 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         const size_t p_ids = 0, p_ti = p_ids + ((b.ids.size() * 4 + 255) & ~(size_t)255);
         const size_t p_sf = p_ti + ((b.tiles.size() * sizeof(TileInfo) + 255) & ~(size_t)255);
         const size_t p_un = p_sf + ((b.seq_first.size() * 4 + 255) & ~(size_t)255);
-        const size_t p_out = p_un + ((b.units.size() * 4 + 255) & ~(size_t)255);
+        const size_t p_bn = p_un + ((b.units.size() * 4 + 255) & ~(size_t)255);
+        const size_t p_tp = p_bn + ((b.bins.size() * 4 + 255) & ~(size_t)255);
+        const size_t p_out = p_tp + ((b.tile_pos.size() * 4 + 255) & ~(size_t)255);
         const size_t p_hid = p_out + (((size_t)(s1 - s0) * H * 4 + 255) & ~(size_t)255);
         const size_t p_need = p_hid + (hidden_out ? (size_t)nt * 32 * H * 4 : 0);
         if (e->pin_cap[slot] < p_need) {
@@ -329,9 +398,11 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         std::memcpy(pn + p_ti, b.tiles.data(), b.tiles.size() * sizeof(TileInfo));
         std::memcpy(pn + p_sf, b.seq_first.data(), b.seq_first.size() * 4);
         std::memcpy(pn + p_un, b.units.data(), b.units.size() * 4);
-        // [ids | tiles | seq_first | units] have the same 256-aligned offsets on both sides: one copy
-        MIR_REQUIRE(o_ids == p_ids && o_ti == p_ti && o_sf == p_sf && o_un == p_un, "staging layout mismatch");
-        MIR_HIP(hipMemcpyAsync(w + o_ids, pn + p_ids, p_un + b.units.size() * 4, hipMemcpyHostToDevice, s));
+        std::memcpy(pn + p_bn, b.bins.data(), b.bins.size() * 4);
+        std::memcpy(pn + p_tp, b.tile_pos.data(), b.tile_pos.size() * 4);
+        // [ids | tiles | seq_first | units | bins | tile_pos] have the same 256-aligned offsets on both sides: one copy
+        MIR_REQUIRE(o_ids == p_ids && o_ti == p_ti && o_sf == p_sf && o_un == p_un && o_bn == p_bn && o_tp == p_tp, "staging layout mismatch");
+        MIR_HIP(hipMemcpyAsync(w + o_ids, pn + p_ids, p_tp + b.tile_pos.size() * 4, hipMemcpyHostToDevice, s));
         const int32_t *d_ids = reinterpret_cast<int32_t *>(w + o_ids);
         const TileInfo *d_ti = reinterpret_cast<TileInfo *>(w + o_ti);
         uint4 *a0 = reinterpret_cast<uint4 *>(w + o_a), *a1 = reinterpret_cast<uint4 *>(w + o_b);
@@ -371,14 +442,22 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         }
         for (int li = 0; li < nl && !small; ++li) {
             const Layer &l = e->L[li];
-            qkv_kernel<<<dim3((nt + QKV_WAVES * QKV_G - 1) / (QKV_WAVES * QKV_G)), dim3(64 * QKV_WAVES), QKV_LDS_BYTES, s>>>(a0, nt, l.wqkv, l.bqkv, qf, kf, vf);
-            {
+            // sequences of more than kFqaTiles tiles (tiles [0, nl)): QKV projection, then attention from Q / K / V in HBM; the others:
+            // both in one kernel, bin by bin, Q / K / V never leaving the CU (fused_qkv_attention_kernel).  a1 = context
+            const int nl = b.n_long_tiles;
+            if (nl > 0) {
+                qkv_kernel<<<dim3((nl + QKV_WAVES * QKV_G - 1) / (QKV_WAVES * QKV_G)), dim3(64 * QKV_WAVES), QKV_LDS_BYTES, s>>>(a0, nl, l.wqkv, l.bqkv, qf, kf, vf);
 #if ENC_ATT == 2
                 const int32_t arc = launch_attention2(qf, kf, vf, reinterpret_cast<const int32_t *>(w + o_un), (int)b.units.size() / 4, a1, s);
 #else
-                const int32_t arc = launch_attention(qf, kf, vf, d_ti, nt, a1, s);
+                const int32_t arc = launch_attention(qf, kf, vf, d_ti, nl, a1, s);
 #endif
                 if (arc != MIR_OK) return arc;
+            }
+            {
+                const int32_t frc = launch_fused_qkv_attention(a0, l.wqkv, l.bqkv, reinterpret_cast<const int32_t *>(w + o_bn),
+                                                               (int)(b.bins.size() / (4 * kFqaTiles)), a1, s);
+                if (frc != MIR_OK) return frc;
             }
             oproj_ln_kernel<<<dim3(std::min((nt + 3) / 4, OPROJ_MAX_GRID)), dim3(512), OPROJ_LDS_BYTES, s>>>(a1, nt, l.wo, l.attn_params, l.attn_params + H, l.attn_params + 2 * H,
                                                                    a0, a1);  // in place: a tile's two waves read its context before the first barrier and write after the last
@@ -397,7 +476,7 @@ static int32_t encode_impl(mir_encoder *e, const int32_t *token_ids, const int32
         }
         if (hidden_out) {
             MIR_REQUIRE((int64_t)nt * 32 <= hidden_cap_tokens, "hidden_out too small: need %d tokens", nt * 32);
-            act_unpack_kernel<<<dim3(nt), dim3(64), 0, s>>>(a0, nt, reinterpret_cast<float *>(w + o_hid));
+            act_unpack_kernel<<<dim3(nt), dim3(64), 0, s>>>(a0, nt, reinterpret_cast<const int32_t *>(w + o_tp), reinterpret_cast<float *>(w + o_hid));
             MIR_HIP(hipMemcpyAsync(pn + p_hid, w + o_hid, (size_t)nt * 32 * H * 4, hipMemcpyDeviceToHost, s));
             pend[slot].hid_dst = hidden_out; pend[slot].hid_off = p_hid; pend[slot].hid_bytes = (size_t)nt * 32 * H * 4;
         }

@@ -365,6 +365,134 @@ __global__ __launch_bounds__(256) void attention2_kernel(const uint4 *__restrict
 }
 
 
+// FUSED QKV projection + attention (round 4, ENC_FQA): Q, K and V never leave the CU.
+// Per layer and 12 288-tile pass qkv_kernel writes 0.9 GB of Q / K / V and attention_kernel reads them back - K / V once per
+// query tile of the sequence - and by counters and ablations both kernels sit on the CU's vector-memory path (~28 B/clk per
+// CU: attention 367 us with real K / V loads and no arithmetic at all 337).  Here a workgroup takes a BIN of whole
+// sequences, at most FQA_TILES token tiles, one WAVE per tile:
+//   * the wave keeps its tile's activations resident (24 B fragments, 96 VGPRs) through all 12 heads;
+//   * the layer's 36 weight blocks (24 KiB: one head's K, V or Q projection) stream through a 3-slot LDS ring (LDS-DMA, one
+//     counted wait + one raw barrier per block), shared by the bin's waves, in head order K_h, V_h, Q_h;
+//   * per head every wave projects its tile's K and V (the same chains and epilogue arithmetic as qkv_kernel / qkv_small_kernel:
+//     a sequence's embedding does not depend on which kernels served it), leaves the fragments in LDS, projects Q into
+//     registers, and after one barrier attends over its sequence's key tiles FROM LDS (attn_step1_rt, the kernels' shared step);
+//   * the context goes out as attention_kernel writes it.
+// What crosses the vector-memory path per tile and layer: x once (24 KiB), the weights once per bin (864 KiB / 8 tiles), the
+// context (2 KiB per head) - against x + 72 KiB of Q / K / V out and (2 + 4 n_kt) KiB per head in.
+// Sequences of more than FQA_TILES tiles stay on qkv_kernel + attention_kernel (their activations do not fit the registers
+// of one workgroup): the host puts them FIRST in a pass, the binned ones after.
+constexpr int FQA_TILES = 8;                         // waves per workgroup = token tiles per bin
+constexpr int FQA_WSLOTS = 3;
+#ifndef FQA_PF
+#define FQA_PF 6
+#endif
+constexpr int FQA_BLOCK_BYTES = KS_H * 1024;         // one (projection, head) weight block
+constexpr int FQA_PPW = KS_H / FQA_TILES;            // 1-KiB pieces of a block per wave
+constexpr int FQA_KV_OFF = FQA_WSLOTS * FQA_BLOCK_BYTES;
+constexpr int FQA_BIAS_OFF = FQA_KV_OFF + FQA_TILES * 4096;
+constexpr int FQA_LDS_BYTES = FQA_BIAS_OFF + 3 * H * 4;
+static_assert(KS_H % FQA_TILES == 0, "a weight block's pieces divide among the waves");
+
+__global__ __launch_bounds__(64 * FQA_TILES, 1) void fused_qkv_attention_kernel(const uint4 *__restrict__ act, const uint4 *__restrict__ wqkv,
+                                                                                 const float *__restrict__ bqkv, const int4 *__restrict__ bins,
+                                                                                 uint4 *__restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *bias = reinterpret_cast<float *>(smem + FQA_BIAS_OFF);
+    uint4 *kvs = reinterpret_cast<uint4 *>(smem + FQA_KV_OFF);  // [slot][K0 K1 V0 V1][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // this wave's slot of the bin: {tile or -1, first slot of its sequence | key tiles << 8, sequence length, -}
+    typedef int __attribute__((ext_vector_type(4))) i32x4;
+    const i32x4 sl = *reinterpret_cast<const __attribute__((address_space(4))) i32x4 *>(reinterpret_cast<uintptr_t>(bins + (size_t)blockIdx.x * FQA_TILES + wave));
+    const bool live = sl.x >= 0;
+    const i32x4 s0 = *reinterpret_cast<const __attribute__((address_space(4))) i32x4 *>(reinterpret_cast<uintptr_t>(bins + (size_t)blockIdx.x * FQA_TILES));
+    const int tt = live ? sl.x : s0.x;  // an empty slot shadows the bin's first tile: it moves its share of the weights, stores nothing
+    const int kv0 = sl.y & 0xff, n_kt = sl.y >> 8, seq_len = sl.z;
+    for (int i = tid; i < 3 * H; i += 64 * FQA_TILES) bias[i] = bqkv[i];
+    uint4 x[KS_H];
+    {
+        const uint4 *xin = act + (size_t)tt * (NFB * 2 * 64) + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS_H; ++ks) x[ks] = enc_load_nt(xin + ks * 64);  // read once here (the output projection's LayerNorm re-reads it as the residual much later)
+    }
+    // ordinary loads are complete before the first DMA: the counted waits below count DMAs and stores only
+#pragma unroll
+    for (int ks = 0; ks < KS_H; ++ks) asm volatile("" : "+v"(x[ks].x), "+v"(x[ks].y), "+v"(x[ks].z), "+v"(x[ks].w));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the biases are in LDS
+
+    // weight blocks in the order they are used: head hd: K (tile 12 + hd), V (24 + hd), Q (hd)
+    auto block_tile = [](int wb) { const int hd = wb / 3, j = wb - 3 * hd; return (j == 0 ? NH : j == 1 ? 2 * NH : 0) + hd; };
+    auto issue = [&](int wb) {
+        const uint4 *src = wqkv + (size_t)block_tile(wb) * (KS_H * 64) + (size_t)(wave * FQA_PPW) * 64;  // wave-uniform
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(enc_lds_addr(smem) + (uint32_t)((wb % FQA_WSLOTS) * FQA_BLOCK_BYTES + wave * FQA_PPW * 1024));
+#pragma unroll
+        for (int i = 0; i < FQA_PPW; ++i) enc_glds16_s(src + i * 64, (uint32_t)lane * 16u, dst + i * 1024);
+    };
+    issue(0);
+    issue(1);
+    uint4 *out = ctx + (size_t)tt * (NFB * 2 * 64) + lane;
+    uint4 qq[2];
+    for (int hd = 0; hd < NH; ++hd) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {  // 0 = K, 1 = V, 2 = Q
+            const int wb = 3 * hd + j;
+            // block wb has landed: younger than its pieces are block wb + 1's and - at a head's first block, in a wave that
+            // has a tile - the previous head's two context stores
+            if (wb == 3 * NH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (j == 0 && hd > 0 && live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FQA_PPW + 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FQA_PPW) : "memory");
+            if (j == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's K / V reads of the previous head are done)
+            __builtin_amdgcn_s_barrier();  // block wb is in LDS for everyone; everyone has left block wb - 1's slot (and, j = 0, the K / V of the previous head)
+            if (wb + 2 < 3 * NH) issue(wb + 2);
+            if (!live) continue;
+            const uint4 *w = reinterpret_cast<const uint4 *>(smem + (size_t)(wb % FQA_WSLOTS) * FQA_BLOCK_BYTES) + lane;
+            f32x16 acc = {0};
+            // one fragment read per MFMA (one tile per wave: qkv_kernel's two tiles share theirs): FQA_PF reads in flight cover
+            // the LDS latency behind 32-cycle MFMAs
+            constexpr int PF = FQA_PF;
+            uint4 fr[PF + 1];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) fr[i] = w[i * 64];
+#pragma unroll
+            for (int ks = 0; ks < KS_H; ++ks) {
+                if (ks + PF < KS_H) fr[(ks + PF) % (PF + 1)] = w[(ks + PF) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = j == 1 ? mfma(x[ks], fr[ks % (PF + 1)], acc) : mfma(fr[ks % (PF + 1)], x[ks], acc);  // V: x W (rows = tokens); Q, K: W^T x^T
+            }
+            const float *b = bias + block_tile(wb) * 32;
+            if (j == 1) {
+                const float bv = b[lane & 31];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += bv;
+            } else {
+                const float qs = j == 2 ? kQScaleLog2e : 1.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + b[fi(r, h)]) * qs;
+            }
+            if (j == 2) {
+                qq[0] = acc_to_frag(acc, 0);
+                qq[1] = acc_to_frag(acc, 1);
+            } else {
+                uint4 *dst = kvs + (size_t)wave * 256 + (size_t)(2 * j) * 64 + lane;
+                dst[0] = acc_to_frag(acc, 0);
+                dst[64] = acc_to_frag(acc, 1);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // the head's K / V of every tile of the bin are in LDS
+        if (!live) continue;
+        AttnState st;
+        for (int kt = 0; kt < n_kt; ++kt) {
+            const uint4 *kv = kvs + (size_t)(kv0 + kt) * 256 + lane;
+            const uint4 k0 = kv[0], k1 = kv[64], v0 = kv[128], v1 = kv[192];
+            attn_step1_rt(st, qq, k0, k1, v0, v1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
+        }
+        attn_store(st, out + (size_t)(hd * 2) * 64);
+    }
+}
+
+
 // Latency path, batches whose sequences all fit one token tile (queries): QKV projection and attention of one (head,
 // tile) in ONE dispatch.  Three waves compute the head's Q, K and V fragments exactly as qkv_small_kernel does (same
 // chains, same bias / scale arithmetic), hand them over through LDS, and the first wave runs the one attention step:
@@ -470,6 +598,20 @@ int32_t launch_attention2(const uint4 *qf, const uint4 *kf, const uint4 *vf, con
                           hipStream_t stream) {
     const int n_wg = (n_units * NH + 3) / 4;
     attention2_kernel<<<dim3((n_wg + 7) / 8 * 8), dim3(256), 0, stream>>>(qf, kf, vf, reinterpret_cast<const int4 *>(units), n_units, ctx);
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
+int32_t fqa_prepare() {
+    auto kern = fused_qkv_attention_kernel;
+    MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FQA_LDS_BYTES));
+    return MIR_OK;
+}
+// bins: n_bins x FQA_TILES slots {tile or -1, first slot of the sequence | key tiles << 8, sequence length, 0} (encoder.hip: build_batch)
+int32_t launch_fused_qkv_attention(const uint4 *act, const uint4 *wqkv, const float *bqkv, const int32_t *bins, int n_bins, uint4 *ctx,
+                                   hipStream_t stream) {
+    if (n_bins <= 0) return MIR_OK;
+    fused_qkv_attention_kernel<<<dim3(n_bins), dim3(64 * FQA_TILES), FQA_LDS_BYTES, stream>>>(act, wqkv, bqkv, reinterpret_cast<const int4 *>(bins), ctx);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }

@@ -194,6 +194,10 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void qkv_kernel(const uint4 *__r
 // the separate file.
 int32_t launch_attention2(const uint4 *qf, const uint4 *kf, const uint4 *vf, const int32_t *units, int n_units, uint4 *ctx,
                           hipStream_t stream);  // units: n_units x int4, see attention2_kernel
+constexpr int kFqaTiles = 8;  // token tiles (= waves) per bin of the fused QKV + attention kernel (encoder_attention.hip)
+int32_t fqa_prepare();        // once per process: dynamic-LDS attribute
+int32_t launch_fused_qkv_attention(const uint4 *act, const uint4 *wqkv, const float *bqkv, const int32_t *bins, int n_bins, uint4 *ctx,
+                                   hipStream_t stream);
 int32_t launch_attention(const uint4 *qf, const uint4 *kf, const uint4 *vf, const TileInfo *ti, int n_tiles,
                          uint4 *ctx, hipStream_t stream);
 // latency path, every sequence of the batch a single tile: QKV projection + attention in one dispatch (encoder_attention.hip)
@@ -594,11 +598,13 @@ __global__ __launch_bounds__(64) void pool_normalize_kernel(const uint4 *__restr
 }
 
 // debug / test helper: ACT -> float32 [n_tokens][384] natural order; one wave per tile
-__global__ __launch_bounds__(64) void act_unpack_kernel(const uint4 *__restrict__ act, int n_tiles,
+// (tile_pos: a tile's position in input order - the throughput path orders a pass's tiles its own way, build_batch)
+__global__ __launch_bounds__(64) void act_unpack_kernel(const uint4 *__restrict__ act, int n_tiles, const int32_t *__restrict__ tile_pos,
                                                         float *__restrict__ out) {
-    const int tt = blockIdx.x, lane = threadIdx.x, h = lane >> 5, t_in = lane & 31;
-    if (tt >= n_tiles) return;
-    const uint4 *tile = act + (size_t)tt * (NFB * 2 * 64);
+    const int lane = threadIdx.x, h = lane >> 5, t_in = lane & 31;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const uint4 *tile = act + (size_t)blockIdx.x * (NFB * 2 * 64);
+    const int tt = tile_pos[blockIdx.x];
     for (int blk = 0; blk < NFB * 2; ++blk) {
         float v[8];
         frag_to_floats(tile[blk * 64 + lane], v);

@@ -17,10 +17,13 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <string_view>
 #include <thread>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -619,6 +622,11 @@ struct mir_kwp_result {
     std::vector<int32_t> counts;   // tokens per text
     std::vector<int64_t> ends;     // bytes[0, ends[i]) = the tokens of texts 0..i
     int64_t n_tokens = 0;
+    // mir_kwp_result_dedupe: the batch's distinct tokens in order of first appearance, and every token as an index into them
+    std::string uniq;              // every distinct token followed by a NUL
+    std::vector<int32_t> ids;      // [n_tokens]
+    int32_t n_unique = 0;
+    bool deduped = false;
 };
 
 extern "C" {
@@ -643,9 +651,17 @@ int32_t mir_keywords_preprocess(const char *texts, const int64_t *offsets, int32
     (void)abbreviations();  // built before the threads start
     constexpr int32_t kGrain = 32;  // texts per work item
     const int32_t n_items = (n_texts + kGrain - 1) / kGrain;
+    // n_threads <= 0: the host's cores, but no more than 16 (MIR_HOST_THREADS overrides): the reported core count of a shared
+    // GPU host (256 on the bench box) says nothing about this process's share, and the index build runs this beside the
+    // encoder's host threads (documents.py:188-198) - 256 threads per call cut the COMBINED rate of the two builders to a third
     int hw = (int)std::thread::hardware_concurrency();
     if (hw <= 0) hw = 1;
-    int nt = n_threads > 0 ? n_threads : hw;
+    static const int cap = [] {
+        const char *e = getenv("MIR_HOST_THREADS");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 16;
+    }();
+    int nt = n_threads > 0 ? n_threads : std::min(hw, cap);
     nt = std::max(1, std::min(nt, std::max(1, (int)n_items)));
     std::vector<std::string> parts((size_t)n_items);
     std::atomic<int32_t> next{0};
@@ -735,6 +751,113 @@ int32_t mir_kwp_result_data(const mir_kwp_result *r, const char **bytes, int64_t
     if (counts) *counts = r->counts.data();
     if (byte_ends) *byte_ends = r->ends.data();
     if (n_tokens) *n_tokens = r->n_tokens;
+    return MIR_OK;
+}
+
+// The batch's DISTINCT tokens (order of first appearance) and every token as an index into them: a consumer that maps tokens
+// to term ids (BM25Retriever's process-wide vocabulary, bm25_retriever.py:78) touches each distinct token once - ~20 000 per
+// 4096 chunks instead of ~800 000 tokens - and a Python caller needs no str object per token.  Threads dedupe their own
+// stretch of texts; the stretches' distinct tokens meet in one table, in order.
+int32_t mir_kwp_result_dedupe(mir_kwp_result *r, int32_t n_threads) {
+    MIR_REQUIRE(r != nullptr, "result is NULL");
+    if (r->deduped) return MIR_OK;
+    const int32_t n_texts = (int32_t)r->counts.size();
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw <= 0) hw = 1;
+    int nt = n_threads > 0 ? n_threads : std::min(hw, 16);
+    nt = std::max(1, std::min(nt, std::max(1, n_texts / 64)));
+    struct Part {
+        int32_t t0 = 0, t1 = 0;
+        int64_t tok0 = 0;
+        std::vector<std::string_view> uniq;
+        std::vector<int32_t> table;
+    };
+    std::vector<Part> parts((size_t)nt);
+    try {
+        r->ids.assign((size_t)r->n_tokens, 0);
+        {
+            int64_t tok = 0;
+            for (int p = 0; p < nt; ++p) {
+                parts[p].t0 = (int32_t)((int64_t)n_texts * p / nt);
+                parts[p].t1 = (int32_t)((int64_t)n_texts * (p + 1) / nt);
+                parts[p].tok0 = tok;
+                for (int32_t t = parts[p].t0; t < parts[p].t1; ++t) tok += r->counts[(size_t)t];
+            }
+        }
+        const char *base = r->bytes.data();
+        auto work = [&](int p) {
+            Part &P = parts[p];
+            std::unordered_map<std::string_view, int32_t> seen;
+            seen.reserve(1 << 14);
+            const int64_t b0 = P.t0 > 0 ? r->ends[(size_t)P.t0 - 1] : 0, b1 = P.t1 > 0 ? r->ends[(size_t)P.t1 - 1] : 0;
+            int64_t tok = P.tok0;
+            for (int64_t i = b0; i < b1;) {
+                const size_t len = std::strlen(base + i);
+                const std::string_view sv(base + i, len);
+                auto it = seen.find(sv);
+                int32_t id;
+                if (it == seen.end()) {
+                    id = (int32_t)P.uniq.size();
+                    seen.emplace(sv, id);
+                    P.uniq.push_back(sv);
+                } else id = it->second;
+                r->ids[(size_t)tok++] = id;
+                i += (int64_t)len + 1;
+            }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int p = 0; p < nt; ++p) th.emplace_back(work, p);
+            for (auto &t : th) t.join();
+        }
+        std::unordered_map<std::string_view, int32_t> all;
+        all.reserve(1 << 16);
+        std::vector<std::string_view> order;
+        for (Part &P : parts) {
+            P.table.resize(P.uniq.size());
+            for (size_t u = 0; u < P.uniq.size(); ++u) {
+                auto it = all.find(P.uniq[u]);
+                if (it == all.end()) {
+                    P.table[u] = (int32_t)order.size();
+                    all.emplace(P.uniq[u], (int32_t)order.size());
+                    order.push_back(P.uniq[u]);
+                } else P.table[u] = it->second;
+            }
+        }
+        auto remap = [&](int p) {
+            const Part &P = parts[p];
+            const int64_t e = p + 1 < nt ? parts[p + 1].tok0 : r->n_tokens;
+            for (int64_t i = P.tok0; i < e; ++i) r->ids[(size_t)i] = P.table[(size_t)r->ids[(size_t)i]];
+        };
+        if (nt == 1) remap(0);
+        else {
+            std::vector<std::thread> th;
+            for (int p = 0; p < nt; ++p) th.emplace_back(remap, p);
+            for (auto &t : th) t.join();
+        }
+        size_t ub = 0;
+        for (const auto &sv : order) ub += sv.size() + 1;
+        r->uniq.clear();
+        r->uniq.reserve(ub);
+        for (const auto &sv : order) { r->uniq.append(sv.data(), sv.size()); r->uniq.push_back('\0'); }
+        r->n_unique = (int32_t)order.size();
+    } catch (const std::exception &e) {
+        mir::set_error("keywords dedupe failed: %s", e.what());
+        return MIR_ERR_INVALID;
+    }
+    r->deduped = true;
+    return MIR_OK;
+}
+
+// after mir_kwp_result_dedupe: uniq_bytes = the distinct tokens, each followed by a NUL; ids[n_tokens] index them
+int32_t mir_kwp_result_unique(const mir_kwp_result *r, const char **uniq_bytes, int64_t *n_uniq_bytes, int32_t *n_unique,
+                              const int32_t **ids) {
+    MIR_REQUIRE(r != nullptr && r->deduped, "result is NULL or not deduplicated (mir_kwp_result_dedupe)");
+    if (uniq_bytes) *uniq_bytes = r->uniq.data();
+    if (n_uniq_bytes) *n_uniq_bytes = (int64_t)r->uniq.size();
+    if (n_unique) *n_unique = r->n_unique;
+    if (ids) *ids = r->ids.data();
     return MIR_OK;
 }
 

@@ -100,6 +100,9 @@ struct mir_index {
     float *d_docsq = nullptr;    // padded to n_tiles*32
     float *d_invnorm = nullptr;  // padded to n_tiles*32
     float *d_dnorm = nullptr;    // max((float)|row|, 1e-8), exact_metric_wave's summation order: cosine_sim of the batched exact pass
+    float *d_tilemax = nullptr;  // [n_tiles] a tile's largest row norm: the sieve's per-tile margin (layout16)
+    bool norms_spread = false;   // the largest row norm exceeds the smallest tile maximum by more than 1/16: the sieve takes its margins per tile /
+                                 // per row (unit-norm embeddings - the headline - keep round 3's one margin per query: the per-tile form cost that step ~3 %)
     float *d_maxnorm = nullptr;
     unsigned long long *d_stats = nullptr;  // 8 counters of the sieve (mir_index_scan_stats)
     int64_t *d_chunk = nullptr;
@@ -151,6 +154,7 @@ static void free_index(mir_index *ix) {
     (void)hipFree(ix->d_docsq);
     (void)hipFree(ix->d_invnorm);
     (void)hipFree(ix->d_dnorm);
+    (void)hipFree(ix->d_tilemax);
     (void)hipFree(ix->d_maxnorm);
     (void)hipFree(ix->d_stats);
     (void)hipFree(ix->d_chunk);
@@ -194,12 +198,13 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
     MIR_HIP(hipMalloc(&ix->d_split, std::max<size_t>(split_bytes, 16)));
     MIR_HIP(hipMalloc(&ix->d_docsq, std::max<size_t>(aux_bytes, 16)));
     MIR_HIP(hipMalloc(&ix->d_invnorm, std::max<size_t>(aux_bytes, 16)));
-    MIR_HIP(hipMalloc(&ix->d_maxnorm, 16));
+    MIR_HIP(hipMalloc(&ix->d_maxnorm, 32));  // norm statistics: [0] largest norm, [1] non-finite flag, [2] largest bf16 residual, [3] largest residual / norm, [4] smallest tile maximum (bits), [5..7] -
     MIR_HIP(hipMalloc(&ix->d_dnorm, std::max<size_t>((size_t)n * 4, 16)));
-    ix->hbm_bytes += split_bytes + 2 * aux_bytes + 16 + (size_t)n * 4;
+    ix->hbm_bytes += split_bytes + 2 * aux_bytes + 32 + (size_t)n * 4;
     MIR_HIP(hipMemsetAsync(ix->d_docsq, 0, std::max<size_t>(aux_bytes, 16), stream));
     MIR_HIP(hipMemsetAsync(ix->d_invnorm, 0, std::max<size_t>(aux_bytes, 16), stream));
-    MIR_HIP(hipMemsetAsync(ix->d_maxnorm, 0, 16, stream));
+    MIR_HIP(hipMemsetAsync(ix->d_maxnorm, 0, 32, stream));
+    MIR_HIP(hipMemsetAsync(reinterpret_cast<char *>(ix->d_maxnorm) + 16, 0xff, 4, stream));  // word 4: a minimum over unsigned float bits
     MIR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_stats), 64));
     MIR_HIP(hipMemsetAsync(ix->d_stats, 0, 64, stream));
     if (n > 0) {
@@ -227,6 +232,13 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
         if (ix->native16) row_dnorm_kernel<_Float16><<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream>>>(ix->d_f16, n, d, ix->d_dnorm);
         else row_dnorm_kernel<float><<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->d_dnorm);
         MIR_HIP(hipGetLastError());
+        if (ix->layout16) {  // the sieve's per-tile margin (vec_kernels_q16.h, hihi_coeff)
+            MIR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_tilemax), (size_t)ix->n_tiles * 4));
+            ix->hbm_bytes += (size_t)ix->n_tiles * 4;
+            tile_maxnorm_kernel<<<dim3((ix->n_tiles + 255) / 256), dim3(256), 0, stream>>>(ix->d_dnorm, n, ix->n_tiles, ix->d_tilemax,
+                                                                                            reinterpret_cast<unsigned int *>(ix->d_maxnorm) + 4);
+            MIR_HIP(hipGetLastError());
+        }
     }
     return MIR_OK;
 }
@@ -487,14 +499,16 @@ static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g,
     const int ks32 = ix->ksteps / 2;
     const size_t lds = sieve_lds_bytes(ks32);
     const uint32_t n_rows = (uint32_t)ix->n;
+#define MIR_SIEVE_PICK(KS, P)                                                                                          \
+    (qpw > 128 ? (sample ? sieve_q16_kernel<KS, KIND, true, 2, P> : sieve_q16_kernel<KS, KIND, false, 2, P>)           \
+               : (sample ? sieve_q16_kernel<KS, KIND, true, 1, P> : sieve_q16_kernel<KS, KIND, false, 1, P>))
 #define MIR_SIEVE_CASE(KS)                                                                                             \
     case KS: {                                                                                                         \
-        auto kern = qpw > 128 ? (sample ? sieve_q16_kernel<KS, KIND, true, 2> : sieve_q16_kernel<KS, KIND, false, 2>)  \
-                              : (sample ? sieve_q16_kernel<KS, KIND, true, 1> : sieve_q16_kernel<KS, KIND, false, 1>); \
+        auto kern = ix->norms_spread ? MIR_SIEVE_PICK(KS, true) : MIR_SIEVE_PICK(KS, false);                           \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qsplit_g, q_norm_g, q_sq_g, q_err_g, ix->d_maxnorm, n_rows, tile0, n_tiles, \
                                                     nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat,     \
-                                                    (uint32_t)(ks32 * 2 * 64 * (ix->hi_only ? 1 : 2)));               \
+                                                    (uint32_t)(ks32 * 2 * 64 * (ix->hi_only ? 1 : 2)), ix->d_tilemax); \
         break;                                                                                                         \
     }
     switch (ks32) {
@@ -506,6 +520,7 @@ static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g,
             return MIR_ERR_UNSUPPORTED;
     }
 #undef MIR_SIEVE_CASE
+#undef MIR_SIEVE_PICK
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }
@@ -721,6 +736,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             sa.l = sb.sv; sa.q0 = q0; sa.nq = nq; sa.k = k; sa.metric = metric; sa.d = d; sa.nan_guard = guard;
             sa.rel_err = ix->native16 ? (float)kH16RelErr : kHiHiRelErr;
             sa.docs = ix->d_orig; sa.docs16 = ix->d_f16; sa.doc_sq = ix->d_docsq;
+            sa.dnorm = (ix->native16 || !ix->norms_spread) ? nullptr : ix->d_dnorm;
             sa.q = dq; sa.q_sq = sb.q_sq; sa.q_norm = sb.q_norm; sa.max_norm = ix->d_maxnorm;
             sa.q_err = ix->native16 ? nullptr : sb.q_err;
             sa.gthr = reinterpret_cast<unsigned long long *>(gt);
@@ -1120,6 +1136,15 @@ static int32_t create_common(const RowSource &src, int64_t n, int32_t d, int32_t
     if (e != hipSuccess) {
         set_error("index build failed: %s", hipGetErrorString(e));
         return fail(MIR_ERR_HIP);
+    }
+    if (ix->d_tilemax) {  // (the build is complete: two floats of its norm statistics decide the sieve's margin form)
+        float st[8] = {};
+        e = hipMemcpy(st, ix->d_maxnorm, 32, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error("index build failed: %s", hipGetErrorString(e));
+            return fail(MIR_ERR_HIP);
+        }
+        ix->norms_spread = !(st[0] <= 1.0625f * st[4]) || getenv("MIR_SIEVE_PER_TILE") != nullptr;  // (NaN / infinite norms: spread)
     }
     *out = ix;
     return MIR_OK;

@@ -62,6 +62,35 @@ __device__ __forceinline__ float hihi_margin(bool cosine, bool l2, float qn, flo
     return l2 ? 2.0f * m : m;
 }
 
+// The same bound PER ROW, for the metrics that rank in the rows' own units (inner product, squared L2): with r = the index's
+// largest |dx| / |x| (statistics word 3), |dx| <= r |x| for every row, so |x.q - hx.hq| <= |x| (r |q| + (1 + r) |dq| + slop |q|)
+// = |x| * hihi_coeff(): the margin of a row is its norm times a per-query coefficient.  (Round 3 used the index's largest
+// norm and largest residual for every row - DESIGN.md 7 gap 4, ADVICE r3: one long row among unit rows widened every row's
+// margin, the candidate buffers overflowed and whole batches went to the exact pass.)  The sieve's filter takes a TILE's
+// largest norm (one float per 32 rows, riding with the tile's norm column), its select each row's own.
+__device__ __forceinline__ float hihi_coeff(bool l2, float qn, float eq, const float *__restrict__ stats) {
+    const float slop = 3.0e-5f;
+    float c = stats[3] * qn + (1.0f + stats[3]) * eq + slop * qn;
+    c *= (1.0f + 2e-5f) * MIR_MARGIN_SCALE;  // (+ the float32 rounding of the norm it multiplies)
+    return l2 ? 2.0f * c : c;
+}
+// one float per tile: the largest row norm of its 32 rows (row_dnorm_kernel's norms), rounded up; min_bits: the smallest of
+// them over the index, as unsigned float bits (norm statistics word 4)
+__global__ __launch_bounds__(256) void tile_maxnorm_kernel(const float *__restrict__ dnorm, int64_t n, uint32_t n_tiles,
+                                                           float *__restrict__ tile_max, unsigned int *__restrict__ min_bits) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    float m = 0.f;
+    for (int r = 0; r < kTileRows; ++r) {
+        const int64_t row = (int64_t)t * kTileRows + r;
+        if (row < n) {
+            const float x = dnorm[row];
+            m = (x > m || x != x) ? x : m;  // (a NaN norm stays: the tile's bound becomes NaN and everything in it passes)
+        }
+    }
+    tile_max[t] = m * (1.0f + 1e-6f);
+    if (m == m) atomicMin(min_bits, __float_as_uint(m));  // (non-negative floats order as their bits)
+}
 // f32 [n][d] row-major -> layout16.  One thread per (tile, block of a half, lane); ks32*32 >= d; columns past d and
 // rows past n are 0.
 // hi_only: a tile is its nb hi blocks alone (shards only the sieve scans), else nb hi blocks followed by nb lo blocks.

@@ -60,12 +60,14 @@ constexpr int kSieveSelectCap = 4096;  // of which at most this many may need th
 constexpr int kSieveMaxK = 64;
 constexpr int kSieveCountStride = 32;  // a query's append counter has a 128-byte line of its own (43K appends on 4 shared lines took 120 us)
 
-__host__ __device__ constexpr size_t sieve_lds_bytes(int ks32) { return (size_t)kSieveStages * (ks32 * 2 * 1024 + kTileRows * 4) + 64; }
+constexpr int kSieveAuxStride = kTileRows + 8;  // floats per stage: the tile's 32 norms + its largest row norm (+ padding; the IP form keeps a copy per wave)
+__host__ __device__ constexpr size_t sieve_lds_bytes(int ks32) { return (size_t)kSieveStages * (ks32 * 2 * 1024 + kSieveAuxStride * 4) + 64; }
 
 // QT = query tiles (16 queries each) per wave: 1 -> 128 queries per launch; 2 -> 256: every 1-KiB document fragment read from
 // LDS feeds BOTH tiles' MFMAs (the stream and the LDS traffic of a pass are the same, the matrix work doubles: at 128 queries
 // the matrix pipe is half idle behind the HBM stream).
-template <int KS32, int KIND, bool SAMPLE, int QT>
+// PTMT: margins per tile (the host's choice per index: its norms are spread, mir_index::norms_spread) instead of one per query.
+template <int KS32, int KIND, bool SAMPLE, int QT, bool PTMT>
 __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
                                                            const uint4 *__restrict__ qsplit, const double *__restrict__ q_norm,
                                                            const double *__restrict__ q_sq, const double *__restrict__ q_err,
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
                                                            const uint64_t *__restrict__ gthr, uint64_t *__restrict__ cand,
                                                            float *__restrict__ candv, uint32_t *__restrict__ ccount,
                                                            float *__restrict__ part_sample, unsigned long long *__restrict__ stat,
-                                                           uint32_t tile_u4) {  // uint4s from one tile's hi blocks to the next tile's
+                                                           uint32_t tile_u4,    // uint4s from one tile's hi blocks to the next tile's
+                                                           const float *__restrict__ tile_max) {  // [tiles] largest row norm (IP, L2: per-tile margin)
     static_assert(QT == 1 || QT == 2, "query tiles per wave");
     constexpr int NS = kSieveStages;
     constexpr int SB = KS32 * 2;          // 1-KiB blocks per stage = a tile's hi blocks
@@ -82,14 +85,16 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     // (tile_u4: STAGE_U4 on a hi-only image, 2 * STAGE_U4 where a tile's lo blocks follow its hi blocks - never read here)
     constexpr int PPW = SB / 8;           // 1-KiB DMA pieces per wave per stage
     constexpr bool AUX = KIND != SCAN_IP; // the tile's 32 norms travel with it: 16 bytes per wave, one more DMA
-    constexpr int PW = PPW + (AUX ? 1 : 0);  // vector-memory operations per wave per stage
+    constexpr bool PTM = PTMT && KIND != SCAN_COS;  // per-tile margin: the tile's largest row norm travels too (cosine's margin is relative already)
+    constexpr int PW = PPW + ((AUX || PTM) ? 1 : 0);  // vector-memory operations per wave per stage
+    constexpr int AS = kSieveAuxStride;
     constexpr int D = NS - 1;             // stages in flight: stage g's slot is free again once stage g has been read
     constexpr int QPL = 128 * QT;         // queries per launch
     static_assert(SB % 8 == 0, "sieve: d padded to a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *ring = reinterpret_cast<uint4 *>(smem);                                  // [NS][STAGE_U4]
     float *aux_lds = reinterpret_cast<float *>(smem + (size_t)NS * STAGE_U4 * 16);   // [NS][32]
-    uint32_t *s_count = reinterpret_cast<uint32_t *>(aux_lds + NS * kTileRows);
+    uint32_t *s_count = reinterpret_cast<uint32_t *>(aux_lds + NS * AS);
 
     const int tid = threadIdx.x, lane = tid & 63, qc = lane & 15, jg = lane >> 4;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,10 +107,12 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     bool lane_live[QT];
     unsigned long long live_mask[QT];
     float mg[QT], bound[QT], guard[QT], best[QT];
+    float cq[QT], tb[QT];  // PTM: the margin's per-query coefficient (x a tile's largest norm = mg) and the threshold with its rounding slack
     bf16x8 qh[QT][KS32];
     const bool active = nq > wave8 * QT * 16;  // (the wave's first tile has queries)
     // (word 1 of the index's norm statistics: a row with a NaN or an infinity was seen at build time)
     const bool finite_rows = __builtin_amdgcn_readfirstlane(__float_as_uint(max_norm[1])) == 0u;
+    constexpr bool ptm = PTM;
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         const int t16 = wave8 * QT + u;
@@ -113,15 +120,18 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         lane_live[u] = qloc[u] < nq;
         live_mask[u] = __builtin_amdgcn_ballot_w64(lane_live[u]);
         mg[u] = 0.f; bound[u] = -__builtin_inff(); guard[u] = __builtin_inff(); best[u] = -__builtin_inff();
+        cq[u] = 0.f; tb[u] = -__builtin_inff();
         if (lane_live[u]) {
             const float qn = (float)q_norm[qloc[u]] * (1.0f + 1e-6f);
             const float eq = (float)q_err[qloc[u]] * (1.0f + 1e-6f);
             mg[u] = hihi_margin(KIND == SCAN_COS, KIND == SCAN_L2, qn, eq, max_norm);
+            if (PTM) cq[u] = hihi_coeff(KIND == SCAN_L2, qn, eq, max_norm);
             if (!SAMPLE) {
                 const uint64_t key = gthr[qloc[u]];
                 if (key != 0) {
                     const float t = key_value(key);
                     bound[u] = t - mg[u] - 2e-6f * fabsf(t);
+                    tb[u] = t - 2e-6f * fabsf(t);
                 }
             } else if (nan_guard) {
                 // sq = q_sq - v < 0 is NaN under euclidean_dist: rows whose v + mg could reach q_sq do not count as known rows
@@ -142,9 +152,14 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave8 * PPW) * 64) * 16);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
-        if (AUX) {  // lanes 0..3 of wave w bring norms 4w .. 4w + 3 of the tile
-            const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_addr_of(aux_lds) + ((g % NS) * kTileRows + wave8 * 4) * 4);
-            if (lane < 4) glds4_b32(aux + (size_t)tile * kTileRows + wave8 * 4 + lane, adst);
+        if (AUX) {  // lanes 0..3 of wave w bring norms 4w .. 4w + 3 of the tile; lane 4 of the last wave the tile's largest row norm (slot 32)
+            const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_addr_of(aux_lds) + ((g % NS) * AS + wave8 * 4) * 4);
+            const bool tm_lane = PTM && wave8 == 7 && lane == 4;
+            const float *src1 = tm_lane ? tile_max + tile : aux + (size_t)tile * kTileRows + wave8 * 4 + lane;
+            if (lane < 4 || tm_lane) glds4_b32(src1, adst);
+        } else if (PTM) {  // no norm column (inner product): every wave brings its own copy of the tile's largest row norm (slot 4w)
+            const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_addr_of(aux_lds) + ((g % NS) * AS + wave8 * 4) * 4);
+            if (lane == 0) glds4_b32(tile_max + tile, adst);
         }
     };
     // ordinary loads are complete before the first DMA (the counted waits below count DMAs only)
@@ -171,8 +186,11 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     // the next tile's MFMAs (its ~30 vector instructions after a tile's last MFMA were exposed at every barrier).
     // SCAN_L2: a tile's accumulators START at -|x|^2 / 2 (row-wise, the MFMA's C operand), so that c = x.q - |x|^2 / 2 and the
     // ranking value 2 x.q - |x|^2 is 2 c: the filter compares c with half the bound and needs no arithmetic at all.
-    auto filter = [&](int u, const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], uint32_t t) {
+    auto filter = [&](int u, const f32x4 &c0, const f32x4 &c1, const float (&ax)[8], uint32_t t, float tmax) {
         float v[8];
+        // PTM: this tile's bound T - (largest row norm of the tile) x (the query's coefficient); cosine: the launch's constant
+        const float mgt = ptm ? tmax * cq[u] : mg[u];
+        const float bound_t = ptm ? tb[u] - mgt : bound[u];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[i] = KIND == SCAN_COS ? c0[i] * ax[i] : c0[i];
@@ -184,14 +202,14 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const float w = KIND == SCAN_L2 ? 2.0f * v[r] : v[r];
-                    if (w + mg[u] < guard[u]) best[u] = fmaxf(best[u], w - mg[u]);
+                    if (w + mgt < guard[u]) best[u] = fmaxf(best[u], w - mgt);
                 }
             }
             return;
         }
         // one compare per value, their results OR-ed as lane masks (scalar unit): beside the MFMAs every vector instruction
         // of the common path costs matrix-pipe issue slots
-        const float bnd = KIND == SCAN_L2 ? 0.5f * bound[u] : bound[u];
+        const float bnd = KIND == SCAN_L2 ? 0.5f * bound_t : bound_t;
         if (SIEVE_MAX3 && finite_rows) {
             // no row of the index holds a NaN or an infinity (its largest norm is finite): a value is NaN only if the QUERY is,
             // and then all eight are - the maximum of the eight (v_max3: a NaN operand is ignored) decides: four instructions and
@@ -218,8 +236,21 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         }
         uint32_t pm = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound[u])) << r;
+        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound_t)) << r;
         if (!lane_live[u]) pm = 0;
+        if (KIND == SCAN_L2 && ptm && __any(pm != 0)) {
+            // squared L2: the ROW's own margin - its norm is in the tile's norm column - now that something in the tile passed
+            // the tile's bound (the tile's largest norm): a long row widens the band of its 31 neighbours in the common path
+            // only, where that costs nothing.  (The norms go through an asm that depends on the opaque tile index: left
+            // alone, hipcc computes the eight square roots in front of the common path's branch - measured: +24 % per step.)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float a2 = ax[r];
+                asm volatile("" : "+v"(a2) : "s"(t));
+                const float br = tb[u] - __builtin_amdgcn_sqrtf(a2) * cq[u] * (1.0f + 3e-5f);  // (v_sqrt_f32: ~1 ulp, covered by the factor)
+                if (v[r] < br) pm &= ~(1u << r);
+            }
+        }
         if (!__any(pm != 0)) return;
         // rare (a few per cent of the wave-tiles): write the passing (query, row) pairs and their values to this workgroup's region
         const uint32_t row0 = t * kTileRows + 4 * jg;  // this lane's rows: row0 + 16 rh + i
@@ -252,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
 #pragma unroll
     for (int u = 0; u < QT; ++u) { p0[u] = f32x4{0.f, 0.f, 0.f, 0.f}; p1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float pax[8] = {};
+    float p_tmax = 0.f, c_tmax = 0.f;  // the previous / this tile's largest row norm
     uint32_t pt = 0;
     bool have_prev = false;
     for (uint32_t g = 0; g < my_tiles; ++g) {
@@ -271,11 +303,12 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
         for (int i = 0; i < PF; ++i) { f0[i] = st[(2 * i + 0) * 64]; f1[i] = st[(2 * i + 1) * 64]; }
         float cax[8] = {};
         if (AUX) {  // rows 16 rh + 4 jg + i of this tile
-            const float4 a0 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * kTileRows + 4 * jg);
-            const float4 a1 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * kTileRows + 16 + 4 * jg);
+            const float4 a0 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * AS + 4 * jg);
+            const float4 a1 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * AS + 16 + 4 * jg);
             cax[0] = a0.x; cax[1] = a0.y; cax[2] = a0.z; cax[3] = a0.w;
             cax[4] = a1.x; cax[5] = a1.y; cax[6] = a1.z; cax[7] = a1.w;
         }
+        if (ptm) c_tmax = aux_lds[(g % NS) * AS + (AUX ? kTileRows : 4 * wave8)];
         f32x4 c0[QT], c1[QT];
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
@@ -316,21 +349,21 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
                 if (s == 2 + u && have_prev) {  // the previous tile's filter, one query tile per k-step
                     __builtin_amdgcn_sched_barrier(0);
 #if SIEVE_ABL != 4
-                    filter(u, p0[u], p1[u], pax, pt);
+                    filter(u, p0[u], p1[u], pax, pt, p_tmax);
 #else
-                    if (g == 0xffffff) filter(u, p0[u], p1[u], pax, pt);
+                    if (g == 0xffffff) filter(u, p0[u], p1[u], pax, pt, p_tmax);
 #endif
                 }
         }
 #pragma unroll
         for (int u = 0; u < QT; ++u) { p0[u] = c0[u]; p1[u] = c1[u]; }
-        pt = t; have_prev = true;
+        pt = t; have_prev = true; p_tmax = c_tmax;
 #pragma unroll
         for (int i = 0; i < 8; ++i) pax[i] = cax[i];
     }
     if (have_prev) {
 #pragma unroll
-        for (int u = 0; u < QT; ++u) filter(u, p0[u], p1[u], pax, pt);
+        for (int u = 0; u < QT; ++u) filter(u, p0[u], p1[u], pax, pt, p_tmax);
     }
     if (SAMPLE) {
         // four lanes hold a query's column: two values per query, each the maximum over distinct rows
@@ -747,6 +780,7 @@ struct SieveSelectArgs {
     const float *docs;             // f32 [n][d], or null with
     const _Float16 *docs16;        // f16 [n][d] (float16-native index)
     const float *doc_sq;
+    const float *dnorm;            // [n] row norms (row_dnorm_kernel): the per-row margin of inner product / squared L2 on a float32 index, or null
     const double *q, *q_sq, *q_norm;
     const float *max_norm;
     unsigned long long *gthr;      // [nq] of this launch group
@@ -766,7 +800,9 @@ struct SieveSelectArgs {
 };
 
 // grid = nq (one block per query), block = 1024.  Everything up to the last step works on the filter's values alone.
-//   With mg the filter's bound, a listed row's true value lies in [v - mg, v + mg].  kv = the k-th largest v over listed rows
+//   With mg the filter's bound (round 4: PER ROW for inner product / squared L2 on a float32 index - the row's norm times the
+//   query's coefficient, hihi_coeff - otherwise one value per query), a listed row's true value lies in [v - mg, v + mg].
+//   kv = the k-th largest v over listed rows
 //   that are certainly not NaN; then k rows have true values >= kv - mg =: T, so T is a lower bound of the k-th best true value:
 //   mode 0: T is the next launch's threshold (the filter lets v >= T - mg through);
 //   mode 1: a row of the true first k has true value >= T, hence v >= kv - 2 mg: only those (~2-4 k of the few hundred listed)
@@ -845,6 +881,13 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
     const bool l2 = !(a.metric == MIR_METRIC_INNER_PRODUCT || a.metric == MIR_METRIC_COSINE_SIM);
     const float mg = a.q_err ? hihi_margin(a.metric == MIR_METRIC_COSINE_SIM, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm)
                              : a.rel_err * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) * (l2 ? 2.0f : 1.0f);  // (as the filter's)
+    // Per-row margins (float32 index, inner product / squared L2): a row's true value lies within m = |x| * cq of its v (hihi_coeff);
+    // the filter used the row's TILE maximum, which is no smaller.  Everything below is written in LOWER bounds lb = v - m and
+    // UPPER bounds lb + 2 m; with one margin for all rows (cosine, float16-native) that is the round-3 arithmetic in other words.
+    const bool per_row = a.q_err != nullptr && a.dnorm != nullptr && a.metric != MIR_METRIC_COSINE_SIM;  // (dnorm: only where the filter ran per tile)
+    const float cq = per_row ? hihi_coeff(l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) : 0.f;
+    auto margin_of = [&](uint32_t row) { return per_row ? a.dnorm[row] * cq : mg; };
+    const float eps_m = per_row ? 0.f : 1e-6f * mg;  // (per row: the margins carry their own 1e-6; an index-wide mg may be infinite there)
     float guard = __builtin_inff();
     if (a.nan_guard) {
         const float qs = (float)a.q_sq[qi];
@@ -856,38 +899,41 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
         bool safe = false;
         if (e < n) {
             const float v = lv[e];
-            safe = v + mg < guard && v > -__builtin_inff();
-            s_v[e] = safe ? v : -__builtin_inff();
+            const float m = margin_of(lr[e]);
+            safe = v + m < guard && v > -__builtin_inff();
+            s_v[e] = safe ? v - m : -__builtin_inff();  // the row's LOWER bound (a NaN margin - a NaN row norm - is not safe)
         }
         const unsigned long long bal = __ballot(safe);
         if (bal && lane == __builtin_ctzll(bal)) atomicAdd(&s_ns, __popcll(bal));
     }
     __syncthreads();
     const int ns = s_ns;
-    // ---- 1. kv = the k-th largest of the safe values
+    // ---- 1. kv = the k-th largest of the safe rows' lower bounds: k rows have true values >= kv, so kv bounds the k-th best
+    //         true value from below
     const bool have = ns >= a.k;
     const float kv = have ? kth_largest(s_v, n) : 0.f;
     if (a.mode == 0) {
         if (have && tid == 0) {
-            const float thr = kv - mg - 4e-6f * fabsf(kv);
+            const float thr = kv - 4e-6f * fabsf(kv) - eps_m;
             const unsigned long long key = (unsigned long long)orderable(thr) << 32;
             if (thr == thr && key > a.gthr[blockIdx.x]) a.gthr[blockIdx.x] = key;
         }
         if (tid == 0) atomicAdd(a.stats + 4, (unsigned long long)n);  // entries listed after launch 1
         return;
     }
-    // ---- 2. the rows that can be among the first k.  Class 1: v >= kv (at least k of them), the ones that may be NaN, and
-    //         everything when there is no kv - always evaluated.  Class 2: kv - 2 mg <= v < kv - evaluated only if class 1's
-    //         exact values leave them a chance (step 3).  s_fin = class 1, then class 2.
-    const float cut = have ? kv - 2.0f * mg - 1e-5f * fabsf(kv) - 1e-6f * mg : -__builtin_inff();
+    // ---- 2. the rows that can be among the first k.  Class 1: lower bound >= kv (at least k of them), the ones that may be
+    //         NaN, and everything when there is no kv - always evaluated.  Class 2: upper bound >= kv > lower bound - evaluated
+    //         only if class 1's exact values leave them a chance (step 3).  s_fin = class 1, then class 2.
+    const float cut = have ? kv - 1e-5f * fabsf(kv) - eps_m : -__builtin_inff();
     auto compact = [&](int cls, int *counter) {
         for (int e0 = 0; e0 < n; e0 += NT) {
             const int e = e0 + tid;
             bool fin = false;
             if (e < n) {
-                const float v = s_v[e];
-                const bool c1 = !have || !(v > -__builtin_inff()) || !(v < kv);
-                fin = cls == 1 ? c1 : (!c1 && !(v < cut));
+                const float lb = s_v[e];
+                const bool c1 = !have || !(lb > -__builtin_inff()) || !(lb < kv);
+                if (cls == 1) fin = c1;
+                else if (!c1) fin = !(lb + 2.0f * margin_of(lr[e]) * (1.0f + 1e-6f) < cut);
             }
             const unsigned long long bal = __ballot(fin);
             int base = 0;
@@ -956,7 +1002,7 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
         __syncthreads();
         if (s_nn >= a.k) {
             const float rk = kth_largest(s_x, f1);
-            const float need = rk - 4e-6f * fabsf(rk) - 1e-6f * mg - mg;  // (float)rv rounds to nearest: the slack covers it
+            const float need = rk - 4e-6f * fabsf(rk) - eps_m;  // (float)rv rounds to nearest: the slack covers it
             if (tid == 0) s_f = f1;
             __syncthreads();
             // survivors of class 2 move up behind class 1 (in place: a survivor's slot is never beyond its old one)
@@ -968,7 +1014,7 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
                 if (i < f) {
                     e = s_fin[i];
                     er = s_row[i];
-                    keep = !(s_v[e] < need);
+                    keep = !(s_v[e] + 2.0f * margin_of(er) * (1.0f + 1e-6f) < need);  // its UPPER bound reaches the k-th exact value
                 }
                 __syncthreads();
                 const unsigned long long bal = __ballot(keep);

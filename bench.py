@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-sweep", dest="sweep", action="store_false", help="skip the B = 1 / 32 / 64 side measurements")
     ap.add_argument("--c5-rows", type=int, default=6_250_000,
                     help="rows PER GPU of the float16 d=1024 leg (BASELINE config 5: 50M over 8 GPUs); 0 = skip")
+    ap.add_argument("--c2-chunks", type=int, default=0,
+                    help="BASELINE config C2 at its own size: encode this many chunks (1000000) into one block, index and search it; 0 = skip")
     ap.add_argument("--encode-chunks", type=int, default=8192,
                     help="chunks per GPU for the index-build (encoder) leg of the metric; 0 = skip")
     ap.add_argument("--bm25-docs", type=int, default=1_000_000,
@@ -152,6 +154,64 @@ def encoder_leg(np, torch, dist, args, world, rank, local_rank, barrier):
         "unit_norm_outputs": norms_ok,
         "warmup": "one untimed call of the same size (workspaces allocated), then one timed call",
     }
+
+
+def c2_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher):
+    """BASELINE config C2 at its own size (behind --c2-chunks, e.g. 1000000): encode that many synthetic chunks (token ids,
+    length ~N(220, 60)) straight into ONE float32 block in HBM - slabs of 65 536 chunks, only the encoder calls timed - then
+    build the index over the block where it lies and search it: chunks/s quoted on a BASELINE size, and the two halves of
+    the metric meeting in one place."""
+    from aidial_rag_amd.embeddings.embeddings import BgeEncoder
+
+    device = torch.device("cuda", local_rank)
+    n, slab = args.c2_chunks, 65536
+    enc = BgeEncoder.from_state_dict(random_bge_small_state_dict(np), device=local_rank)
+    rng = np.random.default_rng(1999)
+    out = torch.empty((n, 384), dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    warm = [rng.integers(999, 30522, 220).astype(np.int32) for _ in range(4096)]
+    enc.encode_ids_to_device(warm, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dt, tokens, flops = 0.0, 0, 0.0
+    for s0 in range(0, n, slab):
+        m = min(slab, n - s0)
+        lens = np.clip(np.round(rng.normal(220, 60, m)), 8, 512).astype(np.int64)
+        seqs = [rng.integers(999, 30522, L).astype(np.int32) for L in lens]  # (untimed: synthetic input generation)
+        t0 = time.perf_counter()
+        enc.encode_ids_to_device(seqs, out.data_ptr() + s0 * 384 * 4, stream)
+        torch.cuda.synchronize()
+        dt += time.perf_counter() - t0
+        tokens += int(lens.sum())
+        flops += float(sum(12 * (L * (2 * 384 * 1152 + 2 * 384 * 384 + 4 * 384 * 1536) + 4 * L * L * 384) for L in lens))
+    enc.close()
+    t0 = time.perf_counter()
+    index = DeviceIndex.from_device_ptr(out.data_ptr(), n, 384, local_rank, stream=stream)
+    torch.cuda.synchronize()
+    t_index = time.perf_counter() - t0
+    B, k = 256, args.k
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    pick = torch.randint(0, n, (B,), generator=g, device=device)
+    q = out[pick].double()
+    q[1::2] += 0.05 * torch.randn((B // 2, 384), generator=g, dtype=torch.float64, device=device)  # every other query: near its row
+    q = q.contiguous()
+    searcher = ShardedSearcher(local_index=index)
+    for _ in range(5):
+        res = searcher.search(q, k, args.metric)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        res = searcher.search(q, k, args.metric)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rows = res[1].cpu().numpy()
+    found = float((rows[:, :2] == pick.cpu().numpy()[:, None]).any(axis=1).mean())  # (random-weight embeddings crowd together: the row itself or its twin)
+    index.close()
+    return {"workload": f"{n} synthetic chunks (mean {tokens / n:.1f} tokens) -> float32 {n} x 384 in HBM -> index -> {B}-query search, k={k}",
+            "index_build_chunks_per_s": round(n / dt, 1), "encode_s": round(dt, 2),
+            "frac_of_mfma_peak": round(flops / dt / 1e12 / 2500.0, 4), "index_from_rows_s": round(t_index, 3),
+            "search_qps": round(B * 10 / el, 1), "search_ms_per_step": round(1e3 * el / 10, 4),
+            "queries_finding_their_source_row_in_top2": found}
 
 
 def c5_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher):
@@ -1076,6 +1136,8 @@ def main():
 
             with tempfile.TemporaryDirectory() as td:
                 result["index_build"]["through_build_embeddings"] = build_embeddings_leg(np, torch, args, local_rank, td)
+    if args.c2_chunks > 0 and world == 1:
+        result["c2_encode_index_search"] = c2_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher)
     if args.hybrid_docs > 0:
         result["hybrid_c4"] = hybrid_leg(np, torch, dist, args, world, rank, local_rank, barrier, DeviceIndex, ShardedSearcher,
                                          check=(world == 1 and args.cpu_legs))

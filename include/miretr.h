@@ -239,6 +239,11 @@ int32_t mir_keywords_preprocess(const char *texts, const int64_t *offsets, int32
                                 int32_t mode, mir_kwp_result **out);
 int32_t mir_kwp_result_data(const mir_kwp_result *r, const char **bytes, int64_t *n_bytes, const int32_t **counts,
                             const int64_t **byte_ends, int64_t *n_tokens);
+/* The batch's DISTINCT tokens in order of first appearance (each followed by a NUL) and every token as an index into
+ * them: what a vocabulary mapping (bm25_retriever.py:78, rank-bm25's dicts) needs - one lookup per distinct token. */
+int32_t mir_kwp_result_dedupe(mir_kwp_result *r, int32_t n_threads);
+int32_t mir_kwp_result_unique(const mir_kwp_result *r, const char **uniq_bytes, int64_t *n_uniq_bytes, int32_t *n_unique,
+                              const int32_t **ids);
 int32_t mir_kwp_result_free(mir_kwp_result *r);
 
 /* Host utility: term ids written in a vocabulary larger than this corpus (e.g. a process-wide str -> id map

@@ -70,6 +70,28 @@ def test_embeddings_cls_normalised(setup, note):
     np.testing.assert_allclose(raw / np.linalg.norm(raw, axis=1, keepdims=True), got, atol=1e-5)
 
 
+def test_fused_qkv_attention_kernel_is_bit_identical(setup, monkeypatch):
+    """fused_qkv_attention_kernel (Q / K / V kept on the CU for sequences of at most 8 token tiles; off by default - it is not
+    faster) must round exactly like qkv_kernel + attention_kernel: same embeddings, bit for bit, for a mix of
+    short sequences (binned), long ones (the unfused kernels of the same pass) and empty bin slots."""
+    from aidial_rag_amd.embeddings.embeddings import BgeEncoder
+
+    model, enc, seqs, oe = setup
+    rng = np.random.default_rng(17)
+    filler = [rng.integers(999, 30522, int(L)).tolist() for L in rng.integers(1, 513, 120)]  # > 256 tiles: the throughput path
+    want = enc.encode_ids(seqs + filler)
+    monkeypatch.setenv("MIR_ENC_FUSED_QKV_ATTENTION", "1")
+    fused = BgeEncoder.from_state_dict(model.state_dict())
+    try:
+        got = fused.encode_ids(seqs + filler)
+        _, hid_f = fused.debug_hidden(seqs + filler, 2)
+    finally:
+        fused.close()
+    np.testing.assert_array_equal(got, want)
+    _, hid = enc.debug_hidden(seqs + filler, 2)
+    np.testing.assert_array_equal(hid_f, hid)  # (and the debug hidden states come back in input order from either tile order)
+
+
 def test_batching_is_invariant(setup):
     """A sequence's embedding does not depend on what else is in the batch (no cross-sequence leakage, padding
     masked) NOR on which kernels served it: batches of at most 256 token tiles take the latency kernels

@@ -153,6 +153,41 @@ def test_short_queries_against_long_rows_of_equal_norm(ei, metric):
     ix.close()
 
 
+def test_a_few_long_rows_do_not_flood_the_candidates(ei):
+    """Non-normalised shards (multimodal_retriever.py:55-63 allows them): unit rows with 0.1 % rows of norm 10 .. 30.  Round 3's
+    margin used the index's largest norm for every row, so ONE long row widened every row's band, the candidate buffers
+    overflowed and whole batches went to the exact pass (DESIGN.md 7 gap 4).  The margin is per tile in the filter
+    and per row in the select now: all four metrics equal the oracle with flag 0, and the filter lists at most twice the
+    candidates it lists on the same rows without the long ones."""
+    rng = np.random.default_rng(31)
+    d = 384
+    unit_rows = rng.standard_normal((N, d)).astype(np.float32)
+    unit_rows /= np.linalg.norm(unit_rows, axis=1, keepdims=True)
+    docs = unit_rows.copy()
+    long_rows = rng.choice(N, N // 1000, replace=False)
+    docs[long_rows] *= rng.uniform(10.0, 30.0, (len(long_rows), 1)).astype(np.float32)
+    qs = rng.standard_normal((8, d))
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+
+    def listed(ix, metric):
+        ix.scan_stats(reset=True)
+        out = ix.search(qs, 10, metric)
+        st = ix.scan_stats(reset=True)
+        return out, st["candidates_per_query_first_launch"] + st["candidates_per_query_second_launch"], st
+
+    iso = ei.DeviceIndex.from_host(unit_rows)
+    base = {m: listed(iso, m)[1] for m in METRICS}
+    iso.close()
+    ix = ei.DeviceIndex.from_host(docs)
+    for metric in METRICS:
+        out, cand, st = listed(ix, metric)
+        assert int(out[5].sum()) == 0 and st["to_exact_pass"] == 0, f"{metric}: {st}"
+        for i in range(len(qs)):
+            check(metric, qs[i], docs, tuple(o[i] for o in out), 10, f"{metric} q={i}")
+        assert cand <= 2.0 * base[metric] + 64, f"{metric}: {cand:.0f} candidates per query with the long rows, {base[metric]:.0f} without"
+    ix.close()
+
+
 def test_overflowing_buffers_take_the_exact_pass(ei):
     """6 000 bit-identical rows next to the query: more candidates than a query's list holds - the query is flagged and
     the exact pass returns the reference's answer (the lowest rows); the other queries of the batch are untouched.
