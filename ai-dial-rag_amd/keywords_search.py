@@ -224,14 +224,126 @@ def _native_batch(texts: Sequence[str], mode: int, threads: int) -> List[List[st
     return out
 
 
-def keywords_preprocess_batch(texts: Sequence[str], threads: int = 0) -> List[List[str]]:
+class TokenBatch:
+    """The tokens of one native batch, deduplicated: `uniq` = its distinct tokens in order of first appearance (ONE str object
+    each), `ids` = every token as an index into them (int32, all texts back to back), `offsets[i] .. offsets[i + 1]` = text i."""
+
+    __slots__ = ("uniq", "ids", "offsets", "_global", "_lock")
+
+    def __init__(self, uniq: List[str], ids, offsets):
+        import threading
+
+        self.uniq, self.ids, self.offsets = uniq, ids, offsets
+        self._global = None  # (vocabulary object, int32 table uniq index -> its term id): bm25_retriever._doc_token_ids
+        self._lock = threading.Lock()
+
+    def global_ids(self, vocab: dict, lock) -> "np.ndarray":
+        """uniq index -> term id in `vocab` (new tokens get the next ids, in order of first appearance), once per batch."""
+        import numpy as np
+
+        with self._lock:
+            g = self._global
+            if g is None or g[0] is not vocab or len(vocab) < g[2]:  # (a vocabulary that shrank was cleared: tests do)
+                with lock:
+                    for t in self.uniq:  # (ids in order of first appearance, as token-by-token insertion gives them)
+                        if t not in vocab:
+                            vocab[t] = len(vocab)
+                    table = np.fromiter(map(vocab.__getitem__, self.uniq), np.int32, len(self.uniq))
+                self._global = g = (vocab, table, len(vocab))
+            return g[1]
+
+
+class TokenList(Sequence):
+    """One text's `tokenized_text` as a view into its TokenBatch: behaves like the reference's List[str] (len, iteration,
+    indexing, equality with lists, pickling as a plain list) without a str object per token until somebody asks for one -
+    an index build that goes on to the device (BM25Retriever.from_doc_records) never does."""
+
+    __slots__ = ("batch", "a", "b")
+
+    def __init__(self, batch: TokenBatch, a: int, b: int):
+        self.batch, self.a, self.b = batch, a, b
+
+    def __len__(self):
+        return self.b - self.a
+
+    def tolist(self) -> List[str]:
+        u = self.batch.uniq
+        return [u[i] for i in self.batch.ids[self.a : self.b].tolist()]
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self.tolist()[i]
+        n = self.b - self.a
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        return self.batch.uniq[int(self.batch.ids[self.a + i])]
+
+    def __eq__(self, other):
+        if isinstance(other, TokenList):
+            return self.tolist() == other.tolist()
+        return self.tolist() == other
+
+    def __ne__(self, other):
+        return not self == other
+
+    __hash__ = None
+
+    def __repr__(self):
+        return repr(self.tolist())
+
+    def __reduce__(self):  # stored DocumentRecords hold plain lists (document_record.py:42-52)
+        return (list, (self.tolist(),))
+
+
+def _native_batch_lazy(texts: Sequence[str], threads: int) -> List[TokenList]:
+    """keywords_preprocess of a batch as TokenList views: the native call, its dedupe, and ~1 us of Python per text."""
+    import numpy as np
+
+    from . import _native as nat
+
+    n = len(texts)
+    if n == 0:
+        return []
+    blob = "".join(texts).encode("utf-8", "surrogatepass")
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(t) if t.isascii() else len(t.encode("utf-8", "surrogatepass")) for t in texts], out=offsets[1:])
+    assert int(offsets[-1]) == len(blob)
+    res = C.c_void_p()
+    nat.check(nat.lib.mir_keywords_preprocess(blob, offsets.ctypes.data, n, threads, 0, C.byref(res)))
+    try:
+        nat.check(nat.lib.mir_kwp_result_dedupe(res, threads))
+        ptr, nbytes, counts_p, ends_p, ntok = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        nat.check(nat.lib.mir_kwp_result_data(res, C.byref(ptr), C.byref(nbytes), C.byref(counts_p), C.byref(ends_p), C.byref(ntok)))
+        uptr, ubytes, nuniq, ids_p = C.c_void_p(), C.c_int64(), C.c_int32(), C.c_void_p()
+        nat.check(nat.lib.mir_kwp_result_unique(res, C.byref(uptr), C.byref(ubytes), C.byref(nuniq), C.byref(ids_p)))
+        uniq = C.string_at(uptr.value, ubytes.value).decode("utf-8", "surrogatepass").split(_SEP) if ubytes.value else []
+        if uniq:
+            uniq.pop()  # every token is FOLLOWED by a NUL
+        ids = np.ctypeslib.as_array(C.cast(ids_p, C.POINTER(C.c_int32)), shape=(max(ntok.value, 1),))[: ntok.value].copy()
+        counts = np.ctypeslib.as_array(C.cast(counts_p, C.POINTER(C.c_int32)), shape=(n,))
+        tok_off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(counts, out=tok_off[1:])
+    finally:
+        nat.lib.mir_kwp_result_free(res)
+    batch = TokenBatch(uniq, ids, tok_off)
+    o = tok_off.tolist()
+    return [TokenList(batch, o[i], o[i + 1]) for i in range(n)]
+
+
+def keywords_preprocess_batch(texts: Sequence[str], threads: int = 0, lazy: bool = False) -> List[Sequence[str]]:
     """``[keywords_preprocess(t) for t in texts]`` (keywords_search.py:13-18 per chunk, bm25_retriever.py:30-39,112) in ONE
-    native call on all host cores (`threads` <= 0) - csrc/keywords_preprocess.cpp.  With NLTK and its data installed the
-    tokenizer and the stopword list are NLTK's (exact by construction; only the stemmer is native then)."""
+    native call on all host cores (`threads` <= 0) - csrc/keywords_preprocess.cpp.  `lazy`: TokenList views (list-like,
+    no str object per token) instead of lists.  With NLTK and its data installed the tokenizer and the stopword list are
+    NLTK's (exact by construction; only the stemmer is native then)."""
     stop, tokenize = _front_end()
     if FRONT_END == "nltk":
         return [stem_tokens([t for t in tokenize(text) if t not in stop]) for text in texts]
-    return _native_batch(texts, 0, threads)
+    return _native_batch_lazy(texts, threads) if lazy else _native_batch(texts, 0, threads)
 
 
 def word_tokenize_batch(texts: Sequence[str], threads: int = 0) -> List[List[str]]:

@@ -151,7 +151,7 @@ def _build_text_index_chunks(chunks, preprocess: Optional[Callable[[str], List[s
 
     out: List[TextIndexItem] = []
     starts = range(0, len(chunks), _PREPROCESS_BATCH)
-    one = lambda b0: keywords_preprocess_batch([c.text for c in chunks[b0 : b0 + _PREPROCESS_BATCH]])
+    one = lambda b0: keywords_preprocess_batch([c.text for c in chunks[b0 : b0 + _PREPROCESS_BATCH]], lazy=True)
     if len(starts) <= 1:
         batches = map(one, starts)
     else:
@@ -177,12 +177,35 @@ def _doc_token_ids(text_index) -> Tuple[Tuple[np.ndarray, np.ndarray, np.ndarray
     lens = np.fromiter((len(item.tokenized_text) for item in text_index), np.int64, len(text_index))
     ids = np.empty(int(lens.sum()), np.int32)
     pos = 0
-    with _VOCAB_LOCK:
-        look = _VOCAB.setdefault
-        for item in text_index:
-            for t in item.tokenized_text:
+    from ..keywords_search import TokenList
+
+    run = None  # (batch, first token, end token) of consecutive chunks of one native batch: ONE gather for the run
+
+    def flush():
+        nonlocal pos, run
+        if run is not None:
+            bt, a, b = run
+            # the native preprocessor's views: the batch's DISTINCT tokens go through the vocabulary once, the chunks' ids are a gather
+            np.take(bt.global_ids(_VOCAB, _VOCAB_LOCK), bt.ids[a:b], out=ids[pos : pos + (b - a)], mode="clip")  # (int32 table, int32 indexes, int32 out: no casts)
+            pos += b - a
+            run = None
+
+    for item in text_index:
+        toks = item.tokenized_text
+        if isinstance(toks, TokenList):
+            if run is not None and run[0] is toks.batch and run[2] == toks.a:
+                run = (run[0], run[1], toks.b)
+            else:
+                flush()
+                run = (toks.batch, toks.a, toks.b)
+            continue
+        flush()
+        with _VOCAB_LOCK:
+            look = _VOCAB.setdefault
+            for t in toks:
                 ids[pos] = look(t, len(_VOCAB))
                 pos += 1
+    flush()
     return (chunk, lens, ids), chunk.nbytes + lens.nbytes + ids.nbytes
 
 

@@ -673,8 +673,10 @@ def both_builders_leg(np, asyncio, emb, words, rng, n):
             "host_threads": os.cpu_count(), "front_end": ks.front_end_info()["front_end"],
             "python_mirror_one_thread_chunks_per_s": round(1.0 / t_py, 1),
             "native_equals_python_mirror_on_64_chunks": bool(all(a == b.tokenized_text for a, b in zip(ref, items))),
-            "note": "texts in -> TextIndexItem.tokenized_text (List[str]) out; mir_keywords_preprocess on all host cores, "
-                    "two batches in flight; what is left on one Python thread is a str object per token",
+            "note": "texts in -> TextIndexItem.tokenized_text out (TokenList views: list-like, a str object per DISTINCT token of a "
+                    "4096-chunk batch, none per token); mir_keywords_preprocess + mir_kwp_result_dedupe on at most 16 host threads, "
+                    "two batches in flight; `together` = asyncio.gather of both builders (documents.py:188-198), bounded by "
+                    "build_embeddings and the interpreter lock its 32 threads share with this one",
             "ok": bool(len(items) == n and len(embs) == n and len(it2) == n and len(em2) == n)}
 
 

@@ -87,6 +87,52 @@ def test_native_chain_equals_the_python_mirror_on_adversarial_strings():
         assert gk == ks.stem_tokens([x for x in ks._word_tokenize_restated(t) if x not in ks.ENGLISH_STOPWORDS]), repr(t)
 
 
+def test_lazy_token_lists_behave_like_the_lists_and_map_through_the_vocabulary(pairs):
+    """`BM25Retriever.build_index` hands out TokenList views (no str object per token): list-like for every reader of
+    `tokenized_text`, pickled as plain lists, and mapped to term ids batch-wise - the same ids, in the same first-seen order,
+    as token-by-token insertion gives (bm25_retriever.py:78 builds its dicts in that order)."""
+    import asyncio
+    import pickle
+
+    import numpy as np
+
+    from aidial_rag_amd.retrievers import bm25_retriever as br
+
+    class Chunk:
+        def __init__(self, t):
+            self.text = t
+
+    texts = [s for s, _ in pairs[:6000]] + ["", "   "]
+    eager = ks.keywords_preprocess_batch(texts)
+    items = asyncio.run(br.BM25Retriever.build_index([Chunk(t) for t in texts]))
+    assert [i.chunk_index for i in items] == list(range(len(texts)))
+    if ks.FRONT_END != "restated":
+        pytest.skip("NLTK data present: lists, not views")
+    for it, want in zip(items, eager):
+        tl = it.tokenized_text
+        assert isinstance(tl, ks.TokenList) and len(tl) == len(want) and tl == want and list(tl) == want
+        if want:
+            assert tl[0] == want[0] and tl[-1] == want[-1] and tl[1:3] == want[1:3]
+    assert pickle.loads(pickle.dumps(items[5].tokenized_text)) == eager[5] and type(pickle.loads(pickle.dumps(items[5].tokenized_text))) is list
+    assert br.BM25Retriever.has_index([type("D", (), {"text_index": items})()])
+
+    class Item:
+        def __init__(self, i, t):
+            self.chunk_index, self.tokenized_text = i, t
+
+    saved = dict(br._VOCAB)
+    try:
+        br._VOCAB.clear()
+        (_, lens_e, ids_e), _ = br._doc_token_ids([Item(i, t) for i, t in enumerate(eager)])
+        br._VOCAB.clear()
+        (_, lens_l, ids_l), _ = br._doc_token_ids(items)
+        np.testing.assert_array_equal(lens_l, lens_e)
+        np.testing.assert_array_equal(ids_l, ids_e)
+    finally:
+        br._VOCAB.clear()
+        br._VOCAB.update(saved)
+
+
 def test_thread_count_does_not_change_the_result(pairs):
     texts = [s for s, _ in pairs[:3000]]
     one = ks.keywords_preprocess_batch(texts, threads=1)
