@@ -96,6 +96,9 @@ struct mir_index {
     bool native16 = false;       // float16 storage scanned as 2-byte fragments (vec_kernels_f16.h)
     bool layout16 = false;       // float32, d padded to 128 / 256 / 384: the 16x16x32 image of vec_kernels_q16.h
     bool hi_only = false;        // layout16 shard that only the sieve ever scans (>= 32K rows): the image holds the bf16 hi blocks alone
+    bool wide16 = false;         // float32, 384 < d <= 1024, >= 32K rows: `d_hi16` = the bf16 hi parts in the float16-native image's layout,
+    int ks16 = 0;                //   ks16 blocks of 1 KiB per tile (d padded to 512 / 1024); the sieve's BF filter scans it, nothing reads d_split
+    uint4 *d_hi16 = nullptr;
     uint4 *d_split = nullptr;    // bf16 hi/lo fragments, or the float16 fragments of a native16 index
     float *d_docsq = nullptr;    // padded to n_tiles*32
     float *d_invnorm = nullptr;  // padded to n_tiles*32
@@ -155,6 +158,7 @@ static void free_index(mir_index *ix) {
     (void)hipFree(ix->d_invnorm);
     (void)hipFree(ix->d_dnorm);
     (void)hipFree(ix->d_tilemax);
+    (void)hipFree(ix->d_hi16);
     (void)hipFree(ix->d_maxnorm);
     (void)hipFree(ix->d_stats);
     (void)hipFree(ix->d_chunk);
@@ -193,7 +197,12 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
     // hi blocks follow the previous tile's directly, so the filter's stream is contiguous.  (MIR_NO_SIEVE - the A/B switch back to
     // round 2's scan, which does read lo blocks - is read at build time too.)
     ix->hi_only = ix->layout16 && ix->n_tiles >= 4u * kSampleWgs && getenv("MIR_NO_SIEVE") == nullptr;
-    const size_t split_bytes = (size_t)ix->n_tiles * ix->ksteps * ((ix->native16 || ix->hi_only) ? 1024 : 2048);
+    // wide float32 shards of >= 32K rows: the sieve's bf16 filter over a hi-only image of its own (round 4); the hi/lo split image
+    // of the K-split list scan is then never read (k <= 64 -> sieve, beyond -> the exact pass) and is not built
+    ix->wide16 = !ix->native16 && !ix->layout16 && (ix->ksteps == 32 || ix->ksteps == 48 || ix->ksteps == 64) &&
+                 ix->n_tiles >= 4u * kSampleWgs && getenv("MIR_NO_SIEVE") == nullptr && getenv("MIR_NO_SIEVE_WIDE") == nullptr;
+    ix->ks16 = ix->wide16 ? (d + 511) / 512 * 32 : 0;
+    const size_t split_bytes = ix->wide16 ? 16 : (size_t)ix->n_tiles * ix->ksteps * ((ix->native16 || ix->hi_only) ? 1024 : 2048);
     const size_t aux_bytes = (size_t)ix->n_tiles * kTileRows * sizeof(float);
     MIR_HIP(hipMalloc(&ix->d_split, std::max<size_t>(split_bytes, 16)));
     MIR_HIP(hipMalloc(&ix->d_docsq, std::max<size_t>(aux_bytes, 16)));
@@ -220,6 +229,13 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
             const int64_t lanes16 = total_lanes;  // tiles x (ks32 * 2) blocks x 64 lanes; one thread writes a hi and a lo block
             pack_split16_f32_kernel<<<dim3((unsigned)((lanes16 + 255) / 256)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ksteps / 2,
                                                                                                    lanes16, ix->d_split, ix->hi_only);
+            MIR_HIP(hipGetLastError());
+            launch_row_norms(ix->d_orig, n, d, ix, stream);
+        } else if (ix->wide16) {
+            const int64_t lanes = (int64_t)ix->n_tiles * ix->ks16 * 64;
+            MIR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_hi16), (size_t)ix->n_tiles * ix->ks16 * 1024));
+            ix->hbm_bytes += (size_t)ix->n_tiles * ix->ks16 * 1024;
+            pack_hi16_f32_kernel<<<dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ks16 / 2, lanes, ix->d_hi16);
             MIR_HIP(hipGetLastError());
             launch_row_norms(ix->d_orig, n, d, ix, stream);
         } else {
@@ -318,7 +334,7 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     const int ngroups = pl.ngroups, nwg = pl.nwg, klist = pl.klist, qpw = pl.qpw;
     Carver c{base};
     sb.q = host_api ? c.take<double>((size_t)b * d) : nullptr;
-    sb.qsplit = c.take<uint4>((size_t)ngroups * (qpw / 32) * ksteps * 128);
+    sb.qsplit = c.take<uint4>((size_t)ngroups * (qpw / 32) * ksteps * 128);  // (ksteps: the caller passes a wide16 index's ks16 when that is larger)
     sb.q_sq = c.take<double>(b);
     sb.q_err = c.take<double>(b);
     sb.q_norm = c.take<double>(b);
@@ -526,24 +542,28 @@ static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g,
 }
 
 // the float16-native sieve's filter launch (vec_kernels_sieve.h, sieve_h16_kernel)
-template <int KIND>
+// BF: the bf16 hi image of a wide float32 shard (ix->d_hi16, ix->ks16), the query fragments of prep_queries16_kernel, `q_err_g`
+template <int KIND, bool BF = false>
 static int32_t launch_sieve16(const mir_index *ix, const uint4 *qfrag_g, const float *qscale_g, const double *q_norm_g, const double *q_sq_g,
                               int nq, int nwg, uint32_t tile0, uint32_t n_tiles, int nan_guard, const uint64_t *gthr_g, uint64_t *cand,
-                              float *candv, uint32_t *ccount, float *part_sample, bool sample, unsigned long long *stat, hipStream_t stream) {
+                              float *candv, uint32_t *ccount, float *part_sample, bool sample, unsigned long long *stat, hipStream_t stream,
+                              const double *q_err_g = nullptr) {
     const float *aux = KIND == SCAN_L2 ? ix->d_docsq : KIND == SCAN_COS ? ix->d_invnorm : nullptr;
     const size_t lds = sieve16_lds_bytes();
     const uint32_t n_rows = (uint32_t)ix->n;
+    const uint4 *image = BF ? ix->d_hi16 : ix->d_split;
+    const int ks = BF ? ix->ks16 : ix->ksteps;
 #define MIR_SIEVE16_CASE(KS)                                                                                           \
     do {                                                                                                               \
-        auto kern = sample ? sieve_h16_kernel<KS, KIND, true> : sieve_h16_kernel<KS, KIND, false>;                     \
+        auto kern = sample ? sieve_h16_kernel<KS, KIND, true, BF> : sieve_h16_kernel<KS, KIND, false, BF>;             \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_split, aux, qfrag_g, qscale_g, q_norm_g, q_sq_g, ix->d_maxnorm, n_rows, tile0, \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(image, aux, qfrag_g, qscale_g, q_norm_g, q_sq_g, q_err_g, ix->d_maxnorm, n_rows, tile0, \
                                                     n_tiles, nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat); \
     } while (0)
-    if (ix->ksteps == 64) MIR_SIEVE16_CASE(32);
-    else if (ix->ksteps == 32) MIR_SIEVE16_CASE(16);
+    if (ks == 64) MIR_SIEVE16_CASE(32);
+    else if (ks == 32) MIR_SIEVE16_CASE(16);
     else {
-        set_error("internal: the float16 sieve has no instance for %d k-steps", ix->ksteps);
+        set_error("internal: the float16 sieve has no instance for %d k-steps", ks);
         return MIR_ERR_UNSUPPORTED;
     }
 #undef MIR_SIEVE16_CASE
@@ -679,6 +699,10 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (qpw / 16);
         prep_queries16_kernel<<<dim3(std::max(ntiles16 * ks32 + b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(
             dq, b, d, ks32, ntiles16, sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords, sb.q_err);
+    } else if (ix->wide16 && pl.sieve) {  // bf16 hi (and lo, unread) fragments of 16 queries x 32 columns, |q - bf16(q)|
+        const int ks32 = ix->ks16 / 2, ntiles16 = ngroups * (kQ16Queries / 16);
+        prep_queries16_kernel<<<dim3(std::max(ntiles16 * ks32 + b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(
+            dq, b, d, ks32, ntiles16, sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords, sb.q_err);
     } else if (ix->native16) {
         const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (kQ16Queries / 16);
         query_stats_h16_kernel<<<dim3(std::max(b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(dq, b, d, sb.q_sq, sb.q_norm, sb.qscale, gz, gwords);
@@ -726,6 +750,12 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                     if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve16<SCAN_COS>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
                     return launch_sieve16<SCAN_L2>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
                 }
+                if (ix->wide16) {  // (fragments of group g: 8 query tiles x ks16 / 2 k-steps x (hi, lo) blocks)
+                    const uint4 *qw = sb.qsplit + (size_t)g * (kQ16Queries / 16) * (ix->ks16 / 2) * 128;
+                    if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve16<SCAN_IP, true>(ix, qw, nullptr, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream, qerr);
+                    if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve16<SCAN_COS, true>(ix, qw, nullptr, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream, qerr);
+                    return launch_sieve16<SCAN_L2, true>(ix, qw, nullptr, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream, qerr);
+                }
                 if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve<SCAN_IP>(ix, qpw, qs, qn, qsq, qerr, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
                 if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve<SCAN_COS>(ix, qpw, qs, qn, qsq, qerr, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
                 return launch_sieve<SCAN_L2>(ix, qpw, qs, qn, qsq, qerr, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
@@ -735,6 +765,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             SieveSelectArgs sa;
             sa.l = sb.sv; sa.q0 = q0; sa.nq = nq; sa.k = k; sa.metric = metric; sa.d = d; sa.nan_guard = guard;
             sa.rel_err = ix->native16 ? (float)kH16RelErr : kHiHiRelErr;
+            sa.extra_slop = ix->wide16 ? wide_accum_slop(ix->ks16 * 16) : 0.f;
             sa.docs = ix->d_orig; sa.docs16 = ix->d_f16; sa.doc_sq = ix->d_docsq;
             sa.dnorm = (ix->native16 || !ix->norms_spread) ? nullptr : ix->d_dnorm;
             sa.q = dq; sa.q_sq = sb.q_sq; sa.q_norm = sb.q_norm; sa.max_norm = ix->d_maxnorm;
@@ -878,7 +909,7 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
     // lists hold (LDS), an index that could actually return that many rows is searched by the exact pass alone.
     static const bool sieve_off = getenv("MIR_NO_SIEVE") != nullptr;  // (A/B measurements against the round-2 scan)
     static const bool sieve16_off = getenv("MIR_NO_SIEVE16") != nullptr;
-    if (((ix->layout16 && !sieve_off) || (ix->native16 && !sieve16_off && !sieve_off)) && k <= kSieveMaxK) {
+    if (((ix->layout16 && !sieve_off) || (ix->native16 && !sieve16_off && !sieve_off) || ix->wide16) && k <= kSieveMaxK) {
         // large shards (the progressive scan's: >= 64 tiles per workgroup): filter on the hi blocks alone, verify every candidate
         const int wgs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ix->num_cus, 1024), (int64_t)ix->n_tiles));
         if (ix->n_tiles >= 4u * kSampleWgs) {  // from 32K rows: there is a sample to take the first threshold from
@@ -1344,11 +1375,11 @@ int32_t mir_index_search_device(mir_index *idx, const double *queries_device, in
     rc = plan(idx, b, k, &pl);
     if (rc != MIR_OK) return rc;
     SearchBuffers sb;
-    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, pl, false);
+    const size_t need = carve(sb, nullptr, b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, false);
     Workspace *w = nullptr;
     rc = acquire_ws(idx, stream, need, &w);
     if (rc != MIR_OK) return rc;
-    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, pl, false);
+    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, false);
     rc = enqueue_search(idx, queries_device, b, k, metric, sb, pl, out_doc, out_chunk, out_row,
                         out_dist, out_count, out_flags, stream);
     release_ws(idx, w, stream, true);
@@ -1367,11 +1398,11 @@ int32_t mir_index_search(mir_index *idx, const double *queries_host, int32_t b, 
     rc = plan(idx, b, k, &pl);
     if (rc != MIR_OK) return rc;
     SearchBuffers sb;
-    const size_t need = carve(sb, nullptr, b, k, idx->d, idx->ksteps, pl, true);
+    const size_t need = carve(sb, nullptr, b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, true);
     Workspace *w = nullptr;
     rc = acquire_ws(idx, nullptr, need, &w);
     if (rc != MIR_OK) return rc;
-    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, idx->ksteps, pl, true);
+    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, true);
     hipStream_t s = w->stream;
     auto bail = [&](int32_t code) {
         (void)hipStreamSynchronize(s);

@@ -59,6 +59,28 @@ __host__ __device__ constexpr size_t h16_lds_bytes(int klist) {
 
 // f16 [n][d] row-major -> the image above.  One thread per (tile, block, lane); ks32 * 32 >= d; columns past d and rows
 // past n are 0.
+// The same image of a FLOAT32 matrix's bf16 hi parts (wide float32 shards: the sieve's filter, vec_kernels_sieve.h)
+__global__ __launch_bounds__(256) void pack_hi16_f32_kernel(const float *__restrict__ src, int64_t n, int d, int ks32,
+                                                            int64_t total_lanes, uint4 *__restrict__ dst) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_lanes) return;
+    const int lane = (int)(gid & 63);
+    const int64_t blk = gid >> 6;
+    const int nb = ks32 * 2;
+    const int b = (int)(blk % nb);
+    const int64_t tile = blk / nb;
+    const int s = b >> 1, rh = b & 1;
+    const int64_t row = tile * kTileRows + 16 * rh + (lane & 15);
+    const int col0 = 32 * s + 8 * (lane >> 4);
+    uint32_t hi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint32_t lo;
+        split_bf16((row < n && col0 + j < d) ? src[row * (int64_t)d + col0 + j] : 0.f, hi[j], lo);
+    }
+    dst[blk * 64 + lane] = pack8(hi);
+}
+
 __global__ __launch_bounds__(256) void pack_f16_16_kernel(const _Float16 *__restrict__ src, int64_t n, int d, int ks32,
                                                           int64_t total_lanes, uint4 *__restrict__ dst) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;

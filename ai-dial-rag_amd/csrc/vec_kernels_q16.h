@@ -62,6 +62,10 @@ __device__ __forceinline__ float hihi_margin(bool cosine, bool l2, float qn, flo
     return l2 ? 2.0f * m : m;
 }
 
+// hihi_margin's slop covers the float32 accumulation of <= 384 products; the wide float32 sieve (d <= 1024) adds the rest:
+// d 2^-24 of |x||q| (each of the d partial sums rounds once, relative 2^-24, and is at most |x||q|), with a little room
+__host__ __device__ inline float wide_accum_slop(int d_pad) { return 1.1f * (float)d_pad * 5.9604645e-8f; }
+
 // The same bound PER ROW, for the metrics that rank in the rows' own units (inner product, squared L2): with r = the index's
 // largest |dx| / |x| (statistics word 3), |dx| <= r |x| for every row, so |x.q - hx.hq| <= |x| (r |q| + (1 + r) |dq| + slop |q|)
 // = |x| * hihi_coeff(): the margin of a row is its norm times a per-query coefficient.  (Round 3 used the index's largest

@@ -392,10 +392,16 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
 constexpr int kSieve16Stages = 4;
 __host__ __device__ constexpr size_t sieve16_lds_bytes() { return (size_t)kSieve16Stages * (kH16StageKs * 2048 + kTileRows * 4) + 64; }
 
-template <int KS32, int KIND, bool SAMPLE>
+// BF (round 4): the same kernel over the bf16 HI image of a wide FLOAT32 shard (384 < d <= 1024: the multimodal / description
+// retrievers' page embeddings, embeddings_index.py:139-153) - bf16 products, the query's bf16 hi fragments as
+// prep_queries16_kernel writes them (hi and lo blocks alternate: `qfrag` is read with a stride of two blocks), no query scale,
+// and sieve_q16_kernel's margin (hihi_margin with the query's own residual `q_err`, plus d 2^-24 for the longer float32
+// accumulation).  Until round 4 those shards streamed hi AND lo blocks through scan_topk_f16_kernel<SPLIT>: twice the bytes.
+template <int KS32, int KIND, bool SAMPLE, bool BF = false>
 __global__ __launch_bounds__(512, 2) void sieve_h16_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
                                                            const uint4 *__restrict__ qfrag, const float *__restrict__ qscale_inv,
                                                            const double *__restrict__ q_norm, const double *__restrict__ q_sq,
+                                                           const double *__restrict__ q_err,
                                                            const float *__restrict__ max_norm, uint32_t n_rows, uint32_t tile0,
                                                            uint32_t n_tiles, int nq, int nan_guard, const uint64_t *__restrict__ gthr,
                                                            uint64_t *__restrict__ cand, float *__restrict__ candv,
@@ -426,9 +432,11 @@ __global__ __launch_bounds__(512, 2) void sieve_h16_kernel(const uint4 *__restri
 
     float mg = 0.f, bound = -__builtin_inff(), guard = __builtin_inff(), best = -__builtin_inff(), inv_s = 0.f;
     if (lane_live) {
-        inv_s = qscale_inv[qloc];
+        inv_s = BF ? 1.0f : qscale_inv[qloc];
         const float qn = (float)q_norm[qloc] * (1.0f + 1e-6f);
-        mg = (float)kH16RelErr * qn * (KIND == SCAN_COS ? 1.0f : max_norm[0]) * (KIND == SCAN_L2 ? 2.0f : 1.0f);
+        if (BF) mg = hihi_margin(KIND == SCAN_COS, KIND == SCAN_L2, qn, (float)q_err[qloc] * (1.0f + 1e-6f), max_norm) +
+                     wide_accum_slop(KS32 * 32) * qn * (KIND == SCAN_COS ? 1.0f : max_norm[0]) * (KIND == SCAN_L2 ? 2.0f : 1.0f);
+        else mg = (float)kH16RelErr * qn * (KIND == SCAN_COS ? 1.0f : max_norm[0]) * (KIND == SCAN_L2 ? 2.0f : 1.0f);
         if (!SAMPLE) {
             const uint64_t key = gthr[qloc];
             if (key != 0) {
@@ -440,11 +448,12 @@ __global__ __launch_bounds__(512, 2) void sieve_h16_kernel(const uint4 *__restri
             guard = qs - 1e-5f * fabsf(qs);
         }
     }
-    f16x8 qh[KS32];
+    uint4 qh[KS32];  // f16x8 or bf16x8 fragments, by BF
     {
-        const uint4 *qs = qfrag + (size_t)wave8 * KS32 * 64 + lane;
+        constexpr int QB = BF ? 2 : 1;  // blocks per k-step in `qfrag`
+        const uint4 *qs = qfrag + (size_t)wave8 * KS32 * QB * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < KS32; ++s) qh[s] = __builtin_bit_cast(f16x8, qs[s * 64]);
+        for (int s = 0; s < KS32; ++s) qh[s] = qs[s * QB * 64];
     }
     const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + G - 1) / G : 0;
     const uint32_t NG = my_tiles * SPT;
@@ -461,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void sieve_h16_kernel(const uint4 *__restri
         }
     };
 #pragma unroll
-    for (int s = 0; s < KS32; ++s) asm volatile("" : "+v"(qh[s]));
+    for (int s = 0; s < KS32; ++s) asm volatile("" : "+v"(qh[s].x), "+v"(qh[s].y), "+v"(qh[s].z), "+v"(qh[s].w));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t g = 0; g < (uint32_t)D && g < NG; ++g) issue(g);
     auto wait_stage = [&](uint32_t g) {
@@ -554,8 +563,13 @@ __global__ __launch_bounds__(512, 2) void sieve_h16_kernel(const uint4 *__restri
                     f1[(s + 2) % 3] = st[(2 * (s + 2) + 1) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f0[s % 3]), qh[j * kH16StageKs + s], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f1[s % 3]), qh[j * kH16StageKs + s], c1, 0, 0, 0);
+                if (BF) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0[s % 3]), __builtin_bit_cast(bf16x8, qh[j * kH16StageKs + s]), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1[s % 3]), __builtin_bit_cast(bf16x8, qh[j * kH16StageKs + s]), c1, 0, 0, 0);
+                } else {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f0[s % 3]), __builtin_bit_cast(f16x8, qh[j * kH16StageKs + s]), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f1[s % 3]), __builtin_bit_cast(f16x8, qh[j * kH16StageKs + s]), c1, 0, 0, 0);
+                }
                 if (s == 1) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (g + D < NG) issue(g + D);
@@ -776,6 +790,7 @@ struct SieveSelectArgs {
     int q0, nq, k, metric, mode;   // mode 0: thresholds for the next launch; 1: the result
     int d, nan_guard;
     float rel_err;                 // the float16 filter's bound (kH16RelErr); a float32 index: the margin of hihi_margin()
+    float extra_slop;              // wide float32 shards (d > 384): the longer float32 accumulation's share of the margin, relative (wide_accum_slop)
     const double *q_err;           // [b] |q - bf16(q)| (float32 index), or null
     const float *docs;             // f32 [n][d], or null with
     const _Float16 *docs16;        // f16 [n][d] (float16-native index)
@@ -879,7 +894,8 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
     };
     const float qn = (float)a.q_norm[qi] * (1.0f + 1e-6f);
     const bool l2 = !(a.metric == MIR_METRIC_INNER_PRODUCT || a.metric == MIR_METRIC_COSINE_SIM);
-    const float mg = a.q_err ? hihi_margin(a.metric == MIR_METRIC_COSINE_SIM, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm)
+    const float mg = a.q_err ? hihi_margin(a.metric == MIR_METRIC_COSINE_SIM, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) +
+                                   a.extra_slop * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) * (l2 ? 2.0f : 1.0f)
                              : a.rel_err * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) * (l2 ? 2.0f : 1.0f);  // (as the filter's)
     // Per-row margins (float32 index, inner product / squared L2): a row's true value lies within m = |x| * cq of its v (hihi_coeff);
     // the filter used the row's TILE maximum, which is no smaller.  Everything below is written in LOWER bounds lb = v - m and

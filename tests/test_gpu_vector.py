@@ -660,15 +660,16 @@ def test_full_size_c5_float16_properties(amd):
     np.testing.assert_array_equal(od, dist)
 
 
+@pytest.mark.parametrize("n", [40_003, 20_011])
 @pytest.mark.parametrize("metric,d", [(m, 1024) for m in METRICS] + [("sqeuclidean_dist", 768), ("cosine_sim", 520), ("inner_product", 400)])
-def test_float32_wide_dims_k_split_scan(amd, metric, d):
+def test_float32_wide_dims_k_split_scan(amd, metric, d, n):
     """float32 rows with 384 < d <= 1024 (multimodal / description page embeddings are stored as float32,
-    embeddings_index.py:139-153 upstream): the 64-query K-split scan over the bf16 hi/lo image (d padded to 512 / 768 /
-    1024 columns), with the threshold pre-pass (>= 32K rows), a ragged last tile, duplicates, batches of 1 / 64 / 100."""
+    embeddings_index.py:139-153 upstream), a ragged last tile, duplicates, batches of 1 / 64 / 100.  40 003 rows (>= 32K): the
+    sieve's bf16 filter over the hi-only image (round 4: sieve_h16_kernel<BF>, d padded to 512 / 1024) - every query answered
+    with flag 0; 20 011 rows: the 64-query K-split list scan over the bf16 hi/lo image (d padded to 512 / 768 / 1024)."""
     from oracle import embeddings_index as oi
 
     rng = np.random.default_rng(1000 + d)
-    n = 40_003
     docs = (rng.standard_normal((n, d)) * rng.uniform(0.3, 2.0, (n, 1))).astype(np.float32)
     if metric in ("cosine_sim", "inner_product"):
         docs = unit(docs)
@@ -676,15 +677,19 @@ def test_float32_wide_dims_k_split_scan(amd, metric, d):
     qs = rng.standard_normal((100, d))
     qs[5] = docs[n - 1].astype(np.float64)
     dev = amd.ei.DeviceIndex.from_host(docs)
+    dev.scan_stats(reset=True)
     for b in (1, 64, 100):
         _, _, rows, dist, cnt, flags = dev.search(qs[:b], 10, metric)
         assert (cnt == 10).all()
+        if n >= 32768:
+            assert (flags == 0).all(), f"{metric} d={d}: the wide sieve needed the exact pass: {flags}"
         for i in ([0, 5] if b == 1 else [1, 5, 33, 63]) [: b] + ([99] if b == 100 else []):
             with np.errstate(invalid="ignore"):
                 wrows, wdist = oi.find_flat(qs[i], docs, metric, 10)
                 alld = oi.ENUM_TO_METRIC[oi.Metric(metric)](qs[i], docs) if metric == "cosine_sim" else None
             assert_same_ids(metric, rows[i], wrows, (lambda r: alld[r]) if alld is not None else None, f"{metric} d={d} b={b} q={i}")
             np.testing.assert_allclose(dist[i], wdist, rtol=1e-9, atol=2e-7 * d, equal_nan=True)
+    assert (dev.scan_stats()["queries"] > 0) == (n >= 32768)  # the sieve's counters: it ran iff the shard is large enough
     if metric in ("sqeuclidean_dist", "inner_product"):
         _, _, rows, _, _, _ = dev.search(qs[5:6], 10, metric)
         assert list(rows[0, :3]) == [31, 32, n - 1]
