@@ -386,6 +386,11 @@ constexpr int FQA_WSLOTS = 3;
 #ifndef FQA_PF
 #define FQA_PF 6
 #endif
+// FQA_ABL: TIMING-ONLY ablations of the fused kernel (results wrong by design): bit 0 one key tile per head instead of the
+// sequence's n_kt, bit 1 a third of the projections' k-steps
+#ifndef FQA_ABL
+#define FQA_ABL 0
+#endif
 constexpr int FQA_BLOCK_BYTES = KS_H * 1024;         // one (projection, head) weight block
 constexpr int FQA_PPW = KS_H / FQA_TILES;            // 1-KiB pieces of a block per wave
 constexpr int FQA_KV_OFF = FQA_WSLOTS * FQA_BLOCK_BYTES;
@@ -454,9 +459,10 @@ __global__ __launch_bounds__(64 * FQA_TILES, 1) void fused_qkv_attention_kernel(
             uint4 fr[PF + 1];
 #pragma unroll
             for (int i = 0; i < PF; ++i) fr[i] = w[i * 64];
+            constexpr int KSN = (FQA_ABL & 2) ? KS_H / 3 : KS_H;
 #pragma unroll
-            for (int ks = 0; ks < KS_H; ++ks) {
-                if (ks + PF < KS_H) fr[(ks + PF) % (PF + 1)] = w[(ks + PF) * 64];
+            for (int ks = 0; ks < KSN; ++ks) {
+                if (ks + PF < KSN) fr[(ks + PF) % (PF + 1)] = w[(ks + PF) * 64];
                 __builtin_amdgcn_sched_barrier(0);
                 acc = j == 1 ? mfma(x[ks], fr[ks % (PF + 1)], acc) : mfma(fr[ks % (PF + 1)], x[ks], acc);  // V: x W (rows = tokens); Q, K: W^T x^T
             }
@@ -483,10 +489,11 @@ __global__ __launch_bounds__(64 * FQA_TILES, 1) void fused_qkv_attention_kernel(
         __builtin_amdgcn_s_barrier();  // the head's K / V of every tile of the bin are in LDS
         if (!live) continue;
         AttnState st;
-        for (int kt = 0; kt < n_kt; ++kt) {
+        const int n_steps = (FQA_ABL & 1) ? 1 : n_kt;
+        for (int kt = 0; kt < n_steps; ++kt) {
             const uint4 *kv = kvs + (size_t)(kv0 + kt) * 256 + lane;
             const uint4 k0 = kv[0], k1 = kv[64], v0 = kv[128], v1 = kv[192];
-            attn_step1_rt(st, qq, k0, k1, v0, v1, kt == 0, kt == n_kt - 1, 32 * kt, seq_len, h);
+            attn_step1_rt(st, qq, k0, k1, v0, v1, kt == 0, kt == n_steps - 1, 32 * kt, seq_len, h);
         }
         attn_store(st, out + (size_t)(hd * 2) * 64);
     }

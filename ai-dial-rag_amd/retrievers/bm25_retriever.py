@@ -156,7 +156,7 @@ def _build_text_index_chunks(chunks, preprocess: Optional[Callable[[str], List[s
         batches = map(one, starts)
     else:
         # two batches in flight: the native call of one (GIL released, all cores) runs beside the Python side of the other
-        # (a str object per token and a list per chunk: single-threaded by nature)
+        # (the TokenList views and the TextIndexItem objects: single-threaded by nature)
         pool = ThreadPoolExecutor(2, thread_name_prefix="mir-kwp")
         batches = pool.map(one, starts)
     for b0, toks in zip(starts, batches):

@@ -1029,7 +1029,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32 (bf16 MFMA filter with a worst-case error margin, every candidate re-scored in f64 with the reference formula)",
+        "dtype": "f32 (bf16 MFMA filter with a worst-case error margin, every candidate the margin cannot exclude re-scored in f64 with the reference formula)",
         "data": "synthetic",
         "config": {
             "workload": f"brute-force top-k over {n}x{d} float32 unit-norm rows, {args.metric}, k={k}",

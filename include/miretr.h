@@ -65,10 +65,12 @@ extern "C" {
 /* per-query result flags (out_flags).  Results are ALWAYS the reference's.
  * float32 shards of >= 32K rows at d <= 384 are searched by the sieve: a bf16
  * filter with a worst-case error margin lets through every row that can reach a
- * proven lower bound of the k-th best distance, EVERY candidate is re-scored
- * with the reference formula in float64, and the reference order is taken over
- * them - exact by construction; only a full candidate buffer (thousands of rows
- * inside the margin) hands a query to the exact pass.  The other shapes use
+ * proven lower bound of the k-th best distance; the candidates whose filter
+ * value, widened by the margin, can still reach the k-th best EXACT distance are
+ * re-scored with the reference formula in float64 (the others are proven
+ * outside the top k), and the reference order is taken over them - exact by
+ * construction; only a full candidate buffer (thousands of rows inside the
+ * margin) hands a query to the exact pass.  The other shapes use
  * filter scans with candidate lists whose completeness is proven a posteriori;
  * a query they cannot prove (more near-ties at the cut than the lists hold), and
  * any k beyond the filters (64 on the sieve; 52 / 48 / 56 / 28 on the list scans)

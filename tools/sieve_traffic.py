@@ -53,5 +53,5 @@ print(json.dumps({
     "streamed_bytes_per_launch_by_construction": streamed,
     "ratio": hbm / streamed,
     "survey_algorithmic_bytes_per_launch": n * d * 4 + 4 * n + B * d * 4 + B * 10 * 12,
-    "command": "round 3: rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/sieve_stats.py %d %d (WRITE_SIZE in its own pass); tools/sieve_traffic.py" % (n, B),
+    "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/sieve_stats.py %d %d (WRITE_SIZE in its own pass); tools/sieve_traffic.py" % (n, B),
 }, indent=1))
