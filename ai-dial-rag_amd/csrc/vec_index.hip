@@ -16,6 +16,7 @@
 #include "vec_kernels_q16.h"
 #include "vec_kernels_h16.h"
 #include "vec_kernels_sieve.h"
+#include "vec_kernels_i8.h"
 #include "vec_kernels_exact.h"
 
 namespace mir {
@@ -107,6 +108,12 @@ struct mir_index {
     bool norms_spread = false;   // the largest row norm exceeds the smallest tile maximum by more than 1/16: the sieve takes its margins per tile /
                                  // per row (unit-norm embeddings - the headline - keep round 3's one margin per query: the per-tile form cost that step ~3 %)
     float *d_maxnorm = nullptr;
+    // the sieve's int8 first stage (vec_kernels_i8.h): built after the float image where the shard qualifies (build_i8)
+    bool i8 = false;
+    uint4 *d_i8 = nullptr;       // n_stages x 2 tiles x ks64 * 2 blocks of 1 KiB
+    float *d_i8stats = nullptr;  // kI8StatWords floats
+    int ks64 = 0;
+    uint32_t n_stages = 0;       // 64-row stages = ceil(n_tiles / 2)
     unsigned long long *d_stats = nullptr;  // 8 counters of the sieve (mir_index_scan_stats)
     int64_t *d_chunk = nullptr;
     int32_t *d_doc = nullptr;
@@ -158,6 +165,8 @@ static void free_index(mir_index *ix) {
     (void)hipFree(ix->d_invnorm);
     (void)hipFree(ix->d_dnorm);
     (void)hipFree(ix->d_tilemax);
+    (void)hipFree(ix->d_i8);
+    (void)hipFree(ix->d_i8stats);
     (void)hipFree(ix->d_hi16);
     (void)hipFree(ix->d_maxnorm);
     (void)hipFree(ix->d_stats);
@@ -259,6 +268,30 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
     return MIR_OK;
 }
 
+// The int8 image of a shard the bf16 sieve serves, where its one-scale-per-index quantisation and one-margin-per-query bound
+// apply: finite rows, norms not spread (vec_kernels_i8.h).  Runs after build_derived's statistics are known on the host.
+static int32_t build_i8(mir_index *ix, hipStream_t stream) {
+    const int64_t n = ix->n;
+    const int d = ix->d;
+    ix->ks64 = ix->ksteps / 4;  // ksteps counts 16 columns: 8 / 16 / 24 -> 2 / 4 / 6 k-steps of 64
+    ix->n_stages = (ix->n_tiles + 1) / 2;
+    const size_t image = (size_t)ix->n_stages * 2 * ix->ks64 * 2 * 1024;
+    MIR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8), image));
+    MIR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8stats), kI8StatWords * 4));
+    ix->hbm_bytes += image + kI8StatWords * 4;
+    MIR_HIP(hipMemsetAsync(ix->d_i8stats, 0, kI8StatWords * 4, stream));
+    i8_absmax_kernel<<<dim3((unsigned)std::min<int64_t>(4096, (n * d / 4 + 255) / 256 + 1)), dim3(256), 0, stream>>>(
+        ix->d_orig, n * (int64_t)d, reinterpret_cast<unsigned int *>(ix->d_i8stats) + 6);
+    i8_scale_kernel<<<dim3(1), dim3(1), 0, stream>>>(ix->d_i8stats, ix->d_maxnorm);
+    const int64_t lanes = (int64_t)ix->n_stages * 2 * ix->ks64 * 2 * 64;
+    pack_i8_kernel<<<dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ks64, lanes, ix->d_i8stats, ix->d_i8);
+    i8_residual_kernel<<<dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->d_dnorm, ix->d_i8stats);
+    MIR_HIP(hipGetLastError());
+    MIR_HIP(hipStreamSynchronize(stream));
+    ix->i8 = true;
+    return MIR_OK;
+}
+
 static int32_t check_create_args(int64_t n, int32_t d, int32_t dtype, mir_index **out) {
     MIR_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
@@ -291,6 +324,9 @@ struct SearchBuffers {
     double *q_sq;    // [b]
     double *q_err;   // [b] |q - bf16(q)|: what the hi fragments lose on the query's side (layout16; the sieve's margin)
     double *q_norm;  // [b]
+    float *q_amax;   // [b] the int8 filter: a query's largest |q_i| (-1: not finite)
+    float *i8_call;  // [kI8CallWords] its per-call constants
+    int32_t *c_col;  // [n_stages * 64] its squared-L2 C operand column for this call's query scale
     float *qscale;   // [b] 1 / (query scale) of the float16-native scan
     uint64_t *part;  // [ngroups][nwg][qpw][klist]
     uint64_t *gthr;  // [ngroups][128] shared per-query thresholds of the 128-query scan; the control words below
@@ -330,7 +366,7 @@ struct SearchPlan {
     uint32_t sample_tpw = 0;  // the sieve's threshold sample: tiles per sample workgroup
 };
 
-static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int ksteps, const SearchPlan &pl, bool host_api) {
+static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int ksteps, const SearchPlan &pl, bool host_api, size_t i8_rows = 0) {
     const int ngroups = pl.ngroups, nwg = pl.nwg, klist = pl.klist, qpw = pl.qpw;
     Carver c{base};
     sb.q = host_api ? c.take<double>((size_t)b * d) : nullptr;
@@ -338,6 +374,9 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.q_sq = c.take<double>(b);
     sb.q_err = c.take<double>(b);
     sb.q_norm = c.take<double>(b);
+    sb.q_amax = c.take<float>(i8_rows ? b : 0);
+    sb.i8_call = c.take<float>(i8_rows ? kI8CallWords : 0);
+    sb.c_col = c.take<int32_t>(i8_rows);
     sb.qscale = c.take<float>((size_t)ngroups * std::max(128, qpw));
     sb.part = c.take<uint64_t>(pl.sieve ? 0 : (size_t)ngroups * nwg * qpw * klist);  // per-workgroup lists of the list scans (the sieve has its own regions: 33.5 MB per launch group saved)
     // one zeroed control block: gthr | nflag | arrive[b] | sieve over[b] | sieve count[b][32]  (u32 arrays padded to u64)
@@ -541,6 +580,39 @@ static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g,
     return MIR_OK;
 }
 
+// the int8 filter's launch over 64-row stages [stage0, stage0 + n_stages) (vec_kernels_i8.h)
+template <int KIND>
+static int32_t launch_sieve_i8(const mir_index *ix, int qpw, const SearchBuffers &sb, const uint4 *qfrag_g, const double *q_norm_g,
+                               const double *q_sq_g, const double *q_err_g, int nq, int nwg, uint32_t stage0, uint32_t n_stages,
+                               int nan_guard, const uint64_t *gthr_g, uint64_t *cand, float *candv, uint32_t *ccount, float *part_sample,
+                               bool sample, unsigned long long *stat, hipStream_t stream) {
+    const size_t lds = sieve_i8_lds_bytes(ix->ks64);
+    const uint32_t n_rows = (uint32_t)ix->n;
+#define MIR_I8_PICK(KS)                                                                                                \
+    (qpw > 128 ? (sample ? sieve_i8_kernel<KS, KIND, true, 2> : sieve_i8_kernel<KS, KIND, false, 2>)                   \
+               : (sample ? sieve_i8_kernel<KS, KIND, true, 1> : sieve_i8_kernel<KS, KIND, false, 1>))
+#define MIR_I8_CASE(KS)                                                                                                \
+    case KS: {                                                                                                         \
+        auto kern = MIR_I8_PICK(KS);                                                                                   \
+        MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_i8, sb.c_col, qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, sb.i8_call, n_rows, \
+                                                    stage0, n_stages, nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat); \
+        break;                                                                                                         \
+    }
+    switch (ix->ks64) {
+        MIR_I8_CASE(2)
+        MIR_I8_CASE(4)
+        MIR_I8_CASE(6)
+        default:
+            set_error("internal: the int8 filter has no instance for %d k-steps of 64", ix->ks64);
+            return MIR_ERR_UNSUPPORTED;
+    }
+#undef MIR_I8_CASE
+#undef MIR_I8_PICK
+    MIR_HIP(hipGetLastError());
+    return MIR_OK;
+}
+
 // the float16-native sieve's filter launch (vec_kernels_sieve.h, sieve_h16_kernel)
 // BF: the bf16 hi image of a wide float32 shard (ix->d_hi16, ix->ks16), the query fragments of prep_queries16_kernel, `q_err_g`
 template <int KIND, bool BF = false>
@@ -695,7 +767,18 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         }
         return MIR_OK;
     }
-    if (ix->layout16 && qpw >= kQ16Queries) {
+    // the int8 first stage serves this call: the shard has the image, the metric ranks in the rows' own units
+    const bool use_i8 = ix->i8 && pl.sieve && metric != MIR_METRIC_COSINE_SIM && sb.c_col != nullptr;
+    if (use_i8) {
+        const int ntiles16 = ngroups * (qpw / 16);
+        prep_queries_i8_stats_kernel<<<dim3(std::max(b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(dq, b, d, sb.q_sq, sb.q_norm, sb.q_amax, gz, gwords);
+        prep_queries_i8_quant_kernel<<<dim3(ntiles16 * ix->ks64 + b), dim3(64), 0, stream>>>(dq, b, d, ix->ks64, ntiles16, sb.q_amax, ix->d_i8stats,
+                                                                                            sb.qsplit, sb.q_err, sb.i8_call);
+        if (metric != MIR_METRIC_INNER_PRODUCT) {
+            const int64_t n_pad = (int64_t)ix->n_stages * 64;
+            i8_c_column_kernel<<<dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, stream>>>(ix->d_docsq, n_pad, ix->n, sb.i8_call, sb.c_col);
+        }
+    } else if (ix->layout16 && qpw >= kQ16Queries) {
         const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (qpw / 16);
         prep_queries16_kernel<<<dim3(std::max(ntiles16 * ks32 + b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(
             dq, b, d, ks32, ntiles16, sb.qsplit, sb.q_sq, sb.q_norm, gz, gwords, sb.q_err);
@@ -745,6 +828,13 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             auto sieve = [&](uint32_t t0, uint32_t nt, int wgs, uint64_t *cand, float *cv, uint32_t *cc, bool smp) {
                 float *ps = reinterpret_cast<float *>(sb.part_sample);
                 unsigned long long *st = smp ? nullptr : ix->d_stats + (t0 ? 1 : 0);
+                if (use_i8) {  // tiles -> 64-row stages: [t0 / 2, (t0 + nt + 1) / 2) (t0 is even or 0 wherever two launches meet: see below)
+                    const uint32_t s0 = t0 / 2, s1 = std::min<uint32_t>((t0 + nt + 1) / 2, ix->n_stages);
+                    const uint4 *qf = sb.qsplit + (size_t)g * (qpw / 16) * ix->ks64 * 64;
+                    if (metric == MIR_METRIC_INNER_PRODUCT)
+                        return launch_sieve_i8<SCAN_IP>(ix, qpw, sb, qf, qn, qsq, qerr, nq, wgs, s0, s1 - s0, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                    return launch_sieve_i8<SCAN_L2>(ix, qpw, sb, qf, qn, qsq, qerr, nq, wgs, s0, s1 - s0, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                }
                 if (ix->native16) {
                     if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve16<SCAN_IP>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
                     if (metric == MIR_METRIC_COSINE_SIM) return launch_sieve16<SCAN_COS>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
@@ -770,6 +860,12 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             sa.dnorm = (ix->native16 || !ix->norms_spread) ? nullptr : ix->d_dnorm;
             sa.q = dq; sa.q_sq = sb.q_sq; sa.q_norm = sb.q_norm; sa.max_norm = ix->d_maxnorm;
             sa.q_err = ix->native16 ? nullptr : sb.q_err;
+            sa.i8_call = nullptr;
+            if (use_i8) {  // the margin of the int8 filter's values: its statistics, its query residuals, one unit more (i8_margin)
+                sa.max_norm = ix->d_i8stats;
+                sa.i8_call = sb.i8_call;
+                sa.dnorm = nullptr;
+            }
             sa.gthr = reinterpret_cast<unsigned long long *>(gt);
             sa.chunk_ids = ix->d_chunk; sa.doc_ids = ix->d_doc; sa.row_offset = ix->row_offset;
             sa.out_doc = o_doc; sa.out_chunk = o_chunk; sa.out_row = o_row; sa.out_dist = o_dist; sa.out_count = o_count;
@@ -930,6 +1026,7 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
             const bool two = (int64_t)ix->n_tiles >= (int64_t)two_phase_tiles * wgs;
             static const uint32_t first_div = getenv("MIR_SIEVE_FIRST_DIV") ? (uint32_t)atoi(getenv("MIR_SIEVE_FIRST_DIV")) : 16u;  // (experiments)
             pl->tiles_first = two ? std::max<uint32_t>(ix->n_tiles / first_div, std::min<uint32_t>(ix->n_tiles / 4, 4896u)) : 0;
+            pl->tiles_first &= ~1u;  // (the int8 filter walks 64-row stages: the two launches meet at a stage boundary)
             pl->sample_tpw = std::max<uint32_t>(1, std::min<uint32_t>(two ? kSampleTilesPerWg : single_tpw, ix->n_tiles / (4u * kSampleWgs)));
             return MIR_OK;
         }
@@ -1176,6 +1273,15 @@ static int32_t create_common(const RowSource &src, int64_t n, int32_t d, int32_t
             return fail(MIR_ERR_HIP);
         }
         ix->norms_spread = !(st[0] <= 1.0625f * st[4]) || getenv("MIR_SIEVE_PER_TILE") != nullptr;  // (NaN / infinite norms: spread)
+        // the int8 first stage is an EXPERIMENT (round 4): exact, its raw filter loop 1.8 x the bf16 one's rate, and no
+        // faster end to end - its rigorous margin lists ~20 x the candidates.  Built only on request (read per build: tests switch it)
+        const bool i8_on = getenv("MIR_SIEVE_I8") != nullptr && atoi(getenv("MIR_SIEVE_I8")) == 1;
+        unsigned int nonfinite = 0;
+        memcpy(&nonfinite, &st[1], 4);
+        if (ix->hi_only && !ix->norms_spread && nonfinite == 0u && st[0] > 0.f && i8_on) {
+            rc = build_i8(ix, stream);
+            if (rc != MIR_OK) return fail(rc);
+        }
     }
     *out = ix;
     return MIR_OK;
@@ -1375,11 +1481,12 @@ int32_t mir_index_search_device(mir_index *idx, const double *queries_device, in
     rc = plan(idx, b, k, &pl);
     if (rc != MIR_OK) return rc;
     SearchBuffers sb;
-    const size_t need = carve(sb, nullptr, b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, false);
+    const size_t i8_rows = (idx->i8 && pl.sieve) ? (size_t)idx->n_stages * 64 : 0;
+    const size_t need = carve(sb, nullptr, b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, false, i8_rows);
     Workspace *w = nullptr;
     rc = acquire_ws(idx, stream, need, &w);
     if (rc != MIR_OK) return rc;
-    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, false);
+    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, false, i8_rows);
     rc = enqueue_search(idx, queries_device, b, k, metric, sb, pl, out_doc, out_chunk, out_row,
                         out_dist, out_count, out_flags, stream);
     release_ws(idx, w, stream, true);
@@ -1398,11 +1505,12 @@ int32_t mir_index_search(mir_index *idx, const double *queries_host, int32_t b, 
     rc = plan(idx, b, k, &pl);
     if (rc != MIR_OK) return rc;
     SearchBuffers sb;
-    const size_t need = carve(sb, nullptr, b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, true);
+    const size_t i8_rows = (idx->i8 && pl.sieve) ? (size_t)idx->n_stages * 64 : 0;
+    const size_t need = carve(sb, nullptr, b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, true, i8_rows);
     Workspace *w = nullptr;
     rc = acquire_ws(idx, nullptr, need, &w);
     if (rc != MIR_OK) return rc;
-    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, true);
+    carve(sb, static_cast<char *>(w->buf), b, k, idx->d, std::max(idx->ksteps, idx->ks16), pl, true, i8_rows);
     hipStream_t s = w->stream;
     auto bail = [&](int32_t code) {
         (void)hipStreamSynchronize(s);

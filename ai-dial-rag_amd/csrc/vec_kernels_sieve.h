@@ -38,7 +38,10 @@
 
 #ifndef SIEVE_ABL
 #define SIEVE_ABL 0  // measurement builds only (tools/run_vec_variants.sh; results are wrong, only the time means something): 1 = half the
-                     // MFMAs, 3 = no DMA after the prologue, 4 = no filter, 5 = no barrier
+                     // MFMAs, 3 = no DMA after the prologue, 4 = no filter, 5 = no barrier.  Combinable with 4 (nothing is emitted, so
+                     // the chain around the filter stays short): -DSIEVE_ABL_NODMA (as 3), -DSIEVE_ABL_NOWAIT (DMA issued, never
+                     // waited for), -DSIEVE_ABL_HOT (every workgroup streams the same 64 tiles: the DMA's instructions and L2 path
+                     // without HBM traffic) - round 4, DESIGN.md 3.4
 #endif
 #ifndef SIEVE_MAX3
 #define SIEVE_MAX3 1  // 0 = the eight-compare form of the filter's common path on every index (measurement builds)
@@ -53,7 +56,10 @@
 namespace mir {
 
 constexpr int kSieveStages = 6;        // LDS-DMA ring: 6 x 24 KiB at d = 384, five stages in flight
-constexpr int kSieveRegion = 8192;     // candidates a workgroup can write per launch (96 KiB of HBM each)
+#ifndef MIR_SIEVE_REGION
+#define MIR_SIEVE_REGION 8192
+#endif
+constexpr int kSieveRegion = MIR_SIEVE_REGION;  // candidates a workgroup can write per launch (96 KiB of HBM each)
 constexpr int kSieveQueryCap = 16384;  // candidates listed per query (~120 k of them arrive on a 10M-row shard; k = 64 lists ~6 600)
 constexpr int kSieveSelectCap = 4096;  // of which at most this many may need the float64 formula (within 2 mg of the k-th largest v):
                                        // a few dozen as a rule; thousands of near-copies of one row cost a query's block ~1 ms, not the exact pass
@@ -147,7 +153,11 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     const uint32_t NG = my_tiles;
 
     auto issue = [&](uint32_t g) {
+#ifdef SIEVE_ABL_HOT
+        const uint32_t tile = (g & 63u);
+#else
         const uint32_t tile = tile0 + blockIdx.x + g * G;
+#endif
         const uint4 *src = docs + (size_t)tile * tile_u4 + (wave8 * PPW) * 64 + lane;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave8 * PPW) * 64) * 16);
 #pragma unroll
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
     for (uint32_t g = 0; g < (uint32_t)D && g < NG; ++g) issue(g);
 
     auto wait_stage = [&](uint32_t g) {  // stage g has landed: all but the younger stages' operations are done
-#if SIEVE_ABL == 3
+#if SIEVE_ABL == 3 || defined(SIEVE_ABL_NODMA) || defined(SIEVE_ABL_NOWAIT)
         return;
 #endif
         const uint32_t younger = (NG - 1 - g) < (uint32_t)(D - 1) ? (NG - 1 - g) : (uint32_t)(D - 1);
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void sieve_q16_kernel(const uint4 *__restri
 #endif
             if (s == 1) {  // the next stage's DMA once the matrix pipe has work queued
                 __builtin_amdgcn_sched_barrier(0);
-#if SIEVE_ABL != 3
+#if SIEVE_ABL != 3 && !defined(SIEVE_ABL_NODMA)
                 if (g + D < NG) issue(g + D);
 #endif
             }
@@ -634,6 +644,10 @@ __global__ __launch_bounds__(256) void sieve_scatter_kernel(SieveScatterArgs a) 
         const uint64_t key = region[e];
         const float v = regionv[e];
         const int qi = a.q0 + (int)(key >> 32);
+        if ((uint32_t)key == 0xffffffffu) {  // the int8 filter's marker (vec_kernels_i8.h, kI8ClampRow): this query takes the exact pass
+            a.l.over[qi] = 1;
+            continue;
+        }
         const uint32_t slot = atomicAdd(&a.l.count[(size_t)qi * kSieveCountStride], 1u);
         if (slot < (uint32_t)kSieveQueryCap) {
             a.l.row[(size_t)qi * kSieveQueryCap + slot] = (uint32_t)key;
@@ -791,7 +805,8 @@ struct SieveSelectArgs {
     int d, nan_guard;
     float rel_err;                 // the float16 filter's bound (kH16RelErr); a float32 index: the margin of hihi_margin()
     float extra_slop;              // wide float32 shards (d > 384): the longer float32 accumulation's share of the margin, relative (wide_accum_slop)
-    const double *q_err;           // [b] |q - bf16(q)| (float32 index), or null
+    const double *q_err;           // [b] |q - bf16(q)| (float32 index; |q - s_q Q| behind the int8 filter), or null
+    const float *i8_call;          // the int8 filter's per-call constants (vec_kernels_i8.h: max_norm then holds ITS statistics), or null
     const float *docs;             // f32 [n][d], or null with
     const _Float16 *docs16;        // f16 [n][d] (float16-native index)
     const float *doc_sq;
@@ -894,7 +909,8 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
     };
     const float qn = (float)a.q_norm[qi] * (1.0f + 1e-6f);
     const bool l2 = !(a.metric == MIR_METRIC_INNER_PRODUCT || a.metric == MIR_METRIC_COSINE_SIM);
-    const float mg = a.q_err ? hihi_margin(a.metric == MIR_METRIC_COSINE_SIM, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) +
+    const float mg = a.i8_call ? hihi_margin(false, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) + (l2 ? 6.0f : 2.0f) * a.i8_call[0]  // (= i8_margin)
+                   : a.q_err ? hihi_margin(a.metric == MIR_METRIC_COSINE_SIM, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) +
                                    a.extra_slop * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) * (l2 ? 2.0f : 1.0f)
                              : a.rel_err * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) * (l2 ? 2.0f : 1.0f);  // (as the filter's)
     // Per-row margins (float32 index, inner product / squared L2): a row's true value lies within m = |x| * cq of its v (hihi_coeff);

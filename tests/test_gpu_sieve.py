@@ -330,3 +330,62 @@ def test_worst_case_bf16_rounding(ei):
             check(metric, qs[i], docs, tuple(o[i] for o in out), 10, f"worst case {metric} q={i}")
     assert list(ix.search(qs, 10, "inner_product")[2][1][:5]) == list(a_pos)
     ix.close()
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean_dist", "euclidean_dist", "inner_product"])
+def test_int8_first_stage_experiment_is_exact(ei, metric, monkeypatch):
+    """The sieve's int8 first stage (csrc/vec_kernels_i8.h; an experiment, built only with MIR_SIEVE_I8=1): a filter on
+    v_mfma_i32_16x16x64_i8 with the rigorous Cauchy-Schwarz margin of the int8 residuals.  Whatever route a query takes - its
+    own select or, when its lists overflow, the exact pass - ids, order and distances are the oracle's; on isotropic unit rows
+    the int8 route must answer itself (flag 0) for ordinary queries.  Also: rows of one large norm with short queries (the
+    integer C operand stays small: C' is taken relative to the largest norm), a row far shorter than the others (the clamp's
+    marker sends its queries to the exact pass), 200 queries (two query tiles per wave) and 40 (one)."""
+    monkeypatch.setenv("MIR_SIEVE_I8", "1")
+    rng = np.random.default_rng(808)
+    n, d = 600_001, 384  # two filter launches; an odd number of 32-row tiles: the last 64-row stage is half empty
+    docs = rng.standard_normal((n, d)).astype(np.float32)
+    docs /= np.linalg.norm(docs, axis=1, keepdims=True)
+    docs[400_000] = docs[77]       # an exact duplicate, one copy per launch
+    qs = rng.standard_normal((200, d))
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    qs[0] = docs[77].astype(np.float64)
+    qs[1] *= 0.25
+    ix = ei.DeviceIndex.from_host(docs)
+    for b, k in ((200, 10), (40, 64)):
+        with np.errstate(invalid="ignore"):
+            out = ix.search(qs[:b], k, metric)
+        st = ix.scan_stats()
+        assert st["queries"] == b, st  # the sieve (not a list scan) answered
+        # (query 1 is a quarter as long as the others: under the call's common query scale its residual is relatively four times
+        # theirs, its lists may overflow)
+        assert int(np.delete(out[5], 1).sum()) == 0, f"{metric} b={b}: queries took the exact pass: {out[5]} {st}"
+        for i in list(range(6)) + [b - 1]:
+            check(metric, qs[i], docs, tuple(o[i] for o in out), k, f"{metric} b={b} k={k} q={i}")
+    # one long query stretches the CALL's query scale: the others' residuals grow, their lists overflow, the exact pass answers -
+    # slow, and exact
+    q3 = qs[:4].copy()
+    q3[2] *= 40.0
+    out = ix.search(q3, 10, metric)
+    for i in range(4):
+        check(metric, q3[i], docs, tuple(o[i] for o in out), 10, f"{metric} long query in the batch q={i} flag={out[5][i]}")
+    ix.close()
+    if metric == "inner_product":
+        return
+    # rows of norm 50 (equal to 1e-4), queries of norm 1e-2 .. 1: the C operand is relative to the largest norm; and one row of
+    # norm 1 among them - far below the clamp for the short queries: those go to the exact pass, and every answer is exact
+    docs2 = rng.standard_normal((n, d))
+    docs2 *= ((50.0 + rng.uniform(-1e-4, 1e-4, n)) / np.linalg.norm(docs2, axis=1))[:, None]
+    docs2 = docs2.astype(np.float32)
+    docs2[1234] *= np.float32(0.02)
+    q2 = rng.standard_normal((8, d))
+    q2 *= (np.array([1e-2, 1e-2, 3e-2, 1e-1, 1e-1, 0.3, 1.0, 1.0]) / np.linalg.norm(q2, axis=1))[:, None]
+    ix = ei.DeviceIndex.from_host(docs2)
+    out = ix.search(q2, 10, metric)
+    from oracle import embeddings_metrics as om
+
+    for i in range(len(q2)):
+        alld = om.ENUM_TO_METRIC[om.Metric(metric)](q2[i], docs2)
+        want = np.argsort(alld, kind="stable")[:10]
+        np.testing.assert_array_equal(out[2][i][: out[4][i]], want, err_msg=f"{metric} long rows q={i} flag={out[5][i]}")
+        np.testing.assert_allclose(out[3][i][: out[4][i]], alld[want], rtol=0, atol=1e-9)
+    ix.close()
