@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(Bm25Dev m, const int32_t
                                                         double *__restrict__ out_scores,
                                                         double *__restrict__ part_score,
                                                         int32_t *__restrict__ part_idx,
-                                                        int32_t *__restrict__ part_cnt, DenseMerge dm) {
+                                                        int32_t *__restrict__ part_cnt, DenseMerge dm,
+                                                        const int32_t *__restrict__ dense_list = nullptr,
+                                                        const int32_t *__restrict__ dense_n = nullptr) {
     __shared__ double sc[kBm25Tile];
     __shared__ double red_s[4];
     __shared__ int64_t red_i[4];
@@ -279,8 +281,14 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(Bm25Dev m, const int32_t
     __shared__ int m_off[kBm25Chunk + 1];
     __shared__ int m_cnt;
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x, q = blockIdx.y;
-    if (need_dense && !need_dense[q]) return;   // fallback launch: only the flagged queries run
+    const int tile = blockIdx.x;
+    // fallback launch: the listed queries only, blockIdx.y, + gridDim.y, ...; otherwise query blockIdx.y
+    const int n_list = dense_list ? *dense_n : (int)gridDim.y;
+    for (int li = blockIdx.y; li < n_list; li += gridDim.y) {
+    const int q = dense_list ? dense_list[li] : li;
+    if (li != (int)blockIdx.y) __syncthreads();  // (the previous query's use of the shared arrays is over)
+    [&]() {
+    if (need_dense && !need_dense[q]) return;
     const int base = tile * kBm25Tile;
     const int cnt = (int)((m.n_docs - base) < kBm25Tile ? (m.n_docs - base) : kBm25Tile);
     const int qb = q_ptr[q], qe = q_ptr[q + 1];
@@ -384,6 +392,8 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(Bm25Dev m, const int32_t
     if (!s_last) return;
     __threadfence();
     bm25_merge_tail(part_score, part_idx, part_cnt, m.ntiles, k, dm, q);
+    }();
+    }
 }
 
 // ---- routing between the two fast passes (bm25_wave_kernel below, one wave per (tile, query); this tile kernel for the
@@ -407,6 +417,8 @@ struct WavePool {
     uint32_t *off;     // [b] its first pool entry
     int32_t *hlist;    // [b] the heavy queries, for bm25_sparse_kernel; hlist[b] = their number
     uint32_t *arrive;  // [b] dense pass: tiles of the query that have written their candidates (the last one merges them)
+    int32_t *dense_list;  // [b] the queries the dense pass has to run (bm25_finish_kernel appends), dense_n[0] of them
+    int32_t *dense_n;
     long long capacity;
 };
 __host__ __device__ inline long long wave_pool_capacity(int b, int ntiles) {
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_
             at += need;
         }
         __syncthreads();
-        if (tid == 0) pool.hlist[b] = s_nheavy;
+        if (tid == 0) { pool.hlist[b] = s_nheavy; *pool.dense_n = 0; }
         return;
     }
     for (int q0 = 0; q0 < b; q0 += nthreads) {
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(1024) void bm25_plan_kernel(Bm25Dev m, const int32_
         if (tid == nthreads - 1) s_base += s_scan[nthreads - 1];
         __syncthreads();
     }
-    if (tid == 0) pool.hlist[b] = s_nheavy;
+    if (tid == 0) { pool.hlist[b] = s_nheavy; *pool.dense_n = 0; }
 }
 
 // Fast pass.  grid = (ntiles, ceil(b / qc)), block = 256: a workgroup owns one tile and walks `qc`
@@ -1157,6 +1169,9 @@ __global__ __launch_bounds__(256) void bm25_finish_kernel(WavePool pool, double 
     const int q = blockIdx.x;
     if (pool.light[q]) bm25_select_body(pool, k, doc_offset, n_docs, need_dense, out_idx, out_score, out_count, L);
     else bm25_merge_body(part_score, part_idx, part_cnt, ntiles, k, doc_offset, n_docs, 0, q, need_dense, out_idx, out_score, out_count, L);
+    // the dense pass walks a LIST of the queries that came up short (thread 0 wrote the flag above): a grid of (tiles x b)
+    // workgroups that each read a flag and return was 200 us of the 4096-query step
+    if (threadIdx.x == 0 && need_dense[q]) pool.dense_list[atomicAdd(pool.dense_n, 1)] = q;
 }
 
 // ---- any n (bm25_retriever.py:81-84 takes any n): beyond the 64 results the selection kernels hold, the dense score
@@ -1522,9 +1537,11 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     pool.off = reinterpret_cast<uint32_t *>(pool.light + b);
     pool.hlist = reinterpret_cast<int32_t *>(pool.off + b);
     pool.arrive = reinterpret_cast<uint32_t *>(pool.hlist + b + 1);
-    pool.count = pool.arrive + b;
+    pool.dense_list = reinterpret_cast<int32_t *>(pool.arrive + b);
+    pool.dense_n = pool.dense_list + b;
+    pool.count = reinterpret_cast<uint32_t *>(pool.dense_n + 1);
     {
-        size_t o = (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 20 + 4 + (size_t)b * kWvCountStride * 4;
+        size_t o = (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 24 + 8 + (size_t)b * kWvCountStride * 4;
         o = (o + 255) & ~(size_t)255;
         pool.score = reinterpret_cast<double *>(p + o);
         pool.doc = reinterpret_cast<int32_t *>(p + o + (size_t)pool.capacity * 8);
@@ -1563,14 +1580,15 @@ static int32_t bm25_run(mir_bm25 *h, const int32_t *d_terms, const int32_t *d_pt
     DenseMerge dm;
     dm.arrive = pool.arrive; dm.doc_offset = h->doc_offset; dm.n_docs = h->n_docs; dm.need_dense = need;
     dm.out_idx = d_out_idx; dm.out_score = d_out_score; dm.out_count = d_out_count;
-    bm25_tile_kernel<<<dim3(T, b), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, k, need, nullptr, part_score, part_idx, part_cnt, dm);
+    bm25_tile_kernel<<<dim3(T, std::min(b, 16)), dim3(256), 0, s>>>(dev_view(h), d_terms, d_ptr, k, need, nullptr, part_score, part_idx, part_cnt, dm,
+                                                                      pool.dense_list, pool.dense_n);
     MIR_HIP(hipGetLastError());
     return MIR_OK;
 }
 
-// [part_score | part_idx | part_cnt | need, light, off (b each), hlist (b + 1), arrive (b) | count (b x 32) | pool scores | pool documents]
+// [part_score | part_idx | part_cnt | need, light, off (b each), hlist (b + 1), arrive (b), dense_list (b), dense_n (1) | count (b x 32) | pool scores | pool documents]
 static size_t part_bytes(int b, int T, int k) {
-    size_t o = (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 20 + 4 + (size_t)b * kWvCountStride * 4;
+    size_t o = (size_t)b * T * k * 12 + (size_t)b * T * 4 + (size_t)b * 24 + 8 + (size_t)b * kWvCountStride * 4;
     o = (o + 255) & ~(size_t)255;
     return o + (size_t)wave_pool_capacity(b, T) * 12 + 64;
 }

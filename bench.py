@@ -491,7 +491,7 @@ def bm25_leg(np, torch, args, local_rank):
         # what bounds it: per (tile, query) a workgroup adds ~postings/ntiles float64 values into LDS one term after the
         # other (a barrier per term) and ranks the touched documents; HBM is far from busy (frac_of_hbm_peak above)
         "bound": "lds+latency (per-term LDS accumulation and block top-k, not HBM)",
-        "bound_evidence": "profiles/r02_bm25_pmc.md",
+        "bound_evidence": "profiles/r04_bm25_pmc.md",
     }
     return res, dev, (indptr, toks)
 
