@@ -40,6 +40,11 @@ DOC_BATCHES_PER_PASS = 64    # outer batches one shared encode may carry (8192 c
 # 20-30 of them, as many again must be tokenising for the next one: 32 -> 64 is 54k -> 57.5k chunks/s (128: 56.5k).  A leader
 # that waits a few ms for batches still being tokenised (instead of leaving with the first alone) was measured too: no gain.
 BUILD_IN_FLIGHT = 64
+# `build_embeddings` over more texts than this streams them through ONE tokeniser thread and ONE encoder caller in slabs
+# (BgeEncoder.embed_documents_stream): the group commit's first pass leaves with whatever one thread tokenised first - a few
+# hundred chunks in a pass that costs as much as a few thousand - and 64 threads take the interpreter lock in turn.
+STREAM_MIN_TEXTS = 2048
+STREAM_SLAB = 2048
 
 BGE_EMBEDDINGS_MODEL_NAME_OR_PATH = os.environ.get("BGE_EMBEDDINGS_MODEL_PATH", "epam/bge-small-en")
 
@@ -182,6 +187,43 @@ class BgeEncoder:
         texts = [t.replace("\n", " ") for t in texts]  # HuggingFaceBgeEmbeddings.embed_documents
         return list(self._doc_commit().submit(self._tokenize_packed(texts))[0])
 
+    def embed_documents_stream(self, texts: List[str], on_batches: Optional[Callable[[int], None]] = None) -> List[np.ndarray]:
+        """All chunk texts of ONE large document set (``build_embeddings`` with more than STREAM_MIN_TEXTS texts): a tokeniser
+        thread runs ahead in slabs of STREAM_SLAB texts (the first one a quarter as long, so the GPU starts early) while this
+        thread feeds the encoder slab after slab - the GPU waits for the first slab's tokenisation only.  The same
+        embeddings as ``embed_documents_numpy`` batch by batch (test_batching_is_invariant: an embedding does not depend on
+        what rides in its pass); `on_batches(n)` reports every n outer batches done, in order."""
+        import queue
+
+        texts = [t.replace("\n", " ") for t in texts]
+        cuts, at = [], 0
+        while at < len(texts):
+            step = STREAM_SLAB // 4 if at == 0 else STREAM_SLAB
+            cuts.append((at, min(len(texts), at + step)))
+            at += step
+        q: "queue.Queue" = queue.Queue(maxsize=3)
+
+        def tokenise():
+            try:
+                for a, b in cuts:
+                    q.put((a, b, self._tokenize_packed(texts[a:b])))
+            except BaseException as e:  # the consumer re-raises it
+                q.put(e)
+
+        t = threading.Thread(target=tokenise, name="bge-tokenise", daemon=True)
+        t.start()
+        out: List[np.ndarray] = []
+        for _ in cuts:
+            item = q.get()
+            if isinstance(item, BaseException):
+                raise item
+            a, b, (flat, lens) = item
+            out.extend(self.encode_packed(flat, lens))
+            if on_batches is not None:
+                on_batches((b + EMBEDDINGS_BATCH_SIZE - 1) // EMBEDDINGS_BATCH_SIZE - (a + EMBEDDINGS_BATCH_SIZE - 1) // EMBEDDINGS_BATCH_SIZE)
+        t.join()
+        return out
+
     def _doc_commit(self):
         gc = getattr(self, "_dc", None)
         if gc is None:
@@ -319,6 +361,15 @@ async def build_embeddings(texts: Iterable[str], stageio=None) -> List[np.ndarra
     batches = [texts[i : i + EMBEDDINGS_BATCH_SIZE] for i in range(0, len(texts), EMBEDDINGS_BATCH_SIZE)]
     if not batches:
         return []
+    impl = bge_embedding_impl()
+    if len(texts) > STREAM_MIN_TEXTS and hasattr(impl, "embed_documents_stream") and getattr(impl.tokenizer, "encode_packed", None):
+        bar = _progress(len(batches), stageio)
+        try:
+            return await asyncio.get_running_loop().run_in_executor(
+                _indexing_executor(), impl.embed_documents_stream, texts, (bar.update if bar is not None else None))
+        finally:
+            if bar is not None:
+                bar.close()
     gate = asyncio.Semaphore(BUILD_IN_FLIGHT)
 
     async def one(batch):

@@ -591,7 +591,8 @@ def build_embeddings_leg(np, torch, args, local_rank, tmpdir):
         ids = tok(texts[:1024], add_special_tokens=True, truncation=True, max_length=512)["input_ids"]
         t_tok = (time.perf_counter() - t1) / 1024
         res = {"chunks_per_s": rates[-1], "chunks_per_s_each_run": rates, "chunks": n, "outer_batch": emb.EMBEDDINGS_BATCH_SIZE,
-               "shared_encoder_passes": enc._doc_commit().passes - p0,
+               "route": ("streamed: one tokeniser thread ahead of one encoder caller, slabs of %d texts" % emb.STREAM_SLAB) if n > emb.STREAM_MIN_TEXTS
+                        else "group commit: %d shared encoder passes" % (enc._doc_commit().passes - p0),
                "mean_tokens_per_chunk": round(float(np.mean([len(x) for x in ids])), 1),
                "host_tokenise_us_per_chunk_1thread": round(t_tok * 1e6, 1),
                "note": "texts in, List[np.ndarray] out; includes WordPiece tokenisation (native, mir_wordpiece_encode) and result hand-over",
@@ -676,7 +677,7 @@ def both_builders_leg(np, asyncio, emb, words, rng, n):
             "note": "texts in -> TextIndexItem.tokenized_text out (TokenList views: list-like, a str object per DISTINCT token of a "
                     "4096-chunk batch, none per token); mir_keywords_preprocess + mir_kwp_result_dedupe on at most 16 host threads, "
                     "two batches in flight; `together` = asyncio.gather of both builders (documents.py:188-198), bounded by "
-                    "build_embeddings and the interpreter lock its 32 threads share with this one",
+                    "build_embeddings (streamed slabs: a tokeniser thread and an encoder caller) sharing the interpreter with this one",
             "ok": bool(len(items) == n and len(embs) == n and len(it2) == n and len(em2) == n)}
 
 

@@ -232,6 +232,14 @@ def test_build_embeddings_through_the_product_surface(setup, tmp_path, monkeypat
         assert cos.min() > 0.9995, cos
         alone = impl.encode_ids([ids[i] for i in pick])
         np.testing.assert_array_equal(np.stack([got[i] for i in pick]), alone)  # batching-invariant, bit for bit
+        # more than STREAM_MIN_TEXTS texts take the streamed form (one tokeniser thread ahead of one encoder caller, slabs):
+        # the same embeddings bit for bit, the same progress lines
+        monkeypatch.setattr(emb, "STREAM_MIN_TEXTS", 300)
+        monkeypatch.setattr(emb, "STREAM_SLAB", 256)
+        stage2 = io.StringIO()
+        got2 = asyncio.run(emb.build_embeddings(texts, stage2))
+        assert len(got2) == 700 and "6/6" in stage2.getvalue()
+        np.testing.assert_array_equal(np.stack(got2), np.stack(got))
         q = asyncio.run(emb.bge_embedding.aembed_query("what is the climate\nin the alps?"))
         assert isinstance(q, list) and len(q) == 384 and isinstance(q[0], float)
         qids = impl.tokenizer([emb.BGE_QUERY_INSTRUCTION_EN + "what is the climate in the alps?"])["input_ids"]
