@@ -20,7 +20,7 @@
 // Exactness.  T is a lower bound of the query's k-th best TRUE value (k rows at or above it are known), so all of
 // the true top k are at or above T, hence among the candidates, hence - by the same argument with kv - among the rows
 // evaluated and ordered exactly.  No candidate list is bounded by k: the only way to lose a row is a full buffer, which is
-// counted; the query then takes the exact pass (exact_topk_batch_kernel).  There is no "uncertain" outcome and no
+// counted; the query then takes the exact pass (exact_pass_kernel).  There is no "uncertain" outcome and no
 // completeness check.
 //
 // Thresholds, progressively (as the q16 scan): a 32K-row sample gives T0 (the k-th largest of 512 per-lane lower

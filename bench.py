@@ -315,8 +315,8 @@ def variant_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher, kind)
       clustered       4096 centres, intra-cluster cosine ~0.9, queries near centres: how much of the scan's speed
                       comes from thresholds that isotropic data makes easy
       near_duplicate  10 % of the rows in groups of 32 near-identical rows, half of the queries aimed at such a
-                      group: the k-th neighbour falls inside a group, which no float32 filter can order - those
-                      queries take the exact pass
+                      group: the k-th neighbour falls inside a group, which no float32 filter can order - the sieve's
+                      select evaluates the group in float64 (round 2's list scan sent those queries to the exact pass)
     Reports QPS, the roofline of the scan bracket, the share of queries answered by the exact pass, and - on the
     host, with the CPU oracle over ALL rows - identity of the ids for two queries."""
     from oracle import embeddings_index as oracle_index
