@@ -285,10 +285,18 @@ static int32_t build_i8(mir_index *ix, hipStream_t stream) {
     i8_scale_kernel<<<dim3(1), dim3(1), 0, stream>>>(ix->d_i8stats, ix->d_maxnorm);
     const int64_t lanes = (int64_t)ix->n_stages * 2 * ix->ks64 * 2 * 64;
     pack_i8_kernel<<<dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ks64, lanes, ix->d_i8stats, ix->d_i8);
-    i8_residual_kernel<<<dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->d_dnorm, ix->d_i8stats);
+    i8_residual_kernel<<<dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->d_dnorm, ix->d_docsq, ix->d_i8stats);
     MIR_HIP(hipGetLastError());
+    float st[kI8StatWords] = {};
+    MIR_HIP(hipMemcpyAsync(st, ix->d_i8stats, sizeof(st), hipMemcpyDeviceToHost, stream));
     MIR_HIP(hipStreamSynchronize(stream));
-    ix->i8 = true;
+    // the integer test takes the smallest squared norm for every row's: rows of ONE norm only (normalised embeddings)
+    ix->i8 = st[7] > 0.f && st[1] - st[7] <= 1e-3f * st[1];
+    if (!ix->i8) {
+        (void)hipFree(ix->d_i8);
+        ix->d_i8 = nullptr;
+        ix->hbm_bytes -= image;
+    }
     return MIR_OK;
 }
 
@@ -324,9 +332,7 @@ struct SearchBuffers {
     double *q_sq;    // [b]
     double *q_err;   // [b] |q - bf16(q)|: what the hi fragments lose on the query's side (layout16; the sieve's margin)
     double *q_norm;  // [b]
-    float *q_amax;   // [b] the int8 filter: a query's largest |q_i| (-1: not finite)
-    float *i8_call;  // [kI8CallWords] its per-call constants
-    int32_t *c_col;  // [n_stages * 64] its squared-L2 C operand column for this call's query scale
+    float *q_amax;   // [b] the int8 filter: a query's largest |q_i| (-1: not finite); its scales go to `qscale`
     float *qscale;   // [b] 1 / (query scale) of the float16-native scan
     uint64_t *part;  // [ngroups][nwg][qpw][klist]
     uint64_t *gthr;  // [ngroups][128] shared per-query thresholds of the 128-query scan; the control words below
@@ -375,8 +381,6 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.q_err = c.take<double>(b);
     sb.q_norm = c.take<double>(b);
     sb.q_amax = c.take<float>(i8_rows ? b : 0);
-    sb.i8_call = c.take<float>(i8_rows ? kI8CallWords : 0);
-    sb.c_col = c.take<int32_t>(i8_rows);
     sb.qscale = c.take<float>((size_t)ngroups * std::max(128, qpw));
     sb.part = c.take<uint64_t>(pl.sieve ? 0 : (size_t)ngroups * nwg * qpw * klist);  // per-workgroup lists of the list scans (the sieve has its own regions: 33.5 MB per launch group saved)
     // one zeroed control block: gthr | nflag | arrive[b] | sieve over[b] | sieve count[b][32]  (u32 arrays padded to u64)
@@ -395,9 +399,10 @@ static size_t carve(SearchBuffers &sb, char *base, int b, int k, int d, int kste
     sb.qt = c.take<double>((size_t)((b + kXbQ - 1) / kXbQ) * xb_dpad(d) * kXbQ);
     sb.part_sample = c.take<uint64_t>(std::max((size_t)kSampleWgs * 128 * klist, (size_t)kSampleWgs * std::max(128, qpw)));  // (the sieve's sample: two floats per workgroup and query)
     const size_t sv_q = pl.sieve ? (size_t)b * kSieveQueryCap : 0;
-    sb.sv_cand = c.take<uint64_t>(pl.sieve ? (size_t)2 * nwg * kSieveRegion : 0);
-    sb.sv_candv = c.take<float>(pl.sieve ? (size_t)2 * nwg * kSieveRegion : 0);
-    sb.sv_ccount = c.take<uint32_t>(pl.sieve ? (size_t)2 * nwg : 0);
+    const size_t region = i8_rows ? (size_t)kI8Region : (size_t)kSieveRegion;  // (the int8 filter: eight wave-private parts per workgroup)
+    sb.sv_cand = c.take<uint64_t>(pl.sieve ? (size_t)2 * nwg * region : 0);
+    sb.sv_candv = c.take<float>(pl.sieve ? (size_t)2 * nwg * region : 0);
+    sb.sv_ccount = c.take<uint32_t>(pl.sieve ? (size_t)2 * nwg * (i8_rows ? 8 : 1) : 0);
     sb.sv.rv = c.take<float>(sv_q);
     sb.sv.row = c.take<uint32_t>(sv_q);
     if (host_api) {
@@ -582,7 +587,7 @@ static int32_t launch_sieve(const mir_index *ix, int qpw, const uint4 *qsplit_g,
 
 // the int8 filter's launch over 64-row stages [stage0, stage0 + n_stages) (vec_kernels_i8.h)
 template <int KIND>
-static int32_t launch_sieve_i8(const mir_index *ix, int qpw, const SearchBuffers &sb, const uint4 *qfrag_g, const double *q_norm_g,
+static int32_t launch_sieve_i8(const mir_index *ix, int qpw, const float *q_scale_g, const uint4 *qfrag_g, const double *q_norm_g,
                                const double *q_sq_g, const double *q_err_g, int nq, int nwg, uint32_t stage0, uint32_t n_stages,
                                int nan_guard, const uint64_t *gthr_g, uint64_t *cand, float *candv, uint32_t *ccount, float *part_sample,
                                bool sample, unsigned long long *stat, hipStream_t stream) {
@@ -595,7 +600,7 @@ static int32_t launch_sieve_i8(const mir_index *ix, int qpw, const SearchBuffers
     case KS: {                                                                                                         \
         auto kern = MIR_I8_PICK(KS);                                                                                   \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_i8, sb.c_col, qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, sb.i8_call, n_rows, \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_i8, ix->d_docsq, qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, q_scale_g, n_rows, \
                                                     stage0, n_stages, nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat); \
         break;                                                                                                         \
     }
@@ -768,16 +773,12 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         return MIR_OK;
     }
     // the int8 first stage serves this call: the shard has the image, the metric ranks in the rows' own units
-    const bool use_i8 = ix->i8 && pl.sieve && metric != MIR_METRIC_COSINE_SIM && sb.c_col != nullptr;
+    const bool use_i8 = ix->i8 && pl.sieve && metric != MIR_METRIC_COSINE_SIM && sb.q_amax != nullptr;
     if (use_i8) {
         const int ntiles16 = ngroups * (qpw / 16);
         prep_queries_i8_stats_kernel<<<dim3(std::max(b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(dq, b, d, sb.q_sq, sb.q_norm, sb.q_amax, gz, gwords);
-        prep_queries_i8_quant_kernel<<<dim3(ntiles16 * ix->ks64 + b), dim3(64), 0, stream>>>(dq, b, d, ix->ks64, ntiles16, sb.q_amax, ix->d_i8stats,
-                                                                                            sb.qsplit, sb.q_err, sb.i8_call);
-        if (metric != MIR_METRIC_INNER_PRODUCT) {
-            const int64_t n_pad = (int64_t)ix->n_stages * 64;
-            i8_c_column_kernel<<<dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, stream>>>(ix->d_docsq, n_pad, ix->n, sb.i8_call, sb.c_col);
-        }
+        prep_queries_i8_quant_kernel<<<dim3(ntiles16 * ix->ks64 + b), dim3(64), 0, stream>>>(dq, b, d, ix->ks64, ntiles16, sb.q_amax, sb.qsplit,
+                                                                                            sb.q_err, sb.qscale);
     } else if (ix->layout16 && qpw >= kQ16Queries) {
         const int ks32 = ix->ksteps / 2, ntiles16 = ngroups * (qpw / 16);
         prep_queries16_kernel<<<dim3(std::max(ntiles16 * ks32 + b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(
@@ -832,8 +833,8 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                     const uint32_t s0 = t0 / 2, s1 = std::min<uint32_t>((t0 + nt + 1) / 2, ix->n_stages);
                     const uint4 *qf = sb.qsplit + (size_t)g * (qpw / 16) * ix->ks64 * 64;
                     if (metric == MIR_METRIC_INNER_PRODUCT)
-                        return launch_sieve_i8<SCAN_IP>(ix, qpw, sb, qf, qn, qsq, qerr, nq, wgs, s0, s1 - s0, guard, gt, cand, cv, cc, ps, smp, st, stream);
-                    return launch_sieve_i8<SCAN_L2>(ix, qpw, sb, qf, qn, qsq, qerr, nq, wgs, s0, s1 - s0, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                        return launch_sieve_i8<SCAN_IP>(ix, qpw, sb.qscale + q0, qf, qn, qsq, qerr, nq, wgs, s0, s1 - s0, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                    return launch_sieve_i8<SCAN_L2>(ix, qpw, sb.qscale + q0, qf, qn, qsq, qerr, nq, wgs, s0, s1 - s0, guard, gt, cand, cv, cc, ps, smp, st, stream);
                 }
                 if (ix->native16) {
                     if (metric == MIR_METRIC_INNER_PRODUCT) return launch_sieve16<SCAN_IP>(ix, qs16, qsc, qn, qsq, nq, wgs, t0, nt, guard, gt, cand, cv, cc, ps, smp, st, stream);
@@ -860,10 +861,10 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             sa.dnorm = (ix->native16 || !ix->norms_spread) ? nullptr : ix->d_dnorm;
             sa.q = dq; sa.q_sq = sb.q_sq; sa.q_norm = sb.q_norm; sa.max_norm = ix->d_maxnorm;
             sa.q_err = ix->native16 ? nullptr : sb.q_err;
-            sa.i8_call = nullptr;
-            if (use_i8) {  // the margin of the int8 filter's values: its statistics, its query residuals, one unit more (i8_margin)
+            sa.i8_qscale = nullptr;
+            if (use_i8) {  // the margin of the int8 filter's values: its statistics, its query residuals and scales (i8_margin)
                 sa.max_norm = ix->d_i8stats;
-                sa.i8_call = sb.i8_call;
+                sa.i8_qscale = sb.qscale;
                 sa.dnorm = nullptr;
             }
             sa.gthr = reinterpret_cast<unsigned long long *>(gt);
@@ -878,9 +879,10 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             rc = begin_profile();
             if (rc != MIR_OK) return rc;
             for (int phase = pl.tiles_first ? 0 : 1; phase < 2 && rc == MIR_OK; ++phase) {  // (one launch: the final phase alone)
-                uint64_t *cand = sb.sv_cand + (size_t)phase * nwg * kSieveRegion;
-                float *cv = sb.sv_candv + (size_t)phase * nwg * kSieveRegion;
-                uint32_t *cc = sb.sv_ccount + (size_t)phase * nwg;
+                const size_t region = use_i8 ? (size_t)kI8Region : (size_t)kSieveRegion;
+                uint64_t *cand = sb.sv_cand + (size_t)phase * nwg * region;
+                float *cv = sb.sv_candv + (size_t)phase * nwg * region;
+                uint32_t *cc = sb.sv_ccount + (size_t)phase * nwg * (use_i8 ? 8 : 1);
                 rc = phase == 0 ? sieve(0, pl.tiles_first, nwg, cand, cv, cc, false)
                                 : sieve(pl.tiles_first, ix->n_tiles - pl.tiles_first, nwg, cand, cv, cc, false);
                 if (rc != MIR_OK) break;
@@ -891,7 +893,8 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                     ev1 = nullptr;
                 }
                 ca.cand = cand; ca.candv = cv; ca.ccount = cc;
-                sieve_scatter_kernel<<<dim3(nwg * kSieveScatterSplit), dim3(256), 0, stream>>>(ca);
+                if (use_i8) sieve_scatter_i8_kernel<<<dim3(nwg * 8), dim3(256), 0, stream>>>(ca);
+                else sieve_scatter_kernel<<<dim3(nwg * kSieveScatterSplit), dim3(256), 0, stream>>>(ca);
                 sa.mode = phase;
                 MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sieve_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)sieve_select_lds_bytes()));

@@ -7,30 +7,28 @@
 // KS64 * 2 blocks of 1 KiB: block (s, rh) = k-step of 64 columns s, row half rh: 64 lanes x 16 int8, lane l = (row 16 rh + (l & 15),
 // columns 64 s + 16 (l >> 4) .. + 15) - the A operand of the MFMA (any in-lane order would do: the B operand is packed the
 // same way and a dot product does not care).  An LDS stage is TWO tiles (64 rows, 24 KiB at d = 384).
-// Queries: q ~ s_q Q with one scale per CALL (the largest |q_i| of the batch / 127), B-operand fragments per 16 queries.
+// Queries: q ~ s_q Q with a scale per QUERY (its largest |q_i| / 127), B-operand fragments per 16 queries.
 //
-// Exactness.  I = X.Q is exact (int32; |I| <= 127^2 d < 2^24 for d <= 1024).  With x^ = s_x X, q^ = s_q Q:
+// Exactness.  I = X.Q is exact (int32; |I| <= 127^2 d < 2^24 for d <= 1024, so its float32 conversion is exact too).  With
+// x^ = s_x X, q^ = s_q Q:
 //   x.q - s_x s_q I = (x - x^).q + x^.(q - q^),  |.| <= |x - x^| |q| + (|x| + |x - x^|) |q - q^|   (Cauchy-Schwarz)
 // - hihi_margin()'s formula with the int8 residuals in place of the bf16 ones: the largest |x - x^| over the rows and the
 // largest |x - x^| / |x| are measured at build time (i8 statistics words 2, 3), |q - q^| per query at prep time.  Squared L2
-// ranks 2 x.q - |x|^2 (|x|^2 the float32 value the reference formula uses): per CALL a pre-pass writes an int32 column
-// C'[row] = floor((nb - |x|^2) H + 1/2), H = 1 / (2 s_x s_q), nb = the index's largest squared norm (any constant would do: it
-// keeps C' small, so that it is exact in float32 and the accumulator far from overflow), clamped at 2^24; the accumulators START
-// at C' (the MFMA's C operand, read from LDS with the stage: no arithmetic in the filter), and 2 s_x s_q (I + C') - VOFF is the
-// ranking value to within three units (i8_call: VOFF absorbs nb and the rounding of H).  A row at the clamp (its norm far below
-// the others': |x|^2 < nb - 2^24 / H) always passes, and listing it sends its query to the exact pass.  The filter compares
-// INTEGERS with a bound rounded down; whatever it lets through is re-tested in float exactly as the bf16 filter does, listed with its float value v and its margin, and goes through the same
-// scatter and select (vec_kernels_sieve.h): every listed row's true value lies in [v - mg, v + mg], and the rows select cannot
-// exclude get the reference's float64 formula from the float32 rows.
+// ranks v = 2 x.q - |x|^2 (|x|^2 the float32 value the reference formula uses).  The common path compares INTEGERS: v >= bound
+// implies 2 s_x s_q I >= bound + |x|^2 >= bound + amin, amin = the index's smallest squared norm, i.e. I >= ib with ib the
+// integer part of (bound + amin) / (2 s_x s_q) rounded down: one maximum of eight accumulators and one compare per lane, no
+// arithmetic on the values.  Whatever passes is redone in float exactly as the bf16 filter does it (v = 2 s_x s_q I - |x|^2 per
+// row, one rounding), listed with v and its margin, and goes through the scatter and select of vec_kernels_sieve.h: every listed
+// row's true value lies in [v - mg, v + mg], and the rows select cannot exclude get the reference's float64 formula from the
+// float32 rows.  The integer test is conservative by (|x|^2 - amin) / (2 s_x s_q) units, which is why the image is built only
+// for shards whose squared norms agree to 1e-3 (normalised embeddings: to 1e-7).
 //
-// Served: float32 shards the bf16 sieve serves (d padded to 128 / 256 / 384, >= 32K rows) whose rows are finite and whose
-// norms are not spread (one margin per query), squared L2 / euclidean / inner product.  Everything else - cosine, spread
-// norms, the wide and the float16-native shards - stays on the bf16 / float16 filters.
+// Served: float32 shards the bf16 sieve serves (d padded to 128 / 256 / 384, >= 32K rows) whose rows are finite and of one
+// norm, squared L2 / euclidean / inner product.  Everything else - cosine, other norms, the wide and the float16-native
+// shards - stays on the bf16 / float16 filters.
 //
 // STATUS: an experiment, built only when MIR_SIEVE_I8=1 is set at index build (tests/test_gpu_sieve.py runs it against the
-// oracle).  Measured on 10M x 384 unit rows, 256 queries per step (profiles/r04_i8_sieve.md): the filter loop alone runs a pass in
-// 1.00 ms against the bf16 filter's 1.80 - and the rigorous margin (0.0226 |x||q| against bf16's 0.0038) lists 5.3k + 8.8k
-// candidates per query instead of 330 + 289, whose emission, scatter and selection take the 0.8 ms back.  Not the default.
+// oracle); measurements in profiles/r04_i8_sieve.md.
 #pragma once
 #include "vec_kernels_sieve.h"
 
@@ -38,20 +36,16 @@ namespace mir {
 
 typedef int __attribute__((ext_vector_type(4))) i32x4;
 
-// i8 statistics (floats): [0] largest row norm, [1] 0, [2] largest |x - x^|, [3] largest |x - x^| / |x| - the layout hihi_margin()
-// reads - [4] s_x, [5] 1 / s_x, [6] largest |x_i| (as bits while it is being reduced)
+// i8 statistics (floats): [0] largest row norm, [1] largest squared norm (float32 doc_sq), [2] largest |x - x^|, [3] largest
+// |x - x^| / |x| - the layout hihi_margin() reads - [4] s_x, [5] 1 / s_x, [6] largest |x_i|, [7] smallest squared norm
+// (words 1, 2, 3, 6, 7 are reduced as float bits: non-negative floats order as their bits)
 constexpr int kI8StatWords = 8;
-// per call (floats): [0] U = s_x s_q (one unit of I), [1] H = fl(1 / (2 U)), [2] K = fl(nb H + 1/2), [3] VOFF = 2 U K - nb (2 U H - 1)
-// (computed in float64), [4] s_q, [5] 1 / s_q
-constexpr int kI8CallWords = 8;
-constexpr int kI8Clamp = 1 << 24;            // C' never exceeds this (float32 holds it exactly)
-constexpr int kI8MaxDot = 127 * 127 * 384;   // |I| <= this (d <= 384): an accumulator >= kI8Clamp - kI8MaxDot belongs to a clamped row
-constexpr uint32_t kI8ClampRow = 0xffffffffu;  // a candidate with this row sends its query to the exact pass (sieve_scatter_kernel)
-
+constexpr int kI8Region = 32768;       // candidates a workgroup can write per launch: eight wave-private parts of 4096
+constexpr int kI8WavePart = kI8Region / 8;
 // the filter's margin in the ranking units of `l2` / inner product: the rounding residuals (hihi_margin) + the units lost to
 // the integer C operand and to the float conversion of the value
 __device__ __forceinline__ float i8_margin(bool l2, float qn, float eq, const float *__restrict__ stats, float unit) {
-    return hihi_margin(false, l2, qn, eq, stats) + (l2 ? 6.0f : 2.0f) * unit;
+    return hihi_margin(false, l2, qn, eq, stats) + (l2 ? 4.0f : 2.0f) * unit;
 }
 
 __global__ __launch_bounds__(256) void i8_absmax_kernel(const float *__restrict__ src, int64_t total, unsigned int *__restrict__ out_bits) {
@@ -77,7 +71,7 @@ __global__ void i8_scale_kernel(float *__restrict__ stats, const float *__restri
     stats[4] = s;
     stats[5] = 1.0f / s;
     stats[0] = max_norm[0];
-    stats[1] = 0.f;
+    stats[7] = __builtin_inff();  // (a minimum over float bits)
 }
 
 __device__ __forceinline__ int i8_quant(float x, float inv) {
@@ -112,7 +106,7 @@ __global__ __launch_bounds__(256) void pack_i8_kernel(const float *__restrict__ 
 
 // per row: |x - s_x X| and its ratio to |x| -> the maxima (statistics words 2, 3; float bits, non-negative).  16 lanes per row.
 __global__ __launch_bounds__(256) void i8_residual_kernel(const float *__restrict__ src, int64_t n, int d, const float *__restrict__ dnorm,
-                                                          float *__restrict__ stats) {
+                                                          const float *__restrict__ doc_sq, float *__restrict__ stats) {
     const int lg = threadIdx.x & 15;
     const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const float s = stats[4], inv = stats[5];
@@ -129,6 +123,8 @@ __global__ __launch_bounds__(256) void i8_residual_kernel(const float *__restric
         const float nm = dnorm[row];
         atomicMax(reinterpret_cast<unsigned int *>(stats) + 2, __float_as_uint(e));
         if (nm > 0.f) atomicMax(reinterpret_cast<unsigned int *>(stats) + 3, __float_as_uint(e / nm * (1.0f + 1e-6f)));
+        atomicMax(reinterpret_cast<unsigned int *>(stats) + 1, __float_as_uint(doc_sq[row]));
+        atomicMin(reinterpret_cast<unsigned int *>(stats) + 7, __float_as_uint(doc_sq[row]));
     }
 }
 
@@ -163,25 +159,20 @@ __global__ __launch_bounds__(64) void prep_queries_i8_stats_kernel(const double 
     }
 }
 // Kernel 2.  Blocks [0, ntiles16 * ks64): B-operand fragments of query tile w, k-step s: lane l = (query 16 w + (l & 15), columns
-// 64 s + 16 (l >> 4) .. + 15).  Blocks [ntiles16 * ks64, + b): the query's residual |q - s_q Q| in float64; the first of them
-// also writes the call's constants.
+// 64 s + 16 (l >> 4) .. + 15), every query with its own scale.  Blocks [ntiles16 * ks64, + b): the query's scale and its
+// residual |q - s_q Q| in float64.
 __global__ __launch_bounds__(64) void prep_queries_i8_quant_kernel(const double *__restrict__ q, int b, int d, int ks64, int ntiles16,
-                                                                   const float *__restrict__ q_amax, const float *__restrict__ stats,
-                                                                   uint4 *__restrict__ qfrag, double *__restrict__ q_err,
-                                                                   float *__restrict__ call) {
+                                                                   const float *__restrict__ q_amax, uint4 *__restrict__ qfrag,
+                                                                   double *__restrict__ q_err, float *__restrict__ q_scale) {
     const int lane = threadIdx.x, blk = blockIdx.x;
-    float m = 0.f;
-    for (int i = lane; i < b; i += 64) m = fmaxf(m, q_amax[i]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    const float sq = m > 0.f ? m / 127.0f : 1.0f;
-    const float inv = 1.0f / sq;
     if (blk < ntiles16 * ks64) {
         const int s = blk % ks64, w = blk / ks64;
         const int qi = 16 * w + (lane & 15);
         const int col0 = 64 * s + 16 * (lane >> 4);
         uint32_t wv[4] = {0u, 0u, 0u, 0u};
-        if (qi < b && q_amax[qi] >= 0.f) {
+        const float m = qi < b ? q_amax[qi] : -1.0f;
+        if (m >= 0.f) {
+            const float inv = m > 0.f ? 127.0f / m : 1.0f;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const float x = col0 + j < d ? (float)q[(int64_t)qi * d + col0 + j] : 0.f;
@@ -192,52 +183,35 @@ __global__ __launch_bounds__(64) void prep_queries_i8_quant_kernel(const double 
     } else {
         const int qi = blk - ntiles16 * ks64;
         if (qi >= b) return;
-        double e2 = 0.0;
-        const bool ok = q_amax[qi] >= 0.f;
+        const float m = q_amax[qi];
+        const bool ok = m >= 0.f;
+        const float inv = m > 0.f ? 127.0f / m : 1.0f;   // (the same value the fragment blocks use)
+        const float sq = 1.0f / inv;                     // the scale the filter and select multiply with: Q was made with `inv`,
+        double e2 = 0.0;                                 // the residual below is measured against THIS sq
         for (int j = lane; j < d; j += 64) {
             const double x = q[(int64_t)qi * d + j];
             const double r = ok ? x - (double)sq * (double)i8_quant((float)x, inv) : x;  // ((float)x: what the fragment was made from)
             e2 += r * r;
         }
         e2 = wave_sum(e2);
-        if (lane == 0) q_err[qi] = sqrt(e2);
-        if (qi == 0 && lane == 0) {
-            const float U = stats[4] * sq, H = 0.5f / U, nb = stats[0] * stats[0];
-            const float K = nb * H + 0.5f;
-            call[0] = U;
-            call[1] = H;
-            call[2] = K;
-            call[3] = (float)(2.0 * (double)U * (double)K - (double)nb * (2.0 * (double)U * (double)H - 1.0));
-            call[4] = sq;
-            call[5] = inv;
+        if (lane == 0) {
+            q_err[qi] = sqrt(e2);
+            q_scale[qi] = sq;
         }
     }
-}
-
-// squared L2, once per call: C'[row] for the call's query scale (see the header).  Rows past n: the clamp (they pass the integer
-// test and are dropped by the row bound).
-__global__ __launch_bounds__(256) void i8_c_column_kernel(const float *__restrict__ doc_sq, int64_t n_pad, int64_t n,
-                                                          const float *__restrict__ call, int32_t *__restrict__ out) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_pad) return;
-    const float H = call[1], K = call[2];
-    int c = kI8Clamp;
-    if (r < n) {
-        const float f = floorf(fmaf(doc_sq[r], -H, K));
-        c = f < (float)kI8Clamp ? (int)f : kI8Clamp;  // (a NaN norm: the clamp; the index is finite where this filter runs)
-    }
-    out[r] = c;
 }
 
 // ---- the filter ----
 __host__ __device__ constexpr size_t sieve_i8_lds_bytes(int ks64) { return (size_t)kSieveStages * (ks64 * 4 * 1024 + (64 + 8) * 4) + 64; }
 
 // QT = query tiles (16 queries each) per wave, as sieve_q16_kernel.  KS64 = k-steps of 64 columns (2, 4, 6).
+// Candidates: every wave writes its own part of the workgroup's region (kI8WavePart entries; the count is wave-uniform: no
+// LDS atomic on the emit path), ccount[workgroup][8].
 template <int KS64, int KIND, bool SAMPLE, int QT>
-__global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restrict__ docs, const int32_t *__restrict__ aux,
+__global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
                                                           const uint4 *__restrict__ qfrag, const double *__restrict__ q_norm,
                                                           const double *__restrict__ q_sq, const double *__restrict__ q_err,
-                                                          const float *__restrict__ stats, const float *__restrict__ call,
+                                                          const float *__restrict__ stats, const float *__restrict__ q_scale,
                                                           uint32_t n_rows, uint32_t stage0, uint32_t n_stages, int nq, int nan_guard,
                                                           const uint64_t *__restrict__ gthr, uint64_t *__restrict__ cand,
                                                           float *__restrict__ candv, uint32_t *__restrict__ ccount,
@@ -249,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
     constexpr int SB = NB * 2;             // per stage (two tiles)
     constexpr int STAGE_U4 = SB * 64;
     constexpr int PPW = SB / 8;            // 1-KiB DMA pieces per wave per stage
-    constexpr bool AUX = KIND == SCAN_L2;  // the stage's 64 C' values (i8_c_column_kernel) travel with it: lanes 0..7 of every wave bring 8 of them
+    constexpr bool AUX = KIND == SCAN_L2;  // the stage's 64 squared norms travel with it: lanes 0..7 of every wave bring 8 of them
     constexpr int PW = PPW + (AUX ? 1 : 0);
     constexpr int AS = 64 + 8;
     constexpr int D = NS - 1;
@@ -257,21 +231,17 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
     static_assert(SB % 8 == 0, "sieve_i8: d padded to a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *ring = reinterpret_cast<uint4 *>(smem);
-    int32_t *aux_lds = reinterpret_cast<int32_t *>(smem + (size_t)NS * STAGE_U4 * 16);
-    uint32_t *s_count = reinterpret_cast<uint32_t *>(aux_lds + NS * AS);
+    float *aux_lds = reinterpret_cast<float *>(smem + (size_t)NS * STAGE_U4 * 16);
 
     const int tid = threadIdx.x, lane = tid & 63, qc = lane & 15, jg = lane >> 4;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t G = gridDim.x;
-    if (tid == 0) *s_count = 0;
 
-    const float unit = call[0];                                  // one unit of I in inner-product units
-    const float vs = KIND == SCAN_L2 ? 2.0f * unit : unit;       // an accumulator -> the ranking value: v = vs * acc - voff
-    const float voff = KIND == SCAN_L2 ? call[3] : 0.f;
+    const float amin = KIND == SCAN_L2 ? stats[7] : 0.f;  // the smallest squared norm of the index
     int qloc[QT];
     bool lane_live[QT];
     unsigned long long live_mask[QT];
-    float mg[QT], bound[QT], guard[QT], best[QT];
+    float mg[QT], bound[QT], guard[QT], best[QT], vs[QT];  // vs: an accumulator -> 2 x.q (squared L2) / x.q in float
     int ib[QT];  // the integer form of the bound, rounded down (everything the float test below would pass passes it)
     i32x4 qh[QT][KS64];
     const bool active = nq > wave8 * QT * 16;
@@ -281,18 +251,20 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
         qloc[u] = t16 * 16 + qc;
         lane_live[u] = qloc[u] < nq;
         live_mask[u] = __builtin_amdgcn_ballot_w64(lane_live[u]);
-        mg[u] = 0.f; bound[u] = -__builtin_inff(); guard[u] = __builtin_inff(); best[u] = -__builtin_inff();
+        mg[u] = 0.f; bound[u] = -__builtin_inff(); guard[u] = __builtin_inff(); best[u] = -__builtin_inff(); vs[u] = 1.0f;
         ib[u] = (int)0x80000000;
         if (lane_live[u]) {
             const float qn = (float)q_norm[qloc[u]] * (1.0f + 1e-6f);
             const float eq = (float)q_err[qloc[u]] * (1.0f + 1e-6f);
+            const float unit = stats[4] * q_scale[qloc[u]];  // one unit of I in inner-product units
+            vs[u] = KIND == SCAN_L2 ? 2.0f * unit : unit;
             mg[u] = i8_margin(KIND == SCAN_L2, qn, eq, stats, unit);
             if (!SAMPLE) {
                 const uint64_t key = gthr[qloc[u]];
                 if (key != 0) {
                     const float t = key_value(key);
                     bound[u] = t - mg[u] - 2e-6f * fabsf(t);
-                    const float bi = floorf((bound[u] + voff) / vs) - 2.0f;  // (a NaN or infinite query: mg is NaN or infinite, the bound stays at its minimum)
+                    const float bi = floorf((bound[u] + amin) / vs[u]) - 2.0f;  // (a NaN or infinite query: mg is NaN or infinite, the bound stays at its minimum)
                     if (bi > -2.0e9f && bi < 2.0e9f) ib[u] = (int)bi;
                     else if (bi >= 2.0e9f) ib[u] = 0x7fffffff;
                 }
@@ -331,20 +303,21 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
         if (younger == (uint32_t)(D - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    uint64_t *region = cand + (size_t)blockIdx.x * kSieveRegion;
-    float *regionv = candv + (size_t)blockIdx.x * kSieveRegion;
+    uint64_t *region = cand + ((size_t)blockIdx.x * 8 + wave8) * kI8WavePart;
+    float *regionv = candv + ((size_t)blockIdx.x * 8 + wave8) * kI8WavePart;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t wcount = 0;  // (wave-uniform) candidates this wave has written; beyond kI8WavePart they are counted, not stored
 
     // The filter of one 32-row tile and query tile, one tile late (as sieve_q16_kernel's): eight int32 accumulators against the
     // lane's integer bound - a maximum and ONE compare; what passes is redone in float
-    auto filter = [&](int u, const i32x4 &c0, const i32x4 &c1, uint32_t t) {
+    auto filter = [&](int u, const i32x4 &c0, const i32x4 &c1, const float (&ax)[8], uint32_t t) {
         if (SAMPLE) {
             if (lane_live[u]) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const int a = r < 4 ? c0[r & 3] : c1[r & 3];
-                    const float w = fmaf(vs, (float)a, -voff);
-                    if (w + mg[u] < guard[u] && a < kI8Clamp - kI8MaxDot) best[u] = fmaxf(best[u], w - mg[u]);  // (a clamped row's value is not its own)
+                    const float fi = (float)(r < 4 ? c0[r & 3] : c1[r & 3]);
+                    const float w = KIND == SCAN_L2 ? fmaf(vs[u], fi, -ax[r]) : vs[u] * fi;
+                    if (w + mg[u] < guard[u]) best[u] = fmaxf(best[u], w - mg[u]);
                 }
             }
             return;
@@ -354,12 +327,10 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
         if ((__builtin_amdgcn_ballot_w64(m >= ib[u]) & live_mask[u]) == 0ull) return;
         asm volatile("" : "+s"(t));  // (the rare path below depends on t: nothing of it is computed ahead of the branch)
         float v[8];
-        uint32_t clamped = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int a = r < 4 ? c0[r & 3] : c1[r & 3];
-            v[r] = fmaf(vs, (float)a, -voff);
-            clamped |= (uint32_t)(KIND == SCAN_L2 && a >= kI8Clamp - kI8MaxDot) << r;
+            const float fi = (float)(r < 4 ? c0[r & 3] : c1[r & 3]);
+            v[r] = KIND == SCAN_L2 ? fmaf(vs[u], fi, -ax[r]) : vs[u] * fi;
         }
         uint32_t pm = 0;
 #pragma unroll
@@ -376,27 +347,23 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
             const bool has = pm != 0;
             const int r = has ? __builtin_ctz(pm) : 0;
             const unsigned long long bal = __ballot(has);
-            const int leader = __builtin_ctzll(bal);
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(s_count, (uint32_t)__popcll(bal));
-            base = __shfl(base, leader, 64);
-            const uint32_t slot = base + (uint32_t)__popcll(bal & lt_mask);
+            const uint32_t slot = wcount + (uint32_t)__popcll(bal & lt_mask);
+            wcount += (uint32_t)__popcll(bal);
             float vr = v[0];
 #pragma unroll
             for (int i = 1; i < 8; ++i) vr = r == i ? v[i] : vr;
-            if (has && slot < (uint32_t)kSieveRegion) {
-                // (a row at the clamp: its value is a lower bound only - the marker hands the query to the exact pass)
-                const uint32_t row = (clamped >> r) & 1u ? kI8ClampRow : row0 + 16 * (r >> 2) + (r & 3);
-                region[slot] = ((uint64_t)(uint32_t)qloc[u] << 32) | (uint64_t)row;
+            if (has && slot < (uint32_t)kI8WavePart) {
+                region[slot] = ((uint64_t)(uint32_t)qloc[u] << 32) | (uint64_t)(row0 + 16 * (r >> 2) + (r & 3));
                 regionv[slot] = vr;
             }
             pm &= pm - 1;
         }
     };
 
-    i32x4 p0[QT], p1[QT];  // the previous tile's accumulators and its index
+    i32x4 p0[QT], p1[QT];  // the previous tile's accumulators, squared norms and index
 #pragma unroll
     for (int u = 0; u < QT; ++u) { p0[u] = i32x4{0, 0, 0, 0}; p1[u] = i32x4{0, 0, 0, 0}; }
+    float pax[8] = {};
     uint32_t pt = 0;
     bool have_prev = false;
     for (uint32_t g = 0; g < my_stages; ++g) {
@@ -414,16 +381,16 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
             uint4 f0[PF + 1], f1[PF + 1];
 #pragma unroll
             for (int i = 0; i < PF; ++i) { f0[i] = st[(2 * i + 0) * 64]; f1[i] = st[(2 * i + 1) * 64]; }
-            i32x4 c0[QT], c1[QT];
-            if (AUX) {  // rows 32 sub + 16 rh + 4 jg + i of this stage: the accumulators start at C'
-                const i32x4 n0 = *reinterpret_cast<const i32x4 *>(aux_lds + (g % NS) * AS + 32 * sub + 4 * jg);
-                const i32x4 n1 = *reinterpret_cast<const i32x4 *>(aux_lds + (g % NS) * AS + 32 * sub + 16 + 4 * jg);
-#pragma unroll
-                for (int u = 0; u < QT; ++u) { c0[u] = n0; c1[u] = n1; }
-            } else {
-#pragma unroll
-                for (int u = 0; u < QT; ++u) { c0[u] = i32x4{0, 0, 0, 0}; c1[u] = i32x4{0, 0, 0, 0}; }
+            float cax[8] = {};
+            if (AUX) {  // rows 32 sub + 16 rh + 4 jg + i of this stage
+                const float4 a0 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * AS + 32 * sub + 4 * jg);
+                const float4 a1 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * AS + 32 * sub + 16 + 4 * jg);
+                cax[0] = a0.x; cax[1] = a0.y; cax[2] = a0.z; cax[3] = a0.w;
+                cax[4] = a1.x; cax[5] = a1.y; cax[6] = a1.z; cax[7] = a1.w;
             }
+            i32x4 c0[QT], c1[QT];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) { c0[u] = i32x4{0, 0, 0, 0}; c1[u] = i32x4{0, 0, 0, 0}; }
 #pragma unroll
             for (int s = 0; s < KS64; ++s) {
                 if (s + PF < KS64) {
@@ -444,22 +411,24 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
                 for (int u = 0; u < QT; ++u)
                     if (s == 1 + u && s < KS64 && have_prev) {  // the previous tile's filter, one query tile per k-step
                         __builtin_amdgcn_sched_barrier(0);
-                        filter(u, p0[u], p1[u], pt);
+                        filter(u, p0[u], p1[u], pax, pt);
                     }
             }
             if (KS64 < QT + 1 && have_prev) {  // (two k-steps per tile: the second query tile's filter did not fit above)
 #pragma unroll
-                for (int u = KS64 - 1; u < QT; ++u) filter(u, p0[u], p1[u], pt);
+                for (int u = KS64 - 1; u < QT; ++u) filter(u, p0[u], p1[u], pax, pt);
             }
 #pragma unroll
             for (int u = 0; u < QT; ++u) { p0[u] = c0[u]; p1[u] = c1[u]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pax[i] = cax[i];
             pt = stage * 2 + sub;
             have_prev = true;
         }
     }
     if (have_prev) {
 #pragma unroll
-        for (int u = 0; u < QT; ++u) filter(u, p0[u], p1[u], pt);
+        for (int u = 0; u < QT; ++u) filter(u, p0[u], p1[u], pax, pt);
     }
     if (SAMPLE) {
 #pragma unroll
@@ -470,10 +439,46 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
         }
         return;
     }
+    if (lane == 0) {
+        ccount[(size_t)blockIdx.x * 8 + wave8] = wcount;  // may exceed kI8WavePart: the scatter then hands every query to the exact pass
+        if (stat && wcount) atomicAdd(stat, (unsigned long long)wcount);
+    }
+}
+
+// The scatter behind the int8 filter: a workgroup's candidates lie in eight wave-private parts.  One block per (workgroup, part):
+// count the part's candidates per query in LDS, reserve each query's range of its list with ONE atomic, then place them.
+// (A thread and an atomic per candidate, sieve_scatter_kernel's way, took 157 us per launch at 8.8k candidates per query.)
+__global__ __launch_bounds__(256) void sieve_scatter_i8_kernel(SieveScatterArgs a) {
+    __shared__ uint32_t s_cnt[256], s_base[256];
+    const int tid = threadIdx.x;
+    const int part = blockIdx.x;  // (region x 8 + wave)
+    uint32_t cnt = a.ccount[part];
+    s_cnt[tid] = 0;
     __syncthreads();
-    if (tid == 0) {
-        ccount[blockIdx.x] = *s_count;
-        if (stat && *s_count) atomicAdd(stat, (unsigned long long)*s_count);
+    if (cnt > (uint32_t)kI8WavePart) {  // the part overflowed: whose candidates were lost is unknown
+        for (int i = tid; i < a.nq; i += 256) a.l.over[a.q0 + i] = 1;
+        cnt = kI8WavePart;
+    }
+    const uint64_t *region = a.cand + (size_t)part * kI8WavePart;
+    const float *regionv = a.candv + (size_t)part * kI8WavePart;
+    for (uint32_t e = tid; e < cnt; e += 256) atomicAdd(&s_cnt[(int)(region[e] >> 32) & 255], 1u);
+    __syncthreads();
+    {
+        const uint32_t c = s_cnt[tid];
+        s_base[tid] = c ? atomicAdd(&a.l.count[(size_t)(a.q0 + tid) * kSieveCountStride], c) : 0u;
+        s_cnt[tid] = 0;
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < cnt; e += 256) {
+        const uint64_t key = region[e];
+        const int ql = (int)(key >> 32) & 255, qi = a.q0 + ql;
+        const uint32_t slot = s_base[ql] + atomicAdd(&s_cnt[ql], 1u);
+        if (slot < (uint32_t)kSieveQueryCap) {
+            a.l.row[(size_t)qi * kSieveQueryCap + slot] = (uint32_t)key;
+            a.l.rv[(size_t)qi * kSieveQueryCap + slot] = regionv[e];
+        } else {
+            a.l.over[qi] = 1;
+        }
     }
 }
 

@@ -644,10 +644,6 @@ __global__ __launch_bounds__(256) void sieve_scatter_kernel(SieveScatterArgs a) 
         const uint64_t key = region[e];
         const float v = regionv[e];
         const int qi = a.q0 + (int)(key >> 32);
-        if ((uint32_t)key == 0xffffffffu) {  // the int8 filter's marker (vec_kernels_i8.h, kI8ClampRow): this query takes the exact pass
-            a.l.over[qi] = 1;
-            continue;
-        }
         const uint32_t slot = atomicAdd(&a.l.count[(size_t)qi * kSieveCountStride], 1u);
         if (slot < (uint32_t)kSieveQueryCap) {
             a.l.row[(size_t)qi * kSieveQueryCap + slot] = (uint32_t)key;
@@ -806,7 +802,7 @@ struct SieveSelectArgs {
     float rel_err;                 // the float16 filter's bound (kH16RelErr); a float32 index: the margin of hihi_margin()
     float extra_slop;              // wide float32 shards (d > 384): the longer float32 accumulation's share of the margin, relative (wide_accum_slop)
     const double *q_err;           // [b] |q - bf16(q)| (float32 index; |q - s_q Q| behind the int8 filter), or null
-    const float *i8_call;          // the int8 filter's per-call constants (vec_kernels_i8.h: max_norm then holds ITS statistics), or null
+    const float *i8_qscale;        // [b] the int8 filter's query scales (vec_kernels_i8.h: max_norm then holds ITS statistics), or null
     const float *docs;             // f32 [n][d], or null with
     const _Float16 *docs16;        // f16 [n][d] (float16-native index)
     const float *doc_sq;
@@ -909,7 +905,7 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
     };
     const float qn = (float)a.q_norm[qi] * (1.0f + 1e-6f);
     const bool l2 = !(a.metric == MIR_METRIC_INNER_PRODUCT || a.metric == MIR_METRIC_COSINE_SIM);
-    const float mg = a.i8_call ? hihi_margin(false, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) + (l2 ? 6.0f : 2.0f) * a.i8_call[0]  // (= i8_margin)
+    const float mg = a.i8_qscale ? hihi_margin(false, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) + (l2 ? 4.0f : 2.0f) * a.max_norm[4] * a.i8_qscale[qi]  // (= i8_margin)
                    : a.q_err ? hihi_margin(a.metric == MIR_METRIC_COSINE_SIM, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) +
                                    a.extra_slop * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) * (l2 ? 2.0f : 1.0f)
                              : a.rel_err * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) * (l2 ? 2.0f : 1.0f);  // (as the filter's)
