@@ -112,6 +112,7 @@ struct mir_index {
     bool i8 = false;
     uint4 *d_i8 = nullptr;       // n_stages x 2 tiles x ks64 * 2 blocks of 1 KiB
     float *d_i8stats = nullptr;  // kI8StatWords floats
+    float4 *d_i8tp = nullptr;    // [n_stages * 2] tile parameters (scale, residual bound, 1 / (2 scale))
     int ks64 = 0;
     uint32_t n_stages = 0;       // 64-row stages = ceil(n_tiles / 2)
     unsigned long long *d_stats = nullptr;  // 8 counters of the sieve (mir_index_scan_stats)
@@ -167,6 +168,7 @@ static void free_index(mir_index *ix) {
     (void)hipFree(ix->d_tilemax);
     (void)hipFree(ix->d_i8);
     (void)hipFree(ix->d_i8stats);
+    (void)hipFree(ix->d_i8tp);
     (void)hipFree(ix->d_hi16);
     (void)hipFree(ix->d_maxnorm);
     (void)hipFree(ix->d_stats);
@@ -212,7 +214,7 @@ static int32_t build_derived(mir_index *ix, hipStream_t stream) {
                  ix->n_tiles >= 4u * kSampleWgs && getenv("MIR_NO_SIEVE") == nullptr && getenv("MIR_NO_SIEVE_WIDE") == nullptr;
     ix->ks16 = ix->wide16 ? (d + 511) / 512 * 32 : 0;
     const size_t split_bytes = ix->wide16 ? 16 : (size_t)ix->n_tiles * ix->ksteps * ((ix->native16 || ix->hi_only) ? 1024 : 2048);
-    const size_t aux_bytes = (size_t)ix->n_tiles * kTileRows * sizeof(float);
+    const size_t aux_bytes = (size_t)(ix->n_tiles + 1) * kTileRows * sizeof(float);  // (one tile more: the int8 filter reads 64-row stages)
     MIR_HIP(hipMalloc(&ix->d_split, std::max<size_t>(split_bytes, 16)));
     MIR_HIP(hipMalloc(&ix->d_docsq, std::max<size_t>(aux_bytes, 16)));
     MIR_HIP(hipMalloc(&ix->d_invnorm, std::max<size_t>(aux_bytes, 16)));
@@ -278,14 +280,14 @@ static int32_t build_i8(mir_index *ix, hipStream_t stream) {
     const size_t image = (size_t)ix->n_stages * 2 * ix->ks64 * 2 * 1024;
     MIR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8), image));
     MIR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8stats), kI8StatWords * 4));
-    ix->hbm_bytes += image + kI8StatWords * 4;
+    MIR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8tp), (size_t)ix->n_stages * 2 * 16));
+    ix->hbm_bytes += image + kI8StatWords * 4 + (size_t)ix->n_stages * 2 * 16;
     MIR_HIP(hipMemsetAsync(ix->d_i8stats, 0, kI8StatWords * 4, stream));
-    i8_absmax_kernel<<<dim3((unsigned)std::min<int64_t>(4096, (n * d / 4 + 255) / 256 + 1)), dim3(256), 0, stream>>>(
-        ix->d_orig, n * (int64_t)d, reinterpret_cast<unsigned int *>(ix->d_i8stats) + 6);
+    i8_tile_scale_kernel<<<dim3(ix->n_stages * 2), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->d_i8tp);
     i8_scale_kernel<<<dim3(1), dim3(1), 0, stream>>>(ix->d_i8stats, ix->d_maxnorm);
     const int64_t lanes = (int64_t)ix->n_stages * 2 * ix->ks64 * 2 * 64;
-    pack_i8_kernel<<<dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ks64, lanes, ix->d_i8stats, ix->d_i8);
-    i8_residual_kernel<<<dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->d_dnorm, ix->d_docsq, ix->d_i8stats);
+    pack_i8_kernel<<<dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->ks64, lanes, ix->d_i8tp, ix->d_i8);
+    i8_residual_kernel<<<dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream>>>(ix->d_orig, n, d, ix->d_docsq, ix->d_i8tp, ix->d_i8stats);
     MIR_HIP(hipGetLastError());
     float st[kI8StatWords] = {};
     MIR_HIP(hipMemcpyAsync(st, ix->d_i8stats, sizeof(st), hipMemcpyDeviceToHost, stream));
@@ -294,8 +296,10 @@ static int32_t build_i8(mir_index *ix, hipStream_t stream) {
     ix->i8 = st[7] > 0.f && st[1] - st[7] <= 1e-3f * st[1];
     if (!ix->i8) {
         (void)hipFree(ix->d_i8);
+        (void)hipFree(ix->d_i8tp);
         ix->d_i8 = nullptr;
-        ix->hbm_bytes -= image;
+        ix->d_i8tp = nullptr;
+        ix->hbm_bytes -= image + (size_t)ix->n_stages * 2 * 16;
     }
     return MIR_OK;
 }
@@ -600,7 +604,7 @@ static int32_t launch_sieve_i8(const mir_index *ix, int qpw, const float *q_scal
     case KS: {                                                                                                         \
         auto kern = MIR_I8_PICK(KS);                                                                                   \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_i8, ix->d_docsq, qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, q_scale_g, n_rows, \
+        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_i8, ix->d_docsq, ix->d_i8tp, qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, q_scale_g, n_rows, \
                                                     stage0, n_stages, nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat); \
         break;                                                                                                         \
     }
@@ -862,9 +866,11 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
             sa.q = dq; sa.q_sq = sb.q_sq; sa.q_norm = sb.q_norm; sa.max_norm = ix->d_maxnorm;
             sa.q_err = ix->native16 ? nullptr : sb.q_err;
             sa.i8_qscale = nullptr;
+            sa.i8_tparam = nullptr;
             if (use_i8) {  // the margin of the int8 filter's values: its statistics, its query residuals and scales (i8_margin)
                 sa.max_norm = ix->d_i8stats;
                 sa.i8_qscale = sb.qscale;
+                sa.i8_tparam = ix->d_i8tp;
                 sa.dnorm = nullptr;
             }
             sa.gthr = reinterpret_cast<unsigned long long *>(gt);
@@ -1276,9 +1282,9 @@ static int32_t create_common(const RowSource &src, int64_t n, int32_t d, int32_t
             return fail(MIR_ERR_HIP);
         }
         ix->norms_spread = !(st[0] <= 1.0625f * st[4]) || getenv("MIR_SIEVE_PER_TILE") != nullptr;  // (NaN / infinite norms: spread)
-        // the int8 first stage is an EXPERIMENT (round 4): exact, its raw filter loop 1.8 x the bf16 one's rate, and no
-        // faster end to end - its rigorous margin lists ~20 x the candidates.  Built only on request (read per build: tests switch it)
-        const bool i8_on = getenv("MIR_SIEVE_I8") != nullptr && atoi(getenv("MIR_SIEVE_I8")) == 1;
+        // the int8 first stage (vec_kernels_i8.h) serves the squared-L2 / euclidean / inner-product searches of a shard of finite rows
+        // of one norm; MIR_SIEVE_I8=0 keeps the bf16 filter for everything (read per build: tests and A/B runs switch it)
+        const bool i8_on = !(getenv("MIR_SIEVE_I8") != nullptr && atoi(getenv("MIR_SIEVE_I8")) == 0);
         unsigned int nonfinite = 0;
         memcpy(&nonfinite, &st[1], 4);
         if (ix->hi_only && !ix->norms_spread && nonfinite == 0u && st[0] > 0.f && i8_on) {

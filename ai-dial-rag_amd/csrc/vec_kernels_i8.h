@@ -3,7 +3,8 @@
 // The bf16 filter at 256 queries per pass is limited by the chip's POWER (its matrix work beside its HBM stream hold the clock
 // at 1.84-1.89 GHz, profiles/r04_sieve_mfma_pmc.md): fewer bytes and cheaper arithmetic per row are what is left.
 //
-// Image.  x ~ s_x X with ONE scale per index, s_x = max |x_i| / 127, X = round(x / s_x) in [-127, 127]; 32-row tiles of
+// Image.  x ~ s_t X with one scale per 32-row TILE, s_t = (the tile's largest |x_i|) / 127, X = round(x / s_t) in [-127, 127]
+// (one scale per index lists 2.3 x the candidates: the largest component of 10M rows is 1.5 x a tile's); 32-row tiles of
 // KS64 * 2 blocks of 1 KiB: block (s, rh) = k-step of 64 columns s, row half rh: 64 lanes x 16 int8, lane l = (row 16 rh + (l & 15),
 // columns 64 s + 16 (l >> 4) .. + 15) - the A operand of the MFMA (any in-lane order would do: the B operand is packed the
 // same way and a dot product does not care).  An LDS stage is TWO tiles (64 rows, 24 KiB at d = 384).
@@ -12,15 +13,17 @@
 // Exactness.  I = X.Q is exact (int32; |I| <= 127^2 d < 2^24 for d <= 1024, so its float32 conversion is exact too).  With
 // x^ = s_x X, q^ = s_q Q:
 //   x.q - s_x s_q I = (x - x^).q + x^.(q - q^),  |.| <= |x - x^| |q| + (|x| + |x - x^|) |q - q^|   (Cauchy-Schwarz)
-// - hihi_margin()'s formula with the int8 residuals in place of the bf16 ones: the largest |x - x^| over the rows and the
-// largest |x - x^| / |x| are measured at build time (i8 statistics words 2, 3), |q - q^| per query at prep time.  Squared L2
+// - hihi_margin()'s formula with the int8 residuals in place of the bf16 ones: e_t = the largest |x - x^| over a TILE's rows is
+// measured at build time (i8 tile parameters), |q - q^| per query at prep time; a row's margin is its tile's,
+// mg_t = e_t (|q| + |q - q^|) + |x|max |q - q^| (+ slop) + 2 units (i8_margin_tile).  Squared L2
 // ranks v = 2 x.q - |x|^2 (|x|^2 the float32 value the reference formula uses).  The common path compares INTEGERS: v >= bound
-// implies 2 s_x s_q I >= bound + |x|^2 >= bound + amin, amin = the index's smallest squared norm, i.e. I >= ib with ib the
-// integer part of (bound + amin) / (2 s_x s_q) rounded down: one maximum of eight accumulators and one compare per lane, no
-// arithmetic on the values.  Whatever passes is redone in float exactly as the bf16 filter does it (v = 2 s_x s_q I - |x|^2 per
+// implies 2 s_t s_q I >= bound_t + |x|^2 >= bound_t + amin, amin = the index's smallest squared norm, i.e. I >= ib with ib the
+// integer part of (bound_t + amin) / (2 s_t s_q) rounded down - four vector instructions per tile and query tile - then one
+// maximum of eight accumulators and one compare per lane, no arithmetic on the values.  Whatever passes is redone in float
+// exactly as the bf16 filter does it (v = 2 s_t s_q I - |x|^2 per
 // row, one rounding), listed with v and its margin, and goes through the scatter and select of vec_kernels_sieve.h: every listed
 // row's true value lies in [v - mg, v + mg], and the rows select cannot exclude get the reference's float64 formula from the
-// float32 rows.  The integer test is conservative by (|x|^2 - amin) / (2 s_x s_q) units, which is why the image is built only
+// float32 rows.  The integer test is conservative by (|x|^2 - amin) / (2 s_t s_q) units, which is why the image is built only
 // for shards whose squared norms agree to 1e-3 (normalised embeddings: to 1e-7).
 //
 // Served: float32 shards the bf16 sieve serves (d padded to 128 / 256 / 384, >= 32K rows) whose rows are finite and of one
@@ -36,42 +39,46 @@ namespace mir {
 
 typedef int __attribute__((ext_vector_type(4))) i32x4;
 
-// i8 statistics (floats): [0] largest row norm, [1] largest squared norm (float32 doc_sq), [2] largest |x - x^|, [3] largest
-// |x - x^| / |x| - the layout hihi_margin() reads - [4] s_x, [5] 1 / s_x, [6] largest |x_i|, [7] smallest squared norm
-// (words 1, 2, 3, 6, 7 are reduced as float bits: non-negative floats order as their bits)
+// i8 statistics (floats): [0] largest row norm, [1] largest squared norm (float32 doc_sq), [2] largest |x - x^| (information),
+// [7] smallest squared norm (words 1, 2, 7 are reduced as float bits: non-negative floats order as their bits)
 constexpr int kI8StatWords = 8;
+// tile parameters (float4 per 32-row tile): x = s_t, y = e_t (largest |x - x^| of its rows, rounded up), z = 1 / (2 s_t), w = -
 constexpr int kI8Region = 32768;       // candidates a workgroup can write per launch: eight wave-private parts of 4096
 constexpr int kI8WavePart = kI8Region / 8;
-// the filter's margin in the ranking units of `l2` / inner product: the rounding residuals (hihi_margin) + the units lost to
-// the integer C operand and to the float conversion of the value
-__device__ __forceinline__ float i8_margin(bool l2, float qn, float eq, const float *__restrict__ stats, float unit) {
-    return hihi_margin(false, l2, qn, eq, stats) + (l2 ? 4.0f : 2.0f) * unit;
+// The margin of a row of a tile with residual bound e_t and scale s_t, in inner-product units, as mg_t = e_t * A + B + 2 s_t s_q:
+//   A = (|q| + |q - q^|) (1 + 1e-5), B = (|x|max |q - q^| + 3e-5 |x|max |q|) (1 + 1e-5)  [hihi_margin's terms, regrouped by e_t]
+// (x 2 in squared-L2 units).  The filter and the select kernel both compute it from these two per-query numbers.
+__device__ __forceinline__ void i8_margin_ab(float qn, float eq, const float *__restrict__ stats, float &A, float &B) {
+    i8_margin_ab_decl(qn, eq, stats, A, B);  // (defined in vec_kernels_sieve.h: the select kernel computes the same margin)
+}
+__device__ __forceinline__ float i8_margin_tile(bool l2, float A, float B, float e_t, float s_t, float sq) {
+    const float m = fmaf(e_t, A, B) + 2.0f * s_t * sq;
+    return l2 ? 2.0f * m : m;
 }
 
-__global__ __launch_bounds__(256) void i8_absmax_kernel(const float *__restrict__ src, int64_t total, unsigned int *__restrict__ out_bits) {
+// one block per 32-row tile: s_t from the tile's largest |x_i| (an all-zero tile: 1)
+__global__ __launch_bounds__(256) void i8_tile_scale_kernel(const float *__restrict__ src, int64_t n, int d, float4 *__restrict__ tparam) {
+    __shared__ float red[4];
+    const int64_t tile = blockIdx.x;
+    const int64_t r0 = tile * kTileRows;
+    const int64_t rows = n - r0 < kTileRows ? n - r0 : kTileRows;
+    const float *p = src + r0 * (int64_t)d;
     float m = 0.f;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    if ((total & 3) == 0) {
-        const float4 *p = reinterpret_cast<const float4 *>(src);
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total / 4; i += stride) {
-            const float4 v = p[i];
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-        }
-    } else {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) m = fmaxf(m, fabsf(src[i]));
-    }
+    for (int64_t i = threadIdx.x; i < rows * d; i += 256) m = fmaxf(m, fabsf(p[i]));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));  // (non-negative floats order as their bits)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float st = m > 0.f ? m / 127.0f : 1.0f;
+        tparam[tile] = make_float4(st, 0.f, 0.5f / st, 0.f);
+    }
 }
-// stats[6] (bits of the largest |x_i|) -> the scale; stats[0] = the index's largest norm
+// statistics: [0] the index's largest norm, [7] a minimum over float bits
 __global__ void i8_scale_kernel(float *__restrict__ stats, const float *__restrict__ max_norm) {
-    const float m = stats[6];
-    const float s = m > 0.f ? m / 127.0f : 1.0f;
-    stats[4] = s;
-    stats[5] = 1.0f / s;
     stats[0] = max_norm[0];
-    stats[7] = __builtin_inff();  // (a minimum over float bits)
+    stats[7] = __builtin_inff();
 }
 
 __device__ __forceinline__ int i8_quant(float x, float inv) {
@@ -81,10 +88,9 @@ __device__ __forceinline__ int i8_quant(float x, float inv) {
 
 // f32 [n][d] -> the int8 image.  One thread per (tile, block, lane); columns past d and rows past n are 0.
 __global__ __launch_bounds__(256) void pack_i8_kernel(const float *__restrict__ src, int64_t n, int d, int ks64, int64_t total_lanes,
-                                                      const float *__restrict__ stats, uint4 *__restrict__ dst) {
+                                                      const float4 *__restrict__ tparam, uint4 *__restrict__ dst) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total_lanes) return;
-    const float inv = stats[5];
     const int lane = (int)(gid & 63);
     const int64_t blk = gid >> 6;
     const int nb = ks64 * 2;
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(256) void pack_i8_kernel(const float *__restrict__ 
     const int col0 = 64 * s + 16 * (lane >> 4);
     uint32_t w[4] = {0u, 0u, 0u, 0u};
     if (row < n) {
+        const float inv = 1.0f / tparam[tile].x;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float x = col0 + j < d ? src[row * (int64_t)d + col0 + j] : 0.f;
@@ -104,25 +111,27 @@ __global__ __launch_bounds__(256) void pack_i8_kernel(const float *__restrict__ 
     dst[blk * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// per row: |x - s_x X| and its ratio to |x| -> the maxima (statistics words 2, 3; float bits, non-negative).  16 lanes per row.
-__global__ __launch_bounds__(256) void i8_residual_kernel(const float *__restrict__ src, int64_t n, int d, const float *__restrict__ dnorm,
-                                                          const float *__restrict__ doc_sq, float *__restrict__ stats) {
+// per row: |x - s_t X| -> its tile's maximum (tparam.y, as float bits: non-negative floats order as their bits); the index's
+// largest and smallest squared norm (statistics words 1, 7).  16 lanes per row.
+__global__ __launch_bounds__(256) void i8_residual_kernel(const float *__restrict__ src, int64_t n, int d, const float *__restrict__ doc_sq,
+                                                          float4 *__restrict__ tparam, float *__restrict__ stats) {
     const int lg = threadIdx.x & 15;
     const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const float s = stats[4], inv = stats[5];
     double e2 = 0.0;
-    if (row < n)
+    if (row < n) {
+        const float s = tparam[row / kTileRows].x;
+        const float inv = 1.0f / s;  // (as pack_i8_kernel)
         for (int j = lg; j < d; j += 16) {
             const float x = src[row * (int64_t)d + j];
             const double r = (double)x - (double)s * (double)i8_quant(x, inv);
             e2 += r * r;
         }
+    }
     e2 = group_sum<16>(e2);
     if (lg == 0 && row < n) {
         const float e = (float)sqrt(e2) * (1.0f + 1e-6f);
-        const float nm = dnorm[row];
+        atomicMax(reinterpret_cast<unsigned int *>(&tparam[row / kTileRows].y), __float_as_uint(e));
         atomicMax(reinterpret_cast<unsigned int *>(stats) + 2, __float_as_uint(e));
-        if (nm > 0.f) atomicMax(reinterpret_cast<unsigned int *>(stats) + 3, __float_as_uint(e / nm * (1.0f + 1e-6f)));
         atomicMax(reinterpret_cast<unsigned int *>(stats) + 1, __float_as_uint(doc_sq[row]));
         atomicMin(reinterpret_cast<unsigned int *>(stats) + 7, __float_as_uint(doc_sq[row]));
     }
@@ -209,6 +218,7 @@ __host__ __device__ constexpr size_t sieve_i8_lds_bytes(int ks64) { return (size
 // LDS atomic on the emit path), ccount[workgroup][8].
 template <int KS64, int KIND, bool SAMPLE, int QT>
 __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
+                                                          const float4 *__restrict__ tparam,
                                                           const uint4 *__restrict__ qfrag, const double *__restrict__ q_norm,
                                                           const double *__restrict__ q_sq, const double *__restrict__ q_err,
                                                           const float *__restrict__ stats, const float *__restrict__ q_scale,
@@ -223,8 +233,9 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
     constexpr int SB = NB * 2;             // per stage (two tiles)
     constexpr int STAGE_U4 = SB * 64;
     constexpr int PPW = SB / 8;            // 1-KiB DMA pieces per wave per stage
-    constexpr bool AUX = KIND == SCAN_L2;  // the stage's 64 squared norms travel with it: lanes 0..7 of every wave bring 8 of them
-    constexpr int PW = PPW + (AUX ? 1 : 0);
+    // the stage's 64 squared norms travel with it (lanes 0..7 of every wave bring 8 of them; inner product never reads them) and,
+    // by the same instruction, its two tiles' parameters (lanes 8..15 of the last wave -> slots 64..71)
+    constexpr int PW = PPW + 1;
     constexpr int AS = 64 + 8;
     constexpr int D = NS - 1;
     constexpr int QPL = 128 * QT;
@@ -241,8 +252,10 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
     int qloc[QT];
     bool lane_live[QT];
     unsigned long long live_mask[QT];
-    float mg[QT], bound[QT], guard[QT], best[QT], vs[QT];  // vs: an accumulator -> 2 x.q (squared L2) / x.q in float
-    int ib[QT];  // the integer form of the bound, rounded down (everything the float test below would pass passes it)
+    constexpr float L = KIND == SCAN_L2 ? 2.0f : 1.0f;  // ranking units per inner-product unit
+    // per query: its scale, the margin's two coefficients (i8_margin_ab), the threshold with its rounding slack, and the two
+    // numbers the per-tile integer bound is made of: ib_t = floor((P1 - e_t A1) / s_t) - 4 (see the header)
+    float sq[QT], mA[QT], mB[QT], tb[QT], P1[QT], A1[QT], guard[QT], best[QT];
     i32x4 qh[QT][KS64];
     const bool active = nq > wave8 * QT * 16;
 #pragma unroll
@@ -251,22 +264,22 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
         qloc[u] = t16 * 16 + qc;
         lane_live[u] = qloc[u] < nq;
         live_mask[u] = __builtin_amdgcn_ballot_w64(lane_live[u]);
-        mg[u] = 0.f; bound[u] = -__builtin_inff(); guard[u] = __builtin_inff(); best[u] = -__builtin_inff(); vs[u] = 1.0f;
-        ib[u] = (int)0x80000000;
+        sq[u] = 1.0f; mA[u] = 0.f; mB[u] = 0.f; tb[u] = -__builtin_inff(); P1[u] = -__builtin_inff(); A1[u] = 0.f;
+        guard[u] = __builtin_inff(); best[u] = -__builtin_inff();
         if (lane_live[u]) {
             const float qn = (float)q_norm[qloc[u]] * (1.0f + 1e-6f);
             const float eq = (float)q_err[qloc[u]] * (1.0f + 1e-6f);
-            const float unit = stats[4] * q_scale[qloc[u]];  // one unit of I in inner-product units
-            vs[u] = KIND == SCAN_L2 ? 2.0f * unit : unit;
-            mg[u] = i8_margin(KIND == SCAN_L2, qn, eq, stats, unit);
+            const bool good = qn < __builtin_inff() && eq < __builtin_inff();  // (false for a NaN too: such a query passes everything, as in the bf16 filter)
+            sq[u] = q_scale[qloc[u]];
+            if (good) i8_margin_ab(qn, eq, stats, mA[u], mB[u]);
             if (!SAMPLE) {
                 const uint64_t key = gthr[qloc[u]];
-                if (key != 0) {
+                if (key != 0 && good) {
                     const float t = key_value(key);
-                    bound[u] = t - mg[u] - 2e-6f * fabsf(t);
-                    const float bi = floorf((bound[u] + amin) / vs[u]) - 2.0f;  // (a NaN or infinite query: mg is NaN or infinite, the bound stays at its minimum)
-                    if (bi > -2.0e9f && bi < 2.0e9f) ib[u] = (int)bi;
-                    else if (bi >= 2.0e9f) ib[u] = 0x7fffffff;
+                    tb[u] = t - 2e-6f * fabsf(t);
+                    P1[u] = (tb[u] + amin - L * mB[u]) / (L * sq[u]);
+                    A1[u] = mA[u] / sq[u];
+                    if (!(P1[u] == P1[u]) || !(A1[u] == A1[u])) { P1[u] = -__builtin_inff(); A1[u] = 0.f; tb[u] = -__builtin_inff(); }
                 }
             } else if (nan_guard) {
                 const float qs = (float)q_sq[qloc[u]];
@@ -286,9 +299,12 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave8 * PPW) * 64) * 16);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
-        if (AUX) {
+        {
             const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_addr_of(aux_lds) + ((g % NS) * AS + wave8 * 8) * 4);
-            if (lane < 8) glds4_b32(aux + (size_t)stage * 64 + wave8 * 8 + lane, adst);
+            const bool tp_lane = wave8 == 7 && lane >= 8 && lane < 16;
+            const float *src1 = tp_lane ? reinterpret_cast<const float *>(tparam) + (size_t)stage * 8 + (lane - 8)
+                                        : aux + (size_t)stage * 64 + wave8 * 8 + lane;
+            if (lane < 8 || tp_lane) glds4_b32(src1, adst);
         }
     };
 #pragma unroll
@@ -308,33 +324,39 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t wcount = 0;  // (wave-uniform) candidates this wave has written; beyond kI8WavePart they are counted, not stored
 
-    // The filter of one 32-row tile and query tile, one tile late (as sieve_q16_kernel's): eight int32 accumulators against the
-    // lane's integer bound - a maximum and ONE compare; what passes is redone in float
-    auto filter = [&](int u, const i32x4 &c0, const i32x4 &c1, const float (&ax)[8], uint32_t t) {
+    // The filter of one 32-row tile and query tile, one tile late (as sieve_q16_kernel's): the tile's integer bound from its scale
+    // and residual (four vector instructions), eight int32 accumulators against it - a maximum and ONE compare; what passes is
+    // redone in float.  tp = the tile's parameters (s_t, e_t, 1 / (2 s_t))
+    auto filter = [&](int u, const i32x4 &c0, const i32x4 &c1, const float (&ax)[8], uint32_t t, const float4 &tp) {
         if (SAMPLE) {
             if (lane_live[u]) {
+                const float vs = L * tp.x * sq[u], mg = i8_margin_tile(KIND == SCAN_L2, mA[u], mB[u], tp.y, tp.x, sq[u]);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const float fi = (float)(r < 4 ? c0[r & 3] : c1[r & 3]);
-                    const float w = KIND == SCAN_L2 ? fmaf(vs[u], fi, -ax[r]) : vs[u] * fi;
-                    if (w + mg[u] < guard[u]) best[u] = fmaxf(best[u], w - mg[u]);
+                    const float w = KIND == SCAN_L2 ? fmaf(vs, fi, -ax[r]) : vs * fi;
+                    if (w + mg < guard[u]) best[u] = fmaxf(best[u], w - mg);
                 }
             }
             return;
         }
+        const float x2 = fmaf(fmaf(-tp.y, A1[u], P1[u]), 2.0f * tp.z, -4.0f);
+        const int ib = (int)__builtin_amdgcn_fmed3f(floorf(x2), -2.0e9f, 2.0e9f);  // (no threshold / a bad query: -inf -> everything passes)
         const int m0 = max(max(c0[0], c0[1]), c0[2]), m1 = max(max(c0[3], c1[0]), c1[1]);
         const int m = max(max(max(c1[2], c1[3]), m0), m1);
-        if ((__builtin_amdgcn_ballot_w64(m >= ib[u]) & live_mask[u]) == 0ull) return;
+        if ((__builtin_amdgcn_ballot_w64(m >= ib) & live_mask[u]) == 0ull) return;
         asm volatile("" : "+s"(t));  // (the rare path below depends on t: nothing of it is computed ahead of the branch)
+        const float vs = L * tp.x * sq[u];
+        const float bound = tb[u] - i8_margin_tile(KIND == SCAN_L2, mA[u], mB[u], tp.y, tp.x, sq[u]);  // (tb = -inf: everything passes)
         float v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float fi = (float)(r < 4 ? c0[r & 3] : c1[r & 3]);
-            v[r] = KIND == SCAN_L2 ? fmaf(vs[u], fi, -ax[r]) : vs[u] * fi;
+            v[r] = KIND == SCAN_L2 ? fmaf(vs, fi, -ax[r]) : vs * fi;
         }
         uint32_t pm = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound[u])) << r;
+        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound)) << r;
         if (!lane_live[u]) pm = 0;
         if (!__any(pm != 0)) return;
         const uint32_t row0 = t * kTileRows + 4 * jg;  // this lane's rows: row0 + 16 rh + i
@@ -364,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
 #pragma unroll
     for (int u = 0; u < QT; ++u) { p0[u] = i32x4{0, 0, 0, 0}; p1[u] = i32x4{0, 0, 0, 0}; }
     float pax[8] = {};
+    float4 ptp = make_float4(1.f, 0.f, 0.5f, 0.f);
     uint32_t pt = 0;
     bool have_prev = false;
     for (uint32_t g = 0; g < my_stages; ++g) {
@@ -381,8 +404,9 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
             uint4 f0[PF + 1], f1[PF + 1];
 #pragma unroll
             for (int i = 0; i < PF; ++i) { f0[i] = st[(2 * i + 0) * 64]; f1[i] = st[(2 * i + 1) * 64]; }
+            const float4 ctp = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * AS + 64 + 4 * sub);  // this tile's parameters
             float cax[8] = {};
-            if (AUX) {  // rows 32 sub + 16 rh + 4 jg + i of this stage
+            if (KIND == SCAN_L2) {  // rows 32 sub + 16 rh + 4 jg + i of this stage
                 const float4 a0 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * AS + 32 * sub + 4 * jg);
                 const float4 a1 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * AS + 32 * sub + 16 + 4 * jg);
                 cax[0] = a0.x; cax[1] = a0.y; cax[2] = a0.z; cax[3] = a0.w;
@@ -411,24 +435,25 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
                 for (int u = 0; u < QT; ++u)
                     if (s == 1 + u && s < KS64 && have_prev) {  // the previous tile's filter, one query tile per k-step
                         __builtin_amdgcn_sched_barrier(0);
-                        filter(u, p0[u], p1[u], pax, pt);
+                        filter(u, p0[u], p1[u], pax, pt, ptp);
                     }
             }
             if (KS64 < QT + 1 && have_prev) {  // (two k-steps per tile: the second query tile's filter did not fit above)
 #pragma unroll
-                for (int u = KS64 - 1; u < QT; ++u) filter(u, p0[u], p1[u], pax, pt);
+                for (int u = KS64 - 1; u < QT; ++u) filter(u, p0[u], p1[u], pax, pt, ptp);
             }
 #pragma unroll
             for (int u = 0; u < QT; ++u) { p0[u] = c0[u]; p1[u] = c1[u]; }
 #pragma unroll
             for (int i = 0; i < 8; ++i) pax[i] = cax[i];
+            ptp = ctp;
             pt = stage * 2 + sub;
             have_prev = true;
         }
     }
     if (have_prev) {
 #pragma unroll
-        for (int u = 0; u < QT; ++u) filter(u, p0[u], p1[u], pax, pt);
+        for (int u = 0; u < QT; ++u) filter(u, p0[u], p1[u], pax, pt, ptp);
     }
     if (SAMPLE) {
 #pragma unroll

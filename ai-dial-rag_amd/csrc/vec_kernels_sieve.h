@@ -795,6 +795,11 @@ __device__ __forceinline__ double sieve_metric_g16(const T *__restrict__ row, co
 }
 
 // ---------------------------------------------------------------- select
+// (the int8 filter's margin coefficients - vec_kernels_i8.h, i8_margin_ab - are needed here too)
+__device__ __forceinline__ void i8_margin_ab_decl(float qn, float eq, const float *__restrict__ stats, float &A, float &B) {
+    A = (qn + eq) * (1.0f + 1e-5f) * MIR_MARGIN_SCALE;
+    B = (stats[0] * eq + 3.0e-5f * stats[0] * qn) * (1.0f + 1e-5f) * MIR_MARGIN_SCALE;
+}
 struct SieveSelectArgs {
     SieveLists l;
     int q0, nq, k, metric, mode;   // mode 0: thresholds for the next launch; 1: the result
@@ -803,6 +808,7 @@ struct SieveSelectArgs {
     float extra_slop;              // wide float32 shards (d > 384): the longer float32 accumulation's share of the margin, relative (wide_accum_slop)
     const double *q_err;           // [b] |q - bf16(q)| (float32 index; |q - s_q Q| behind the int8 filter), or null
     const float *i8_qscale;        // [b] the int8 filter's query scales (vec_kernels_i8.h: max_norm then holds ITS statistics), or null
+    const float4 *i8_tparam;       // [tiles] its tile parameters (s_t, e_t, ..): a row's margin is its tile's
     const float *docs;             // f32 [n][d], or null with
     const _Float16 *docs16;        // f16 [n][d] (float16-native index)
     const float *doc_sq;
@@ -905,16 +911,30 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
     };
     const float qn = (float)a.q_norm[qi] * (1.0f + 1e-6f);
     const bool l2 = !(a.metric == MIR_METRIC_INNER_PRODUCT || a.metric == MIR_METRIC_COSINE_SIM);
-    const float mg = a.i8_qscale ? hihi_margin(false, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) + (l2 ? 4.0f : 2.0f) * a.max_norm[4] * a.i8_qscale[qi]  // (= i8_margin)
-                   : a.q_err ? hihi_margin(a.metric == MIR_METRIC_COSINE_SIM, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) +
+    const float mg = a.q_err ? hihi_margin(a.metric == MIR_METRIC_COSINE_SIM, l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) +
                                    a.extra_slop * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) * (l2 ? 2.0f : 1.0f)
                              : a.rel_err * qn * (a.metric == MIR_METRIC_COSINE_SIM ? 1.0f : a.max_norm[0]) * (l2 ? 2.0f : 1.0f);  // (as the filter's)
     // Per-row margins (float32 index, inner product / squared L2): a row's true value lies within m = |x| * cq of its v (hihi_coeff);
     // the filter used the row's TILE maximum, which is no smaller.  Everything below is written in LOWER bounds lb = v - m and
     // UPPER bounds lb + 2 m; with one margin for all rows (cosine, float16-native) that is the round-3 arithmetic in other words.
-    const bool per_row = a.q_err != nullptr && a.dnorm != nullptr && a.metric != MIR_METRIC_COSINE_SIM;  // (dnorm: only where the filter ran per tile)
-    const float cq = per_row ? hihi_coeff(l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) : 0.f;
-    auto margin_of = [&](uint32_t row) { return per_row ? a.dnorm[row] * cq : mg; };
+    const bool i8 = a.i8_qscale != nullptr;  // behind the int8 filter: a row's margin is its tile's (i8_margin_tile, the filter's own formula)
+    const bool per_row = i8 || (a.q_err != nullptr && a.dnorm != nullptr && a.metric != MIR_METRIC_COSINE_SIM);  // (dnorm: only where the filter ran per tile)
+    const float cq = (per_row && !i8) ? hihi_coeff(l2, qn, (float)a.q_err[qi] * (1.0f + 1e-6f), a.max_norm) : 0.f;
+    float i8A = 0.f, i8B = 0.f;
+    const float i8sq = i8 ? a.i8_qscale[qi] : 0.f;
+    if (i8) {
+        const float eq = (float)a.q_err[qi] * (1.0f + 1e-6f);
+        if (qn < __builtin_inff() && eq < __builtin_inff()) i8_margin_ab_decl(qn, eq, a.max_norm, i8A, i8B);
+        else i8A = i8B = __builtin_inff();
+    }
+    auto margin_of = [&](uint32_t row) {
+        if (i8) {
+            const float4 tp = a.i8_tparam[row / kTileRows];
+            const float m = fmaf(tp.y, i8A, i8B) + 2.0f * tp.x * i8sq;
+            return l2 ? 2.0f * m : m;
+        }
+        return per_row ? a.dnorm[row] * cq : mg;
+    };
     const float eps_m = per_row ? 0.f : 1e-6f * mg;  // (per row: the margins carry their own 1e-6; an index-wide mg may be infinite there)
     float guard = __builtin_inff();
     if (a.nan_guard) {
