@@ -1474,6 +1474,7 @@ int32_t mir_index_scan_stats(mir_index *idx, int32_t reset, int64_t *out8) {
     MIR_HIP(hipDeviceSynchronize());
     MIR_HIP(hipMemcpy(out8, idx->d_stats, 64, hipMemcpyDeviceToHost));
     if (reset) MIR_HIP(hipMemset(idx->d_stats, 0, 64));
+    out8[6] = idx->i8 ? 1 : 0;  // the shard has the int8 image: its squared-L2 / euclidean / inner-product searches use the int8 first stage
     return MIR_OK;
 }
 

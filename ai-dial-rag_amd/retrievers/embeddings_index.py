@@ -176,7 +176,8 @@ class DeviceIndex:
                 "candidates_per_query_first_launch": round(float(out[0]) / q, 1),
                 "candidates_per_query_second_launch": round(float(out[1]) / q, 1),
                 "listed_per_query_after_first_launch": round(float(out[4]) / q, 1),
-                "evaluated_in_float64_per_query": round(float(out[5]) / q, 1)}
+                "evaluated_in_float64_per_query": round(float(out[5]) / q, 1),
+                "int8_first_stage": bool(out[6])}
 
     def metric_eval(self, query: np.ndarray, metric) -> np.ndarray:
         q = nat.as_f64_queries(query, self.d)[0]

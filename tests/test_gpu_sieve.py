@@ -42,8 +42,11 @@ def check(metric, q, docs, got, k, msg):
     np.testing.assert_allclose(dist[:cnt], alld[g], rtol=0, atol=5e-7 if metric == "cosine_sim" else 1e-9, equal_nan=True, err_msg=msg)
 
 
-@pytest.fixture(scope="module")
-def corpus():
+@pytest.fixture(scope="module", params=["bf16", "int8"])
+def corpus(request):
+    """Two forms of one corpus, one per first stage of the sieve: with a zero row and a NaN row the shard's norms are neither
+    finite nor equal and the bf16 filter serves it; without them (every row of norm 1 to 1e-7) the int8 filter does
+    (csrc/vec_kernels_i8.h; `scan_stats()["int8_first_stage"]`)."""
     rng = np.random.default_rng(77)
     docs = rng.standard_normal((N, 384)).astype(np.float32)
     docs /= np.linalg.norm(docs, axis=1, keepdims=True)
@@ -56,8 +59,9 @@ def corpus():
     dups = [17, 40_000, 300_000, 599_999]
     for p in dups:
         docs[p] = docs[dup_src]
-    docs[777] = 0.0            # a zero row (cosine: clamped norm)
-    docs[100_000, 5] = np.nan  # a NaN row: distance NaN, sorts last
+    if request.param == "bf16":
+        docs[777] = 0.0            # a zero row (cosine: clamped norm)
+        docs[100_000, 5] = np.nan  # a NaN row: distance NaN, sorts last
     qs = rng.standard_normal((12, 384))
     qs /= np.linalg.norm(qs, axis=1, keepdims=True)
     off = rng.standard_normal(384)
@@ -65,13 +69,14 @@ def corpus():
     qs[1] = docs[dup_src].astype(np.float64)                             # five bit-identical rows first; euclidean_dist: NaN quirk
     qs[2] = docs[dups[1]].astype(np.float64) * 3.0
     qs[3] = 0.0                                                          # zero query
-    return docs, qs, group, dups + [dup_src]
+    return docs, qs, group, dups + [dup_src], request.param == "int8"
 
 
 @pytest.mark.parametrize("metric", METRICS)
 def test_sieve_equals_oracle(ei, corpus, metric):
-    docs, qs, group, dups = corpus
+    docs, qs, group, dups, int8 = corpus
     ix = ei.DeviceIndex.from_host(docs)
+    assert ix.scan_stats()["int8_first_stage"] == int8
     for k in (10, 1, 64):
         with np.errstate(invalid="ignore"):
             out = ix.search(qs, k, metric)
@@ -87,7 +92,7 @@ def test_sieve_equals_oracle(ei, corpus, metric):
 
 
 def test_batch_sizes_groups_and_row_offset(ei, corpus):
-    docs, qs, _, _ = corpus
+    docs, qs, _, _, _ = corpus
     rng = np.random.default_rng(5)
     big = rng.standard_normal((300, 384))
     big[:12] = qs
@@ -258,7 +263,7 @@ def test_concurrent_searches_share_a_handle(ei, corpus):
     different batch sizes (one and two query tiles per wave, two launch groups) on one handle, each with its own workspace."""
     import threading
 
-    docs, qs, _, _ = corpus
+    docs, qs, _, _, _ = corpus
     rng = np.random.default_rng(12)
     big = rng.standard_normal((300, 384))
     big[:12] = qs
@@ -332,10 +337,32 @@ def test_worst_case_bf16_rounding(ei):
     ix.close()
 
 
+@pytest.mark.parametrize("d", [128, 200])
+def test_int8_first_stage_other_dimensions(ei, d, monkeypatch):
+    """Unit rows at d padded to 128 / 256 (two and four k-steps of 64 per tile), all metrics (cosine stays on the bf16 filter of
+    the same index), and the same index built with MIR_SIEVE_I8=0: both answer exactly."""
+    rng = np.random.default_rng(d)
+    docs = rng.standard_normal((N, d)).astype(np.float32)
+    docs /= np.linalg.norm(docs, axis=1, keepdims=True)
+    docs[4000] = docs[9]
+    qs = rng.standard_normal((70, d)) * 2.0
+    qs[0] = docs[9].astype(np.float64)
+    for on in (True, False):
+        monkeypatch.setenv("MIR_SIEVE_I8", "1" if on else "0")
+        ix = ei.DeviceIndex.from_host(docs)
+        assert ix.scan_stats()["int8_first_stage"] == on
+        for metric in METRICS:
+            out = ix.search(qs, 7, metric)
+            assert int(out[5].sum()) == 0, (metric, on, out[5])
+            for i in (0, 1, 2, 69):
+                check(metric, qs[i], docs, tuple(o[i] for o in out), 7, f"d={d} int8={on} {metric} q={i}")
+        ix.close()
+
+
 @pytest.mark.parametrize("metric", ["sqeuclidean_dist", "euclidean_dist", "inner_product"])
-def test_int8_first_stage_experiment_is_exact(ei, metric, monkeypatch):
-    """The sieve's int8 first stage (csrc/vec_kernels_i8.h; an experiment, built only with MIR_SIEVE_I8=1): a filter on
-    v_mfma_i32_16x16x64_i8 with the rigorous Cauchy-Schwarz margin of the int8 residuals.  Whatever route a query takes - its
+def test_int8_first_stage_is_exact(ei, metric, monkeypatch):
+    """The sieve's int8 first stage (csrc/vec_kernels_i8.h; on by default where a shard qualifies, MIR_SIEVE_I8=0: off): a filter on
+    v_mfma_i32_16x16x64_i8 with the rigorous Cauchy-Schwarz margin of the int8 residuals, per tile.  Whatever route a query takes - its
     own select or, when its lists overflow, the exact pass - ids, order and distances are the oracle's; on isotropic unit rows
     the int8 route must answer itself (flag 0).  Also: queries of very different lengths in one batch (a scale per query), rows
     of one large norm with short queries, 200 queries (two query tiles per wave) and 40 (one)."""
@@ -350,6 +377,7 @@ def test_int8_first_stage_experiment_is_exact(ei, metric, monkeypatch):
     qs[0] = docs[77].astype(np.float64)
     qs[1] *= 0.25
     ix = ei.DeviceIndex.from_host(docs)
+    assert ix.scan_stats()["int8_first_stage"]
     for b, k in ((200, 10), (40, 64)):
         with np.errstate(invalid="ignore"):
             out = ix.search(qs[:b], k, metric)
@@ -376,6 +404,7 @@ def test_int8_first_stage_experiment_is_exact(ei, metric, monkeypatch):
     q2 = rng.standard_normal((8, d))
     q2 *= (np.array([1e-2, 1e-2, 3e-2, 1e-1, 1e-1, 0.3, 1.0, 1.0]) / np.linalg.norm(q2, axis=1))[:, None]
     ix = ei.DeviceIndex.from_host(docs2)
+    assert ix.scan_stats()["int8_first_stage"]
     out = ix.search(q2, 10, metric)
     from oracle import embeddings_metrics as om
 
