@@ -32,6 +32,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md; never the 2:1-sparsity figure)
+MFMA_PEAK_TOPS_I8 = 5000.0      # dense int8 MFMA peak: v_mfma_i32_16x16x64_i8 runs at twice the bf16 rate (MI355X_MICROARCH.md, matrix cores)
+
+
+def sieve_image_bytes_per_element(int8):
+    """What the sieve's first stage streams per row element: the int8 image (csrc/vec_kernels_i8.h) or the bf16 hi blocks."""
+    return 1 if int8 else 2
 MAIN_LEG_CHECK_QUERIES = 2
 CHUNK_ROWS = 500_000   # corpus is generated in fixed global chunks so every N sees the same rows
 PRECONDITION_STEPS = 12  # untimed launches before timing starts (W of them are the warm-up steps), see main()
@@ -377,13 +383,16 @@ def variant_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher, kind)
     t_oracle = time.perf_counter() - t0
     del host
     d_pad = (d + 127) // 128 * 128
-    bytes_launch = n * d_pad * 2 + (0 if args.metric == "inner_product" else 4 * n) + B * d * 4 + B * k * 12  # what the sieve moves
+    int8 = bool(stats and stats.get("int8_first_stage") and args.metric != "cosine_sim")
+    bytes_launch = (n * d_pad * sieve_image_bytes_per_element(int8) + (0 if args.metric == "inner_product" else 4 * n) + (n // 32 * 16 if int8 else 0)
+                    + B * d * 4 + B * k * 12)  # what the sieve moves
     avg_ms = scan_ms / max(launches, 1)
     res = {"workload": f"{kind}: {n} x {d} float32 unit rows, {args.metric}, k={k}, {B} queries per step, {steps} steps of fresh queries",
            "ms_per_step": round(1e3 * el / steps, 4), "qps": round(B * steps / el, 1),
            "scan_bracket_ms": round(avg_ms, 4),
            "hbm_frac": round(bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-           "mfma_frac": round(2.0 * n * d_pad * B / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS_BF16, 4),
+           "mfma_frac": round(2.0 * n * d_pad * B / (avg_ms * 1e-3) / 1e12 / (MFMA_PEAK_TOPS_I8 if int8 else MFMA_PEAK_TFLOPS_BF16), 4),
+           "first_stage": "int8" if int8 else "bf16",
            "exact_pass_queries": exact, "exact_pass_share": round(exact / (steps * B), 4),
            "queries_aimed_at_clusters_share": round(aimed / pool, 2),
            "ids_identical_to_cpu_oracle_on_2_queries": same, "oracle_s": round(t_oracle, 1)}
@@ -993,7 +1002,11 @@ def main():
     passes = -(-B // qpl)   # launches groups per step (1 at the default batch)
     survey_bytes = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
     d_pad = (d + 127) // 128 * 128
-    bytes_launch = (n_loc * d_pad * 2 + aux + q_launch * d * 4 + q_launch * k * 12) if sieve else survey_bytes
+    # which first stage this index's searches run: the int8 image (finite rows of one norm; squared L2 / euclidean / inner product)
+    # or the bf16 hi blocks
+    int8 = bool(sieve and sieve_stats.get("int8_first_stage") and args.metric != "cosine_sim")
+    tile_params = (n_loc // 32) * 16 if int8 else 0  # a float4 per 32-row tile: scale, residual bound
+    bytes_launch = (n_loc * d_pad * sieve_image_bytes_per_element(int8) + aux + tile_params + q_launch * d * 4 + q_launch * k * 12) if sieve else survey_bytes
     avg_ms = scan_ms / max(launches, 1)
     hbm_gbs = bytes_launch / (avg_ms * 1e-3) / 1e9
     # HBM traffic per launch comes from PMC counters, which cannot be collected inside this run (rocprofv3 --pmc
@@ -1003,10 +1016,15 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("rows_per_launch") == n_loc and tj.get("dim") == d and bool(tj.get("sieve")) == sieve:
+        if (tj.get("rows_per_launch") == n_loc and tj.get("dim") == d and bool(tj.get("sieve")) == sieve
+                and tj.get("first_stage", "bf16") == ("int8" if int8 else "bf16")):
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run): " + str(tj.get("command", ""))
-    if sieve:
+    if sieve and int8:
+        kernel_name = ("sieve_i8_kernel: two filter launches over the int8 image (first 1/16 of the rows, then the rest; v_mfma_i32_16x16x64_i8, "
+                       "exact integer dot products, a rigorous per-tile margin) with sieve_scatter_i8_kernel + sieve_select_kernel between "
+                       "them (the k-th largest lower bound so far = the second launch's threshold)")
+    elif sieve:
         kernel_name = ("sieve_q16_kernel: two filter launches over the bf16 hi blocks (first 1/16 of the tiles, then the rest) with "
                        "sieve_scatter_kernel + sieve_select_kernel between them (the k-th largest filter value so far, less the margin = "
                        "the second launch's threshold)")
@@ -1016,7 +1034,8 @@ def main():
         kernel_name = "scan_topk_kernel"
     mfma_tflops = 2.0 * n_loc * d_pad * q_launch / (avg_ms * 1e-3) / 1e12 if sieve else None
     hbm_frac = hbm_gbs / HBM_PEAK_GBS
-    mfma_frac = None if mfma_tflops is None else mfma_tflops / MFMA_PEAK_TFLOPS_BF16
+    mfma_peak = MFMA_PEAK_TOPS_I8 if int8 else MFMA_PEAK_TFLOPS_BF16
+    mfma_frac = None if mfma_tflops is None else mfma_tflops / mfma_peak
     by_mfma = mfma_frac is not None and mfma_frac > hbm_frac
 
     result = {
@@ -1030,7 +1049,8 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32 (bf16 MFMA filter with a worst-case error margin, every candidate the margin cannot exclude re-scored in f64 with the reference formula)",
+        "dtype": ("f32 (int8 MFMA filter with exact integer dot products and a rigorous error margin" if int8 else "f32 (bf16 MFMA filter with a rigorous error margin")
+                 + ", every candidate the margin cannot exclude re-scored in f64 with the reference formula)",
         "data": "synthetic",
         "config": {
             "workload": f"brute-force top-k over {n}x{d} float32 unit-norm rows, {args.metric}, k={k}",
@@ -1047,16 +1067,20 @@ def main():
             "kernel": kernel_name,
             "queries_per_launch": qpl,
             "achieved": round(mfma_tflops if by_mfma else hbm_gbs, 1),
-            "peak": MFMA_PEAK_TFLOPS_BF16 if by_mfma else HBM_PEAK_GBS,
-            "unit": "TFLOP/s" if by_mfma else "GB/s",
+            "peak": mfma_peak if by_mfma else HBM_PEAK_GBS,
+            "unit": ("TOP/s" if int8 else "TFLOP/s") if by_mfma else "GB/s",
             "frac": round(mfma_frac if by_mfma else hbm_frac, 4),
             "hbm_gbs": round(hbm_gbs, 1),
             "hbm_frac": round(hbm_frac, 4),
-            "mfma_tflops_hi_hi": None if mfma_tflops is None else round(mfma_tflops, 1),
+            "mfma_tflops_hi_hi": None if mfma_tflops is None else round(mfma_tflops, 1),  # (int8 first stage: TOP/s of the int8 products)
+            "mfma_peak": mfma_peak if sieve else None,
             "mfma_frac": None if mfma_frac is None else round(mfma_frac, 4),
+            "first_stage": ("int8" if int8 else "bf16") if sieve else None,
             "bytes_per_launch": bytes_launch,
-            "bytes_per_launch_is": ("what the sieve's algorithm moves per shard pass: rows * d_pad * 2 (bf16 hi blocks) + norm column + "
-                                    "queries + results" if sieve else "SURVEY.md 8(d) algorithmic bytes of one shard pass"),
+            "bytes_per_launch_is": (("what the sieve's algorithm moves per shard pass: rows * d_pad * 1 (int8 image) + norm column + tile "
+                                     "parameters + queries + results" if int8 else
+                                     "what the sieve's algorithm moves per shard pass: rows * d_pad * 2 (bf16 hi blocks) + norm column + "
+                                     "queries + results") if sieve else "SURVEY.md 8(d) algorithmic bytes of one shard pass"),
             "flops_per_launch": None if mfma_tflops is None else 2.0 * n_loc * d_pad * q_launch,
             "survey_bytes": survey_bytes,
             "survey_bytes_is": "SURVEY.md 8(d): rows * d * 4 + norm column + queries + results (a float32 stream of the shard)",
@@ -1102,7 +1126,7 @@ def main():
             sweep.append({"queries_per_step": Bs, "qps": round(Bs * 10 / el, 1), "ms_per_step": round(1e3 * el / 10, 4),
                           "scan_launch_ms": round(a_ms, 4), "hbm_frac": round(bytes_launch / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                           "mfma_frac": (None if not sieve else
-                                        round(2.0 * n_loc * d_pad * min(Bs, qpl) / (a_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS_BF16, 4))})
+                                        round(2.0 * n_loc * d_pad * min(Bs, qpl) / (a_ms * 1e-3) / 1e12 / mfma_peak, 4))})
         result["batch_sweep"] = sweep
         # the other metrics of embeddings_metrics.py at the headline batch (north_star names cosine; the index is the same image)
         others = []

@@ -26,12 +26,12 @@ dur = {}
 for r in csv.DictReader(open(ft)):
     dur[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"].split("(")[0])
 def top(vals, names, key):  # the main (second) filter launches = the largest counter values of that kernel
-    v = sorted((x for d, x in vals.items() if key in names[d] and "true" not in names[d].split("<")[1]), reverse=True)
+    v = sorted((x for d, x in vals.items() if (key + "q16_kernel" in names[d] or key + "i8_kernel" in names[d]) and "true" not in names[d].split("<")[1]), reverse=True)
     v = v[: max(1, len(v) // 2 - 2)]
     return sum(v) / len(v)
-key = "sieve_q16_kernel"
+key = "sieve_"
 mb, ga = top(m, nm, key), top(g, ng, key)
-d = sorted((x for x, n in dur.values() if key in n and "true" not in n.split("<")[1]), reverse=True)
+d = sorted((x for x, n in dur.values() if (key + "q16_kernel" in n or key + "i8_kernel" in n) and "true" not in n.split("<")[1]), reverse=True)
 d = d[: max(1, len(d) // 2 - 2)]; dn = sum(d) / len(d)
 print(f"sieve_stats.py {args}: second filter launch (mean of the full-size launches)")
 print(f"  SQ_VALU_MFMA_BUSY_CYCLES (sum over 1024 SIMDs) {mb:,.0f}   GRBM_GUI_ACTIVE (sum over 8 XCDs) {ga:,.0f}   duration {dn/1e3:.1f} us (under the GRBM pass)")

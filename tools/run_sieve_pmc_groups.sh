@@ -16,7 +16,7 @@ per = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(f"/tmp/sv_pmcg_{g}/**/p_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "sieve_q16_kernel" in n and "true" not in n.split("<")[1].split(">")[0].split(",")[2]:
+        if ("sieve_q16_kernel" in n or "sieve_i8_kernel" in n) and "true" not in n.split("<")[1].split(">")[0].split(",")[2]:
             per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
 for c, d in sorted(per.items()):
     v = sorted(d.values(), reverse=True)

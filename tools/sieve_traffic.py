@@ -27,7 +27,7 @@ fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "W
 n, d = int(sys.argv[3]), int(sys.argv[4])
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 128  # queries per launch (what sieve_stats.py was run with)
 def split_filter(by):  # the filter kernel's dispatches alternate first launch / second launch (the sample instance has another name)
-    name = [k for k in by if "sieve_q16_kernel" in k and "true" not in k.split("<")[1]][0]
+    name = [k for k in by if ("sieve_q16_kernel" in k or "sieve_i8_kernel" in k) and "true" not in k.split("<")[1]][0]
     v = [x for _, x in sorted(by[name])][-32:]  # the timed steps
     return name, sum(v[0::2]) / len(v[0::2]), sum(v[1::2]) / len(v[1::2])
 def mean_of(by, key):
@@ -36,15 +36,17 @@ def mean_of(by, key):
     return sum(v) / len(v)
 name, f1, f2 = split_filter(fetch)
 _, w1, w2 = split_filter(write)
-fv, fs = mean_of(fetch, "sieve_scatter_kernel"), mean_of(fetch, "sieve_select_kernel")
-wv, ws = mean_of(write, "sieve_scatter_kernel"), mean_of(write, "sieve_select_kernel")
+fv, fs = mean_of(fetch, "sieve_scatter"), mean_of(fetch, "sieve_select_kernel")
+wv, ws = mean_of(write, "sieve_scatter"), mean_of(write, "sieve_select_kernel")
+int8 = "sieve_i8_kernel" in name
 reads = 2 * (f1 + f2) * 1024
 between = 2 * (fv + fs) * 1024 + (wv + ws) * 1024  # one scatter + select pair sits inside the bracket (the mean is over both pairs)
 hbm = reads + (w1 + w2) * 1024 + between
-streamed = n * ((d + 127) // 128 * 128) * 2 + 4 * n + B * d * 4 + B * 10 * 12
+streamed = n * ((d + 127) // 128 * 128) * (1 if int8 else 2) + 4 * n + (n // 32 * 16 if int8 else 0) + B * d * 4 + B * 10 * 12
 print(json.dumps({
     "sieve": True,
-    "kernel": name + ": the two filter launches that stream one shard's bf16 hi blocks (first 1/16 of the tiles, then the rest), plus the sieve_scatter_kernel / sieve_select_kernel pair between them - what bench.py's HIP events bracket; the 32K-row sample launch before them is outside the bracket",
+    "first_stage": "int8" if int8 else "bf16",
+    "kernel": name + ": the two filter launches that stream one shard's " + ("int8 image" if int8 else "bf16 hi blocks") + " (first 1/16 of the tiles, then the rest), plus the scatter / select pair between them - what bench.py's HIP events bracket; the 32K-row sample launch before them is outside the bracket",
     "rows_per_launch": n, "dim": d, "queries_per_launch": B,
     "FETCH_SIZE_KiB_mean": {"first_launch": f1, "second_launch": f2, "scatter_kernel": fv, "select_kernel": fs},
     "WRITE_SIZE_KiB_mean": {"first_launch": w1, "second_launch": w2, "scatter_kernel": wv, "select_kernel": ws},
