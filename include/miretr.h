@@ -64,7 +64,8 @@ extern "C" {
 
 /* per-query result flags (out_flags).  Results are ALWAYS the reference's.
  * float32 shards of >= 32K rows at d <= 384 are searched by the sieve: a bf16
- * filter with a worst-case error margin lets through every row that can reach a
+ * filter (an int8 one where the rows are finite and of one norm and the metric is
+ * not cosine) with a rigorous error margin lets through every row that can reach a
  * proven lower bound of the k-th best distance; the candidates whose filter
  * value, widened by the margin, can still reach the k-th best EXACT distance are
  * re-scored with the reference formula in float64 (the others are proven
