@@ -595,16 +595,24 @@ static int32_t launch_sieve_i8(const mir_index *ix, int qpw, const float *q_scal
                                const double *q_sq_g, const double *q_err_g, int nq, int nwg, uint32_t stage0, uint32_t n_stages,
                                int nan_guard, const uint64_t *gthr_g, uint64_t *cand, float *candv, uint32_t *ccount, float *part_sample,
                                bool sample, unsigned long long *stat, hipStream_t stream) {
-    const size_t lds = sieve_i8_lds_bytes(ix->ks64);
+    // up to 128 queries per launch: four waves per workgroup and two workgroups per CU (0.83 against 0.92 ms per 128-query step at
+    // 10M x 384); 256: eight waves, one workgroup (four waves with four query tiles each spill: 1.49 against 1.28 ms).
+    // MIR_SIEVE_I8_WAVES = 4 / 8 forces one geometry (A/B runs)
+    static const int nw_env = getenv("MIR_SIEVE_I8_WAVES") ? atoi(getenv("MIR_SIEVE_I8_WAVES")) : 0;
+    const bool four = nw_env ? nw_env == 4 : qpw <= 128;
+    const size_t lds = sieve_i8_lds_bytes(ix->ks64, four ? 4 : 8);
     const uint32_t n_rows = (uint32_t)ix->n;
+    const int grid = (four && !sample) ? 2 * nwg : nwg;  // (the candidate parts are per wave: nwg x 8 of them either way)
 #define MIR_I8_PICK(KS)                                                                                                \
-    (qpw > 128 ? (sample ? sieve_i8_kernel<KS, KIND, true, 2> : sieve_i8_kernel<KS, KIND, false, 2>)                   \
-               : (sample ? sieve_i8_kernel<KS, KIND, true, 1> : sieve_i8_kernel<KS, KIND, false, 1>))
+    (four ? (qpw > 128 ? (sample ? sieve_i8_kernel<KS, KIND, true, 4, 4> : sieve_i8_kernel<KS, KIND, false, 4, 4>)     \
+                       : (sample ? sieve_i8_kernel<KS, KIND, true, 2, 4> : sieve_i8_kernel<KS, KIND, false, 2, 4>))    \
+          : (qpw > 128 ? (sample ? sieve_i8_kernel<KS, KIND, true, 2, 8> : sieve_i8_kernel<KS, KIND, false, 2, 8>)     \
+                       : (sample ? sieve_i8_kernel<KS, KIND, true, 1, 8> : sieve_i8_kernel<KS, KIND, false, 1, 8>)))
 #define MIR_I8_CASE(KS)                                                                                                \
     case KS: {                                                                                                         \
         auto kern = MIR_I8_PICK(KS);                                                                                   \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kern<<<dim3(nwg), dim3(512), lds, stream>>>(ix->d_i8, ix->d_docsq, ix->d_i8tp, qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, q_scale_g, n_rows, \
+        kern<<<dim3(grid), dim3(four ? 256 : 512), lds, stream>>>(ix->d_i8, ix->d_docsq, ix->d_i8tp, qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, q_scale_g, n_rows, \
                                                     stage0, n_stages, nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat); \
         break;                                                                                                         \
     }

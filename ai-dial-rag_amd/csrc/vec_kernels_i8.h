@@ -40,6 +40,10 @@
 #pragma once
 #include "vec_kernels_sieve.h"
 
+#ifndef I8_ABL
+#define I8_ABL 0  // measurement builds only (results wrong by design): bit 0 no filter, bit 1 no barrier, bit 2 no DMA after the prologue
+#endif
+
 namespace mir {
 
 typedef int __attribute__((ext_vector_type(4))) i32x4;
@@ -216,13 +220,17 @@ __global__ __launch_bounds__(64) void prep_queries_i8_quant_kernel(const double 
 }
 
 // ---- the filter ----
-__host__ __device__ constexpr size_t sieve_i8_lds_bytes(int ks64) { return (size_t)kSieveStages * (ks64 * 4 * 1024 + (64 + 8) * 4) + 64; }
+// Geometry: NW waves per workgroup.  8 waves: one workgroup per CU, six 24-KiB stages.  4 waves (each with twice the query tiles):
+// TWO workgroups per CU with three stages each - one workgroup's barrier and tile boundary are the other's matrix time (the
+// barrier alone was 12 % of the 8-wave launch), and every document fragment read from LDS feeds twice the MFMAs.
+__host__ __device__ constexpr int sieve_i8_stages(int nw) { return nw == 8 ? kSieveStages : 3; }
+__host__ __device__ constexpr size_t sieve_i8_lds_bytes(int ks64, int nw) { return (size_t)sieve_i8_stages(nw) * (ks64 * 4 * 1024 + (64 + 8) * 4) + 64; }
 
 // QT = query tiles (16 queries each) per wave, as sieve_q16_kernel.  KS64 = k-steps of 64 columns (2, 4, 6).
 // Candidates: every wave writes its own part of the workgroup's region (kI8WavePart entries; the count is wave-uniform: no
 // LDS atomic on the emit path), ccount[workgroup][8].
-template <int KS64, int KIND, bool SAMPLE, int QT>
-__global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
+template <int KS64, int KIND, bool SAMPLE, int QT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
                                                           const float4 *__restrict__ tparam,
                                                           const uint4 *__restrict__ qfrag, const double *__restrict__ q_norm,
                                                           const double *__restrict__ q_sq, const double *__restrict__ q_err,
@@ -232,19 +240,21 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
                                                           float *__restrict__ candv, uint32_t *__restrict__ ccount,
                                                           float *__restrict__ part_sample, unsigned long long *__restrict__ stat) {
     static_assert(KIND == SCAN_L2 || KIND == SCAN_IP, "the int8 filter ranks squared L2 and inner product");
-    static_assert(QT == 1 || QT == 2, "query tiles per wave");
-    constexpr int NS = kSieveStages;
+    static_assert(QT == 1 || QT == 2 || QT == 4, "query tiles per wave");
+    static_assert(NW == 8 || NW == 4, "waves per workgroup");
+    constexpr int NS = sieve_i8_stages(NW);
+    constexpr int APW = 64 / NW;           // squared norms a wave brings per stage
     constexpr int NB = KS64 * 2;           // 1-KiB blocks per 32-row tile
     constexpr int SB = NB * 2;             // per stage (two tiles)
     constexpr int STAGE_U4 = SB * 64;
-    constexpr int PPW = SB / 8;            // 1-KiB DMA pieces per wave per stage
+    constexpr int PPW = SB / NW;           // 1-KiB DMA pieces per wave per stage
     // the stage's 64 squared norms travel with it (lanes 0..7 of every wave bring 8 of them; inner product never reads them) and,
     // by the same instruction, its two tiles' parameters (lanes 8..15 of the last wave -> slots 64..71)
     constexpr int PW = PPW + 1;
     constexpr int AS = 64 + 8;
     constexpr int D = NS - 1;
-    constexpr int QPL = 128 * QT;
-    static_assert(SB % 8 == 0, "sieve_i8: d padded to a multiple of 128");
+    constexpr int QPL = NW * 16 * QT;
+    static_assert(SB % NW == 0, "sieve_i8: d padded to a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *ring = reinterpret_cast<uint4 *>(smem);
     float *aux_lds = reinterpret_cast<float *>(smem + (size_t)NS * STAGE_U4 * 16);
@@ -305,11 +315,11 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
 #pragma unroll
         for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
         {
-            const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_addr_of(aux_lds) + ((g % NS) * AS + wave8 * 8) * 4);
-            const bool tp_lane = wave8 == 7 && lane >= 8 && lane < 16;
-            const float *src1 = tp_lane ? reinterpret_cast<const float *>(tparam) + (size_t)stage * 8 + (lane - 8)
-                                        : aux + (size_t)stage * 64 + wave8 * 8 + lane;
-            if (lane < 8 || tp_lane) glds4_b32(src1, adst);
+            const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_addr_of(aux_lds) + ((g % NS) * AS + wave8 * APW) * 4);
+            const bool tp_lane = wave8 == NW - 1 && lane >= APW && lane < APW + 8;  // (the last wave: slots 64 .. 71)
+            const float *src1 = tp_lane ? reinterpret_cast<const float *>(tparam) + (size_t)stage * 8 + (lane - APW)
+                                        : aux + (size_t)stage * 64 + wave8 * APW + lane;
+            if (lane < APW || tp_lane) glds4_b32(src1, adst);
         }
     };
 #pragma unroll
@@ -324,8 +334,8 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
         if (younger == (uint32_t)(D - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    uint64_t *region = cand + ((size_t)blockIdx.x * 8 + wave8) * kI8WavePart;
-    float *regionv = candv + ((size_t)blockIdx.x * 8 + wave8) * kI8WavePart;
+    uint64_t *region = cand + ((size_t)blockIdx.x * NW + wave8) * kI8WavePart;
+    float *regionv = candv + ((size_t)blockIdx.x * NW + wave8) * kI8WavePart;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t wcount = 0;  // (wave-uniform) candidates this wave has written; beyond kI8WavePart they are counted, not stored
 
@@ -396,8 +406,12 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
     bool have_prev = false;
     for (uint32_t g = 0; g < my_stages; ++g) {
         const uint32_t stage = stage0 + blockIdx.x + g * G;
+#if !(I8_ABL & 4)
         wait_stage(g);
+#endif
+#if !(I8_ABL & 2)
         __builtin_amdgcn_s_barrier();
+#endif
         if (!active) {
             if (g + D < NG) issue(g + D);
             continue;
@@ -434,16 +448,21 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
                 }
                 if (sub == 0 && s == 0) {  // the next stage's DMA once the matrix pipe has work queued
                     __builtin_amdgcn_sched_barrier(0);
+#if !(I8_ABL & 4)
                     if (g + D < NG) issue(g + D);
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < QT; ++u)
                     if (s == 1 + u && s < KS64 && have_prev) {  // the previous tile's filter, one query tile per k-step
                         __builtin_amdgcn_sched_barrier(0);
+#if I8_ABL & 1
+                        if (g == 0xffffff)
+#endif
                         filter(u, p0[u], p1[u], pax, pt, ptp);
                     }
             }
-            if (KS64 < QT + 1 && have_prev) {  // (two k-steps per tile: the second query tile's filter did not fit above)
+            if (KS64 < QT + 1 && have_prev) {  // (few k-steps per tile: the last query tiles' filters did not fit above)
 #pragma unroll
                 for (int u = KS64 - 1; u < QT; ++u) filter(u, p0[u], p1[u], pax, pt, ptp);
             }
@@ -470,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void sieve_i8_kernel(const uint4 *__restric
         return;
     }
     if (lane == 0) {
-        ccount[(size_t)blockIdx.x * 8 + wave8] = wcount;  // may exceed kI8WavePart: the scatter then hands every query to the exact pass
+        ccount[(size_t)blockIdx.x * NW + wave8] = wcount;  // may exceed kI8WavePart: the scatter then hands every query to the exact pass
         if (stat && wcount) atomicAdd(stat, (unsigned long long)wcount);
     }
 }
