@@ -270,7 +270,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
     constexpr float L = KIND == SCAN_L2 ? 2.0f : 1.0f;  // ranking units per inner-product unit
     // per query: its scale, the margin's two coefficients (i8_margin_ab), the threshold with its rounding slack, and the two
     // numbers the per-tile integer bound is made of: ib_t = floor((P1 - e_t A1) / s_t) - 4 (see the header)
-    float sq[QT], mA[QT], mB[QT], tb[QT], P1[QT], A1[QT], guard[QT], best[QT];
+    // (the float bound of the rare path is rebuilt from the same three numbers: bound_t = (P1 - e_t A1 - 2 s_t) L sq - amin)
+    float sq[QT], mA[QT], mB[QT], P1[QT], A1[QT], guard[QT], best[QT];
     i32x4 qh[QT][KS64];
     const bool active = nq > wave8 * QT * 16;
 #pragma unroll
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
         qloc[u] = t16 * 16 + qc;
         lane_live[u] = qloc[u] < nq;
         live_mask[u] = __builtin_amdgcn_ballot_w64(lane_live[u]);
-        sq[u] = 1.0f; mA[u] = 0.f; mB[u] = 0.f; tb[u] = -__builtin_inff(); P1[u] = -__builtin_inff(); A1[u] = 0.f;
+        sq[u] = 1.0f; mA[u] = 0.f; mB[u] = 0.f; P1[u] = -__builtin_inff(); A1[u] = 0.f;
         guard[u] = __builtin_inff(); best[u] = -__builtin_inff();
         if (lane_live[u]) {
             const float qn = (float)q_norm[qloc[u]] * (1.0f + 1e-6f);
@@ -291,10 +292,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
                 const uint64_t key = gthr[qloc[u]];
                 if (key != 0 && good) {
                     const float t = key_value(key);
-                    tb[u] = t - 2e-6f * fabsf(t);
-                    P1[u] = (tb[u] + amin - L * mB[u]) / (L * sq[u]);
+                    const float tb = t - 2e-6f * fabsf(t);
+                    P1[u] = (tb + amin - L * mB[u]) / (L * sq[u]);
                     A1[u] = mA[u] / sq[u];
-                    if (!(P1[u] == P1[u]) || !(A1[u] == A1[u])) { P1[u] = -__builtin_inff(); A1[u] = 0.f; tb[u] = -__builtin_inff(); }
+                    if (!(P1[u] == P1[u]) || !(A1[u] == A1[u])) { P1[u] = -__builtin_inff(); A1[u] = 0.f; }
                 }
             } else if (nan_guard) {
                 const float qs = (float)q_sq[qloc[u]];
@@ -362,7 +363,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
         if ((__builtin_amdgcn_ballot_w64(m >= ib) & live_mask[u]) == 0ull) return;
         asm volatile("" : "+s"(t));  // (the rare path below depends on t: nothing of it is computed ahead of the branch)
         const float vs = L * tp.x * sq[u];
-        const float bound = tb[u] - i8_margin_tile(KIND == SCAN_L2, mA[u], mB[u], tp.y, tp.x, sq[u]);  // (tb = -inf: everything passes)
+        // tb - mg_t in the ranking's units, from the numbers the integer bound was made of (one more rounding or two than
+        // i8_margin_tile's own arithmetic: the factor below widens it by more than that; P1 = -inf: everything passes)
+        const float bound = (fmaf(-tp.y, A1[u], P1[u]) - 2.0f * tp.x) * (L * sq[u]) - amin;
+        const float bound_w = bound - 4e-6f * (fabsf(bound) + amin);
         float v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
         }
         uint32_t pm = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound)) << r;
+        for (int r = 0; r < 8; ++r) pm |= (uint32_t)(!(v[r] < bound_w)) << r;
         if (!lane_live[u]) pm = 0;
         if (!__any(pm != 0)) return;
         const uint32_t row0 = t * kTileRows + 4 * jg;  // this lane's rows: row0 + 16 rh + i
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const uint4 *st = ring + (size_t)(g % NS) * STAGE_U4 + sub * (NB * 64) + lane;
-            constexpr int PF = 2 < KS64 ? 2 : KS64 - 1;  // fragment pairs requested ahead of their MFMAs
+            constexpr int PF = QT == 4 ? 1 : (2 < KS64 ? 2 : KS64 - 1);  // fragment pairs requested ahead of their MFMAs (four query tiles: eight MFMAs per pair already)
             uint4 f0[PF + 1], f1[PF + 1];
 #pragma unroll
             for (int i = 0; i < PF; ++i) { f0[i] = st[(2 * i + 0) * 64]; f1[i] = st[(2 * i + 1) * 64]; }
