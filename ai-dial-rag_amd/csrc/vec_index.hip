@@ -785,7 +785,10 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
         return MIR_OK;
     }
     // the int8 first stage serves this call: the shard has the image, the metric ranks in the rows' own units
-    const bool use_i8 = ix->i8 && pl.sieve && metric != MIR_METRIC_COSINE_SIM && sb.q_amax != nullptr;
+    // ... and k is small: the int8 margin is 4.3 x the bf16 filter's, its lists grow with k (10M x 384: 4.2k candidates per query at k = 10,
+    // 7.5k at 20, 11k at 32 - where the first queries overflow their 16384-entry lists and take the exact pass; the bf16 filter
+    // lists 3.8k at k = 64) - beyond kI8MaxK the same index's bf16 image serves the call
+    const bool use_i8 = ix->i8 && pl.sieve && metric != MIR_METRIC_COSINE_SIM && sb.q_amax != nullptr && k <= kI8MaxK;
     if (use_i8) {
         const int ntiles16 = ngroups * (qpw / 16);
         prep_queries_i8_stats_kernel<<<dim3(std::max(b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(dq, b, d, sb.q_sq, sb.q_norm, sb.q_amax, gz, gwords);

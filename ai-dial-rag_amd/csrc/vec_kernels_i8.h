@@ -30,8 +30,8 @@
 // for shards whose squared norms agree to 1e-3 (normalised embeddings: to 1e-7).
 //
 // Served: float32 shards the bf16 sieve serves (d padded to 128 / 256 / 384, >= 32K rows) whose rows are finite and of one
-// norm, squared L2 / euclidean / inner product.  Everything else - cosine, other norms, the wide and the float16-native
-// shards - stays on the bf16 / float16 filters.
+// norm, squared L2 / euclidean / inner product, k <= 16 (kI8MaxK: the lists grow with k).  Everything else - cosine, larger k,
+// other norms, the wide and the float16-native shards - stays on the bf16 / float16 filters.
 //
 // Built by default for every shard that qualifies (MIR_SIEVE_I8=0 at index build keeps the bf16 filter: the A/B switch;
 // `mir_index_scan_stats` word 6 says which an index has); the bf16 hi image is built beside it and serves cosine.  Measured on
@@ -52,6 +52,7 @@ typedef int __attribute__((ext_vector_type(4))) i32x4;
 // [7] smallest squared norm (words 1, 2, 7 are reduced as float bits: non-negative floats order as their bits)
 constexpr int kI8StatWords = 8;
 // tile parameters (float4 per 32-row tile): x = s_t, y = e_t (largest |x - x^| of its rows, rounded up), z = 1 / (2 s_t), w = -
+constexpr int kI8MaxK = 16;           // results per query the int8 first stage serves (vec_index.hip, enqueue_search)
 constexpr int kI8Region = 32768;       // candidates a workgroup can write per launch: eight wave-private parts of 4096
 constexpr int kI8WavePart = kI8Region / 8;
 // The margin of a row of a tile with residual bound e_t and scale s_t, in inner-product units, as mg_t = e_t * A + B + 2 s_t s_q:

@@ -378,7 +378,7 @@ def test_int8_first_stage_is_exact(ei, metric, monkeypatch):
     qs[1] *= 0.25
     ix = ei.DeviceIndex.from_host(docs)
     assert ix.scan_stats()["int8_first_stage"]
-    for b, k in ((200, 10), (40, 64)):
+    for b, k in ((200, 10), (40, 16), (100, 64)):  # (k beyond 16: the same index's bf16 filter serves the call)
         with np.errstate(invalid="ignore"):
             out = ix.search(qs[:b], k, metric)
         st = ix.scan_stats()
