@@ -294,6 +294,11 @@ static int32_t build_i8(mir_index *ix, hipStream_t stream) {
     MIR_HIP(hipStreamSynchronize(stream));
     // the integer test takes the smallest squared norm for every row's: rows of ONE norm only (normalised embeddings)
     ix->i8 = st[7] > 0.f && st[1] - st[7] <= 1e-3f * st[1];
+    if (ix->i8) {  // the norms' range, for cosine
+        // (doc_sq is a float32 sum of d squares: 1e-4 covers its rounding many times over and costs the bound nothing)
+        const float nr[3] = {sqrtf(st[7]) * (1.0f - 1e-4f), sqrtf(st[1]) * (1.0f + 1e-4f), 1.0f / (sqrtf(st[7]) * (1.0f - 1e-4f))};
+        MIR_HIP(hipMemcpy(ix->d_i8stats + 4, nr, sizeof(nr), hipMemcpyHostToDevice));
+    }
     if (!ix->i8) {
         (void)hipFree(ix->d_i8);
         (void)hipFree(ix->d_i8tp);
@@ -612,7 +617,7 @@ static int32_t launch_sieve_i8(const mir_index *ix, int qpw, const float *q_scal
     case KS: {                                                                                                         \
         auto kern = MIR_I8_PICK(KS);                                                                                   \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kern<<<dim3(grid), dim3(four ? 256 : 512), lds, stream>>>(ix->d_i8, ix->d_docsq, ix->d_i8tp, qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, q_scale_g, n_rows, \
+        kern<<<dim3(grid), dim3(four ? 256 : 512), lds, stream>>>(ix->d_i8, KIND == SCAN_COS ? ix->d_invnorm : ix->d_docsq, ix->d_i8tp, qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, q_scale_g, n_rows, \
                                                     stage0, n_stages, nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat); \
         break;                                                                                                         \
     }
@@ -788,7 +793,7 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
     // ... and k is small: the int8 margin is 4.3 x the bf16 filter's, its lists grow with k (10M x 384: 4.2k candidates per query at k = 10,
     // 7.5k at 20, 11k at 32 - where the first queries overflow their 16384-entry lists and take the exact pass; the bf16 filter
     // lists 3.8k at k = 64) - beyond kI8MaxK the same index's bf16 image serves the call
-    const bool use_i8 = ix->i8 && pl.sieve && metric != MIR_METRIC_COSINE_SIM && sb.q_amax != nullptr && k <= kI8MaxK;
+    const bool use_i8 = ix->i8 && pl.sieve && sb.q_amax != nullptr && k <= kI8MaxK;
     if (use_i8) {
         const int ntiles16 = ngroups * (qpw / 16);
         prep_queries_i8_stats_kernel<<<dim3(std::max(b, (gwords + 63) / 64)), dim3(64), 0, stream>>>(dq, b, d, sb.q_sq, sb.q_norm, sb.q_amax, gz, gwords);
@@ -849,6 +854,8 @@ static int32_t enqueue_search(mir_index *ix, const double *dq, int b, int k, int
                     const uint4 *qf = sb.qsplit + (size_t)g * (qpw / 16) * ix->ks64 * 64;
                     if (metric == MIR_METRIC_INNER_PRODUCT)
                         return launch_sieve_i8<SCAN_IP>(ix, qpw, sb.qscale + q0, qf, qn, qsq, qerr, nq, wgs, s0, s1 - s0, guard, gt, cand, cv, cc, ps, smp, st, stream);
+                    if (metric == MIR_METRIC_COSINE_SIM)
+                        return launch_sieve_i8<SCAN_COS>(ix, qpw, sb.qscale + q0, qf, qn, qsq, qerr, nq, wgs, s0, s1 - s0, guard, gt, cand, cv, cc, ps, smp, st, stream);
                     return launch_sieve_i8<SCAN_L2>(ix, qpw, sb.qscale + q0, qf, qn, qsq, qerr, nq, wgs, s0, s1 - s0, guard, gt, cand, cv, cc, ps, smp, st, stream);
                 }
                 if (ix->native16) {
@@ -1485,7 +1492,7 @@ int32_t mir_index_scan_stats(mir_index *idx, int32_t reset, int64_t *out8) {
     MIR_HIP(hipDeviceSynchronize());
     MIR_HIP(hipMemcpy(out8, idx->d_stats, 64, hipMemcpyDeviceToHost));
     if (reset) MIR_HIP(hipMemset(idx->d_stats, 0, 64));
-    out8[6] = idx->i8 ? 1 : 0;  // the shard has the int8 image: its squared-L2 / euclidean / inner-product searches use the int8 first stage
+    out8[6] = idx->i8 ? 1 : 0;  // the shard has the int8 image: its searches for up to kI8MaxK results use the int8 first stage
     return MIR_OK;
 }
 

@@ -30,11 +30,11 @@
 // for shards whose squared norms agree to 1e-3 (normalised embeddings: to 1e-7).
 //
 // Served: float32 shards the bf16 sieve serves (d padded to 128 / 256 / 384, >= 32K rows) whose rows are finite and of one
-// norm, squared L2 / euclidean / inner product, k <= 16 (kI8MaxK: the lists grow with k).  Everything else - cosine, larger k,
+// norm, all four metrics (cosine: see the kernel), k <= 16 (kI8MaxK: the lists grow with k).  Everything else - larger k,
 // other norms, the wide and the float16-native shards - stays on the bf16 / float16 filters.
 //
 // Built by default for every shard that qualifies (MIR_SIEVE_I8=0 at index build keeps the bf16 filter: the A/B switch;
-// `mir_index_scan_stats` word 6 says which an index has); the bf16 hi image is built beside it and serves cosine.  Measured on
+// `mir_index_scan_stats` word 6 says which an index has); the bf16 hi image is built beside it and serves k > 16.  Measured on
 // 10M x 384 unit rows, 256 queries per step (profiles/r04_i8_sieve.md): 1.26-1.30 ms per step against the bf16 filter's 1.83
 // (197-204k against 137-140k QPS), 1.8k + 2.4k candidates per query against 330 + 289.
 #pragma once
@@ -49,7 +49,9 @@ namespace mir {
 typedef int __attribute__((ext_vector_type(4))) i32x4;
 
 // i8 statistics (floats): [0] largest row norm, [1] largest squared norm (float32 doc_sq), [2] largest |x - x^| (information),
-// [7] smallest squared norm (words 1, 2, 7 are reduced as float bits: non-negative floats order as their bits)
+// [7] smallest squared norm (words 1, 2, 7 are reduced as float bits: non-negative floats order as their bits); written by the
+// host once the build is complete: [4] nmin, [5] nmax = the rows' smallest / largest norm rounded down / up, [6] 1 / nmin
+// rounded up (cosine)
 constexpr int kI8StatWords = 8;
 // tile parameters (float4 per 32-row tile): x = s_t, y = e_t (largest |x - x^| of its rows, rounded up), z = 1 / (2 s_t), w = -
 constexpr int kI8MaxK = 16;           // results per query the int8 first stage serves (vec_index.hip, enqueue_search)
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
                                                           const uint64_t *__restrict__ gthr, uint64_t *__restrict__ cand,
                                                           float *__restrict__ candv, uint32_t *__restrict__ ccount,
                                                           float *__restrict__ part_sample, unsigned long long *__restrict__ stat) {
-    static_assert(KIND == SCAN_L2 || KIND == SCAN_IP, "the int8 filter ranks squared L2 and inner product");
+    static_assert(KIND == SCAN_L2 || KIND == SCAN_IP || KIND == SCAN_COS, "scan kind");
     static_assert(QT == 1 || QT == 2 || QT == 4, "query tiles per wave");
     static_assert(NW == 8 || NW == 4, "waves per workgroup");
     constexpr int NS = sieve_i8_stages(NW);
@@ -269,6 +271,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
     bool lane_live[QT];
     unsigned long long live_mask[QT];
     constexpr float L = KIND == SCAN_L2 ? 2.0f : 1.0f;  // ranking units per inner-product unit
+    // Cosine ranks x.q / |x| on a shard whose norms all lie in [nmin, nmax] (statistics words 4, 5; the image is built only where
+    // they agree to 5e-4): true cosine >= T implies x.q >= T |x| >= min(T nmin, T nmax), so the INTEGER test is the inner
+    // product's with that threshold; the float re-test and the listed value are in cosine units (v = s_t s_q I / |x|, the
+    // row's inverse norm from the aux column), with the inner-product margin times the largest inverse norm (word 6).
+    const float ax_hi = KIND == SCAN_COS ? stats[6] : 1.0f;
+    float tbc[QT];  // (cosine) the threshold in its own units
     // per query: its scale, the margin's two coefficients (i8_margin_ab), the threshold with its rounding slack, and the two
     // numbers the per-tile integer bound is made of: ib_t = floor((P1 - e_t A1) / s_t) - 4 (see the header)
     // (the float bound of the rare path is rebuilt from the same three numbers: bound_t = (P1 - e_t A1 - 2 s_t) L sq - amin)
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
         qloc[u] = t16 * 16 + qc;
         lane_live[u] = qloc[u] < nq;
         live_mask[u] = __builtin_amdgcn_ballot_w64(lane_live[u]);
-        sq[u] = 1.0f; mA[u] = 0.f; mB[u] = 0.f; P1[u] = -__builtin_inff(); A1[u] = 0.f;
+        sq[u] = 1.0f; mA[u] = 0.f; mB[u] = 0.f; P1[u] = -__builtin_inff(); A1[u] = 0.f; tbc[u] = -__builtin_inff();
         guard[u] = __builtin_inff(); best[u] = -__builtin_inff();
         if (lane_live[u]) {
             const float qn = (float)q_norm[qloc[u]] * (1.0f + 1e-6f);
@@ -293,10 +301,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
                 const uint64_t key = gthr[qloc[u]];
                 if (key != 0 && good) {
                     const float t = key_value(key);
-                    const float tb = t - 2e-6f * fabsf(t);
+                    float tb = t - 2e-6f * fabsf(t);
+                    tbc[u] = tb;
+                    if (KIND == SCAN_COS) tb = fminf(tb * stats[4], tb * stats[5]) - 1e-6f * fabsf(tb) * stats[5];
                     P1[u] = (tb + amin - L * mB[u]) / (L * sq[u]);
                     A1[u] = mA[u] / sq[u];
-                    if (!(P1[u] == P1[u]) || !(A1[u] == A1[u])) { P1[u] = -__builtin_inff(); A1[u] = 0.f; }
+                    if (!(P1[u] == P1[u]) || !(A1[u] == A1[u])) { P1[u] = -__builtin_inff(); A1[u] = 0.f; tbc[u] = -__builtin_inff(); }
                 }
             } else if (nan_guard) {
                 const float qs = (float)q_sq[qloc[u]];
@@ -347,11 +357,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
     auto filter = [&](int u, const i32x4 &c0, const i32x4 &c1, const float (&ax)[8], uint32_t t, const float4 &tp) {
         if (SAMPLE) {
             if (lane_live[u]) {
-                const float vs = L * tp.x * sq[u], mg = i8_margin_tile(KIND == SCAN_L2, mA[u], mB[u], tp.y, tp.x, sq[u]);
+                const float vs = L * tp.x * sq[u], mg = i8_margin_tile(KIND == SCAN_L2, mA[u], mB[u], tp.y, tp.x, sq[u]) * ax_hi;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const float fi = (float)(r < 4 ? c0[r & 3] : c1[r & 3]);
-                    const float w = KIND == SCAN_L2 ? fmaf(vs, fi, -ax[r]) : vs * fi;
+                    const float w = KIND == SCAN_L2 ? fmaf(vs, fi, -ax[r]) : KIND == SCAN_COS ? vs * fi * ax[r] : vs * fi;
                     if (w + mg < guard[u]) best[u] = fmaxf(best[u], w - mg);
                 }
             }
@@ -366,13 +376,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
         const float vs = L * tp.x * sq[u];
         // tb - mg_t in the ranking's units, from the numbers the integer bound was made of (one more rounding or two than
         // i8_margin_tile's own arithmetic: the factor below widens it by more than that; P1 = -inf: everything passes)
-        const float bound = (fmaf(-tp.y, A1[u], P1[u]) - 2.0f * tp.x) * (L * sq[u]) - amin;
+        float bound = (fmaf(-tp.y, A1[u], P1[u]) - 2.0f * tp.x) * (L * sq[u]) - amin;
+        if (KIND == SCAN_COS) bound = tbc[u] - i8_margin_tile(false, mA[u], mB[u], tp.y, tp.x, sq[u]) * ax_hi;  // (in cosine units; tbc = -inf: everything passes)
         const float bound_w = bound - 4e-6f * (fabsf(bound) + amin);
         float v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float fi = (float)(r < 4 ? c0[r & 3] : c1[r & 3]);
-            v[r] = KIND == SCAN_L2 ? fmaf(vs, fi, -ax[r]) : vs * fi;
+            v[r] = KIND == SCAN_L2 ? fmaf(vs, fi, -ax[r]) : KIND == SCAN_COS ? vs * fi * ax[r] : vs * fi;
         }
         uint32_t pm = 0;
 #pragma unroll
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
             for (int i = 0; i < PF; ++i) { f0[i] = st[(2 * i + 0) * 64]; f1[i] = st[(2 * i + 1) * 64]; }
             const float4 ctp = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * AS + 64 + 4 * sub);  // this tile's parameters
             float cax[8] = {};
-            if (KIND == SCAN_L2) {  // rows 32 sub + 16 rh + 4 jg + i of this stage
+            if (KIND != SCAN_IP) {  // rows 32 sub + 16 rh + 4 jg + i of this stage: squared norms (squared L2) / inverse norms (cosine)
                 const float4 a0 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * AS + 32 * sub + 4 * jg);
                 const float4 a1 = *reinterpret_cast<const float4 *>(aux_lds + (g % NS) * AS + 32 * sub + 16 + 4 * jg);
                 cax[0] = a0.x; cax[1] = a0.y; cax[2] = a0.z; cax[3] = a0.w;

@@ -931,7 +931,7 @@ __global__ __launch_bounds__(kSieveSelectThreads) void sieve_select_kernel(Sieve
         if (i8) {
             const float4 tp = a.i8_tparam[row / kTileRows];
             const float m = fmaf(tp.y, i8A, i8B) + 2.0f * tp.x * i8sq;
-            return l2 ? 2.0f * m : m;
+            return l2 ? 2.0f * m : a.metric == MIR_METRIC_COSINE_SIM ? m * a.max_norm[6] : m;  // (cosine: x the largest inverse norm)
         }
         return per_row ? a.dnorm[row] * cq : mg;
     };

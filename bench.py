@@ -383,7 +383,7 @@ def variant_leg(np, torch, args, local_rank, DeviceIndex, ShardedSearcher, kind)
     t_oracle = time.perf_counter() - t0
     del host
     d_pad = (d + 127) // 128 * 128
-    int8 = bool(stats and stats.get("int8_first_stage") and args.metric != "cosine_sim")
+    int8 = bool(stats and stats.get("int8_first_stage") and k <= 16)
     bytes_launch = (n * d_pad * sieve_image_bytes_per_element(int8) + (0 if args.metric == "inner_product" else 4 * n) + (n // 32 * 16 if int8 else 0)
                     + B * d * 4 + B * k * 12)  # what the sieve moves
     avg_ms = scan_ms / max(launches, 1)
@@ -1002,9 +1002,8 @@ def main():
     passes = -(-B // qpl)   # launches groups per step (1 at the default batch)
     survey_bytes = n_loc * d * 4 + aux + q_launch * d * 4 + q_launch * k * 12
     d_pad = (d + 127) // 128 * 128
-    # which first stage this index's searches run: the int8 image (finite rows of one norm; squared L2 / euclidean / inner product)
-    # or the bf16 hi blocks
-    int8 = bool(sieve and sieve_stats.get("int8_first_stage") and args.metric != "cosine_sim")
+    # which first stage this index's searches run: the int8 image (finite rows of one norm, k <= 16) or the bf16 hi blocks
+    int8 = bool(sieve and sieve_stats.get("int8_first_stage") and k <= 16)
     tile_params = (n_loc // 32) * 16 if int8 else 0  # a float4 per 32-row tile: scale, residual bound
     bytes_launch = (n_loc * d_pad * sieve_image_bytes_per_element(int8) + aux + tile_params + q_launch * d * 4 + q_launch * k * 12) if sieve else survey_bytes
     avg_ms = scan_ms / max(launches, 1)

@@ -64,8 +64,8 @@ extern "C" {
 
 /* per-query result flags (out_flags).  Results are ALWAYS the reference's.
  * float32 shards of >= 32K rows at d <= 384 are searched by the sieve: a bf16
- * filter (an int8 one where the rows are finite and of one norm and the metric is
- * not cosine) with a rigorous error margin lets through every row that can reach a
+ * filter (an int8 one where the rows are finite and of one norm and k <= 16)
+ * with a rigorous error margin lets through every row that can reach a
  * proven lower bound of the k-th best distance; the candidates whose filter
  * value, widened by the margin, can still reach the k-th best EXACT distance are
  * re-scored with the reference formula in float64 (the others are proven
@@ -164,8 +164,8 @@ int32_t mir_index_profile_read(mir_index *idx, int32_t reset, int64_t *launches,
  * (synchronises the device).  out8[0], out8[1]: candidates written by its first / second filter launch; out8[2]:
  * queries it answered; out8[3]: queries it handed to the exact pass (a full candidate buffer); out8[4]: candidates
  * listed when the second launch's thresholds were taken; out8[5]: rows evaluated with the reference's float64 formula
- * (the candidates that could be among the first k); out8[6]: 1 if the shard holds the int8 image (its squared-L2 /
- * euclidean / inner-product searches run the int8 first stage, csrc/vec_kernels_i8.h), else 0; out8[7]: 0. */
+ * (the candidates that could be among the first k); out8[6]: 1 if the shard holds the int8 image (its searches for
+ * up to 16 results run the int8 first stage, csrc/vec_kernels_i8.h), else 0; out8[7]: 0. */
 int32_t mir_index_scan_stats(mir_index *idx, int32_t reset, int64_t *out8);
 
 /* ENUM_TO_METRIC[metric](query, docs) -> float64[n]
