@@ -14,8 +14,8 @@
 // Queries: q ~ s_q Q with a scale per QUERY (its largest |q_i| / 127), B-operand fragments per 16 queries.
 //
 // Exactness.  I = X.Q is exact (int32; |I| <= 127^2 d < 2^24 for d <= 1024, so its float32 conversion is exact too).  With
-// x^ = s_x X, q^ = s_q Q:
-//   x.q - s_x s_q I = (x - x^).q + x^.(q - q^),  |.| <= |x - x^| |q| + (|x| + |x - x^|) |q - q^|   (Cauchy-Schwarz)
+// x^ = s_t X, q^ = s_q Q:
+//   x.q - s_t s_q I = (x - x^).q + x^.(q - q^),  |.| <= |x - x^| |q| + (|x| + |x - x^|) |q - q^|   (Cauchy-Schwarz)
 // - hihi_margin()'s formula with the int8 residuals in place of the bf16 ones: e_t = the largest |x - x^| over a TILE's rows is
 // measured at build time (i8 tile parameters), |q - q^| per query at prep time; a row's margin is its tile's,
 // mg_t = e_t (|q| + |q - q^|) + |x|max |q - q^| (+ slop) + 2 units (i8_margin_tile).  Squared L2
@@ -23,8 +23,7 @@
 // implies 2 s_t s_q I >= bound_t + |x|^2 >= bound_t + amin, amin = the index's smallest squared norm, i.e. I >= ib with ib the
 // integer part of (bound_t + amin) / (2 s_t s_q) rounded down - four vector instructions per tile and query tile - then one
 // maximum of eight accumulators and one compare per lane, no arithmetic on the values.  Whatever passes is redone in float
-// exactly as the bf16 filter does it (v = 2 s_t s_q I - |x|^2 per
-// row, one rounding), listed with v and its margin, and goes through the scatter and select of vec_kernels_sieve.h: every listed
+// exactly as the bf16 filter does it (v = 2 s_t s_q I - |x|^2 per row, one rounding), listed with v and its margin, and goes through the scatter and select of vec_kernels_sieve.h: every listed
 // row's true value lies in [v - mg, v + mg], and the rows select cannot exclude get the reference's float64 formula from the
 // float32 rows.  The integer test is conservative by (|x|^2 - amin) / (2 s_t s_q) units, which is why the image is built only
 // for shards whose squared norms agree to 1e-3 (normalised embeddings: to 1e-7).
@@ -35,8 +34,8 @@
 //
 // Built by default for every shard that qualifies (MIR_SIEVE_I8=0 at index build keeps the bf16 filter: the A/B switch;
 // `mir_index_scan_stats` word 6 says which an index has); the bf16 hi image is built beside it and serves k > 16.  Measured on
-// 10M x 384 unit rows, 256 queries per step (profiles/r04_i8_sieve.md): 1.26-1.30 ms per step against the bf16 filter's 1.83
-// (197-204k against 137-140k QPS), 1.8k + 2.4k candidates per query against 330 + 289.
+// 10M x 384 unit rows, 256 queries per step (profiles/r04_i8_sieve.md): 1.255-1.27 ms per step against the bf16 filter's 1.83-1.87
+// (201-204k against 135-141k QPS), 1.8k + 2.4k candidates per query against 330 + 289.
 #pragma once
 #include "vec_kernels_sieve.h"
 
@@ -55,7 +54,7 @@ typedef int __attribute__((ext_vector_type(4))) i32x4;
 constexpr int kI8StatWords = 8;
 // tile parameters (float4 per 32-row tile): x = s_t, y = e_t (largest |x - x^| of its rows, rounded up), z = 1 / (2 s_t), w = -
 constexpr int kI8MaxK = 16;           // results per query the int8 first stage serves (vec_index.hip, enqueue_search)
-constexpr int kI8Region = 32768;       // candidates a workgroup can write per launch: eight wave-private parts of 4096
+constexpr int kI8Region = 32768;       // candidates per launch and CU: eight wave-private parts of 4096 (one eight-wave workgroup, or two of four waves)
 constexpr int kI8WavePart = kI8Region / 8;
 // The margin of a row of a tile with residual bound e_t and scale s_t, in inner-product units, as mg_t = e_t * A + B + 2 s_t s_q:
 //   A = (|q| + |q - q^|) (1 + 1e-5), B = (|x|max |q - q^| + 3e-5 |x|max |q|) (1 + 1e-5)  [hihi_margin's terms, regrouped by e_t]
