@@ -1054,7 +1054,8 @@ static int32_t plan(const mir_index *ix, int b, int k, SearchPlan *pl) {
             static const uint32_t first_div = getenv("MIR_SIEVE_FIRST_DIV") ? (uint32_t)atoi(getenv("MIR_SIEVE_FIRST_DIV")) : 16u;  // (experiments)
             pl->tiles_first = two ? std::max<uint32_t>(ix->n_tiles / first_div, std::min<uint32_t>(ix->n_tiles / 4, 4896u)) : 0;
             pl->tiles_first &= ~1u;  // (the int8 filter walks 64-row stages: the two launches meet at a stage boundary)
-            pl->sample_tpw = std::max<uint32_t>(1, std::min<uint32_t>(two ? kSampleTilesPerWg : single_tpw, ix->n_tiles / (4u * kSampleWgs)));
+            static const int two_tpw = getenv("MIR_SIEVE_SAMPLE_TPW2") ? atoi(getenv("MIR_SIEVE_SAMPLE_TPW2")) : kSampleTilesPerWg;  // (experiments)
+            pl->sample_tpw = std::max<uint32_t>(1, std::min<uint32_t>(two ? two_tpw : single_tpw, ix->n_tiles / (4u * kSampleWgs)));
             return MIR_OK;
         }
     }
