@@ -113,6 +113,7 @@ struct mir_index {
     uint4 *d_i8 = nullptr;       // n_stages x 2 tiles x ks64 * 2 blocks of 1 KiB
     float *d_i8stats = nullptr;  // kI8StatWords floats
     float4 *d_i8tp = nullptr;    // [n_stages * 2] tile parameters (scale, residual bound, 1 / (2 scale))
+    float *d_i8rec = nullptr;    // [2][n_stages][72] the filter's per-stage records: squared norms + parameters, inverse norms + parameters
     int ks64 = 0;
     uint32_t n_stages = 0;       // 64-row stages = ceil(n_tiles / 2)
     unsigned long long *d_stats = nullptr;  // 8 counters of the sieve (mir_index_scan_stats)
@@ -169,6 +170,7 @@ static void free_index(mir_index *ix) {
     (void)hipFree(ix->d_i8);
     (void)hipFree(ix->d_i8stats);
     (void)hipFree(ix->d_i8tp);
+    (void)hipFree(ix->d_i8rec);
     (void)hipFree(ix->d_hi16);
     (void)hipFree(ix->d_maxnorm);
     (void)hipFree(ix->d_stats);
@@ -305,6 +307,15 @@ static int32_t build_i8(mir_index *ix, hipStream_t stream) {
         ix->d_i8 = nullptr;
         ix->d_i8tp = nullptr;
         ix->hbm_bytes -= image + (size_t)ix->n_stages * 2 * 16;
+    } else {
+        const size_t rec = (size_t)ix->n_stages * 72 * 4;
+        MIR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_i8rec), 2 * rec));
+        ix->hbm_bytes += 2 * rec;
+        const int64_t n_col = (int64_t)(ix->n_tiles + 1) * kTileRows;  // (the columns are padded by a tile: build_derived)
+        i8_stage_record_kernel<<<dim3(ix->n_stages), dim3(128), 0, stream>>>(ix->d_docsq, n_col, ix->d_i8tp, ix->d_i8rec);
+        i8_stage_record_kernel<<<dim3(ix->n_stages), dim3(128), 0, stream>>>(ix->d_invnorm, n_col, ix->d_i8tp, ix->d_i8rec + (size_t)ix->n_stages * 72);
+        MIR_HIP(hipGetLastError());
+        MIR_HIP(hipStreamSynchronize(stream));
     }
     return MIR_OK;
 }
@@ -617,7 +628,7 @@ static int32_t launch_sieve_i8(const mir_index *ix, int qpw, const float *q_scal
     case KS: {                                                                                                         \
         auto kern = MIR_I8_PICK(KS);                                                                                   \
         MIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kern<<<dim3(grid), dim3(four ? 256 : 512), lds, stream>>>(ix->d_i8, KIND == SCAN_COS ? ix->d_invnorm : ix->d_docsq, ix->d_i8tp, qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, q_scale_g, n_rows, \
+        kern<<<dim3(grid), dim3(four ? 256 : 512), lds, stream>>>(ix->d_i8, ix->d_i8rec + (KIND == SCAN_COS ? (size_t)ix->n_stages * 72 : 0), qfrag_g, q_norm_g, q_sq_g, q_err_g, ix->d_i8stats, q_scale_g, n_rows, \
                                                     stage0, n_stages, nq, nan_guard, gthr_g, cand, candv, ccount, part_sample, stat); \
         break;                                                                                                         \
     }

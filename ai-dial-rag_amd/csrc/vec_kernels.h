@@ -557,6 +557,15 @@ __device__ __forceinline__ void glds4_b32(const void *gsrc, uint32_t lds_byte_ad
         : "v"(gsrc), "s"(lds_byte_addr)
         : "memory");
 }
+// the same with a wave-uniform base (an SGPR pair) and a 32-bit byte offset per lane: no 64-bit address to keep in VGPRs
+__device__ __forceinline__ void glds4_b32_sv(const void *gbase_uniform, uint32_t lane_byte_off, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_byte_off), "s"(gbase_uniform), "s"(lds_byte_addr)
+        : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }

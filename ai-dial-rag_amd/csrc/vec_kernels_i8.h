@@ -152,6 +152,23 @@ __global__ __launch_bounds__(256) void i8_residual_kernel(const float *__restric
     }
 }
 
+// The filter's per-stage record (72 floats per 64-row stage): the stage's 64 squared norms (squared L2, inner product: unread) or
+// inverse norms (cosine), then its two tiles' parameters - ONE contiguous piece of the stage's DMA, one address.
+__global__ __launch_bounds__(128) void i8_stage_record_kernel(const float *__restrict__ col, int64_t n_col, const float4 *__restrict__ tparam,
+                                                              float *__restrict__ rec) {
+    const int64_t stage = blockIdx.x;
+    const int t = threadIdx.x;
+    if (t >= 72) return;
+    float v;
+    if (t < 64) {
+        const int64_t row = stage * 64 + t;
+        v = row < n_col ? col[row] : 0.f;
+    } else {
+        v = reinterpret_cast<const float *>(tparam)[stage * 8 + (t - 64)];
+    }
+    rec[stage * 72 + t] = v;
+}
+
 // ---- queries ----
 // Kernel 1, one block per query (+ the blocks that zero the control words, as prep_queries16_kernel): q_sq and q_norm in float64
 // (the same sums in the same order as prep_queries16_kernel: the select kernel's distances use them) and the query's largest |q_i|.
@@ -237,7 +254,6 @@ __host__ __device__ constexpr size_t sieve_i8_lds_bytes(int ks64, int nw) { retu
 // LDS atomic on the emit path), ccount[workgroup][8].
 template <int KS64, int KIND, bool SAMPLE, int QT, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__restrict__ docs, const float *__restrict__ aux,
-                                                          const float4 *__restrict__ tparam,
                                                           const uint4 *__restrict__ qfrag, const double *__restrict__ q_norm,
                                                           const double *__restrict__ q_sq, const double *__restrict__ q_err,
                                                           const float *__restrict__ stats, const float *__restrict__ q_scale,
@@ -254,8 +270,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
     constexpr int SB = NB * 2;             // per stage (two tiles)
     constexpr int STAGE_U4 = SB * 64;
     constexpr int PPW = SB / NW;           // 1-KiB DMA pieces per wave per stage
-    // the stage's 64 squared norms travel with it (lanes 0..7 of every wave bring 8 of them; inner product never reads them) and,
-    // by the same instruction, its two tiles' parameters (lanes 8..15 of the last wave -> slots 64..71)
+    // the stage's record travels with it: 64 squared norms (inverse norms for cosine; inner product never reads them) and its two
+    // tiles' parameters, one DMA instruction per wave
     constexpr int PW = PPW + 1;
     constexpr int AS = 64 + 8;
     constexpr int D = NS - 1;
@@ -329,12 +345,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sieve_i8_kernel(const uint4 *__res
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(ring) + ((g % NS) * STAGE_U4 + (wave8 * PPW) * 64) * 16);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) glds16_b128(src + i * 64, dst + i * 1024);
-        {
+        {   // the stage's record (i8_stage_record_kernel): every wave its share of the 64 norms, the last one the 8 parameter floats behind them
+            // (a wave-uniform base and the lane's byte offset: a 64-bit per-lane address would be one more live register pair in a
+            // kernel that has none to spare - spilled, its reload's `s_waitcnt vmcnt(0)` drained the DMA ring at every stage)
             const uint32_t adst = __builtin_amdgcn_readfirstlane(lds_addr_of(aux_lds) + ((g % NS) * AS + wave8 * APW) * 4);
-            const bool tp_lane = wave8 == NW - 1 && lane >= APW && lane < APW + 8;  // (the last wave: slots 64 .. 71)
-            const float *src1 = tp_lane ? reinterpret_cast<const float *>(tparam) + (size_t)stage * 8 + (lane - APW)
-                                        : aux + (size_t)stage * 64 + wave8 * APW + lane;
-            if (lane < APW || tp_lane) glds4_b32(src1, adst);
+            const float *abase = aux + (size_t)stage * AS + wave8 * APW;
+            if (lane < APW + (wave8 == NW - 1 ? 8 : 0)) glds4_b32_sv(abase, (uint32_t)lane * 4u, adst);
         }
     };
 #pragma unroll
