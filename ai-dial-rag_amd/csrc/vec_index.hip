@@ -612,7 +612,7 @@ static int32_t launch_sieve_i8(const mir_index *ix, int qpw, const float *q_scal
                                int nan_guard, const uint64_t *gthr_g, uint64_t *cand, float *candv, uint32_t *ccount, float *part_sample,
                                bool sample, unsigned long long *stat, hipStream_t stream) {
     // from 65 queries per launch: four waves per workgroup (two or four query tiles each) and two workgroups per CU - 0.83 against
-    // 0.92 ms per 128-query step at 10M x 384, 1.25-1.27 against 1.27-1.30 per 256; up to 64 queries half of four waves' query
+    // 0.92 ms per 128-query step at 10M x 384, 1.13-1.16 against 1.27-1.30 per 256; up to 64 queries half of four waves' query
     // tiles would be empty: eight waves with one tile each.  MIR_SIEVE_I8_WAVES = 4 / 8 forces one geometry (A/B runs)
     static const int nw_env = getenv("MIR_SIEVE_I8_WAVES") ? atoi(getenv("MIR_SIEVE_I8_WAVES")) : 0;
     const bool four = nw_env ? nw_env == 4 : nq > 64;

@@ -34,8 +34,8 @@
 //
 // Built by default for every shard that qualifies (MIR_SIEVE_I8=0 at index build keeps the bf16 filter: the A/B switch;
 // `mir_index_scan_stats` word 6 says which an index has); the bf16 hi image is built beside it and serves k > 16.  Measured on
-// 10M x 384 unit rows, 256 queries per step (profiles/r04_i8_sieve.md): 1.255-1.27 ms per step against the bf16 filter's 1.83-1.87
-// (201-204k against 135-141k QPS), 1.8k + 2.4k candidates per query against 330 + 289.
+// 10M x 384 unit rows, 256 queries per step (profiles/r04_i8_sieve.md): 1.13-1.14 ms per step against the bf16 filter's 1.83-1.87
+// (224-227k against 135-141k QPS), 1.8k + 2.4k candidates per query against 330 + 289.
 #pragma once
 #include "vec_kernels_sieve.h"
 
