@@ -414,3 +414,84 @@ def test_int8_first_stage_is_exact(ei, metric, monkeypatch):
         np.testing.assert_array_equal(out[2][i][: out[4][i]], want, err_msg=f"{metric} long rows q={i} flag={out[5][i]}")
         np.testing.assert_allclose(out[3][i][: out[4][i]], alld[want], rtol=0, atol=1e-9)
     ix.close()
+
+
+def test_worst_case_int8_rounding(ei):
+    """The int8 first stage's margin must cover the WORST case of its rounding, not the error of random data: Cauchy-Schwarz is
+    tight when every component of a row's rounding residual points along the query.  The query has components +-1/sqrt(d) (its own
+    int8 image is exact), ten competitor rows in the first launch's range sit 0.49 of a quantisation step BELOW their grid point
+    on every coordinate the query is positive on (their filter value OVER-states x.q by |x - x^||q|), and the true best row, in the
+    second launch's range, 0.49 of a step ABOVE (under-stated by as much), its true product half a residual above theirs.  With
+    half the margin (-DMIR_MARGIN_SCALE=0.5f, tools/worst_case_margin_check.sh) the second launch's threshold sits above the best
+    row's filter value and it is lost; with the margin as derived it is found, first, by the int8 route itself."""
+    from oracle import embeddings_metrics as om
+
+    rng = np.random.default_rng(88)
+    d = 384
+    sig = np.where(rng.random(d) < 0.5, -1.0, 1.0)
+    q = sig / np.sqrt(d)
+    docs = rng.standard_normal((N, d)).astype(np.float32)
+    docs /= np.linalg.norm(docs, axis=1, keepdims=True)
+    comp = 40_000 + 32 * np.arange(10) * 7 + 5          # ten competitors, one per tile, rows 40K .. 42K (first launch, past the sample)
+    best = 400_000 + 13                                   # the true best row: second launch
+    t_c = 0.30                                            # the competitors' true product (the random rows stay below ~0.26)
+
+    def special(row, sign, target):
+        """A unit row on the int8 grid of its tile, shifted by sign * 0.49 step along the query on every coordinate; x.q = target."""
+        tile = docs[row // 32 * 32 : row // 32 * 32 + 32]
+        m = np.float32(np.max(np.abs(np.delete(tile, row % 32, axis=0))))
+        s = np.float32(m / np.float32(127.0))
+        inv = np.float32(1.0) / s
+        want_sum = target * np.sqrt(d) / float(s) - sign * 0.49 * d      # sum of Y = X * sig
+        want_sq = 1.0 / float(s) ** 2                                     # sum of (Y + sign * 0.49)^2
+        sd = np.sqrt(max(want_sq / d - (want_sum / d + sign * 0.49) ** 2, 1.0))
+        y = np.clip(np.rint(rng.normal(want_sum / d, sd, d)), -120, 120)
+        for _ in range(20000):                                            # the sum first, one unit at a time
+            diff = int(round(want_sum - y.sum()))
+            if diff == 0:
+                break
+            i = rng.integers(d)
+            if abs(y[i] + np.sign(diff)) <= 120:
+                y[i] += np.sign(diff)
+        for _ in range(20000):                                            # then the norm, by +1 / -1 pairs (the sum stays)
+            cur = float(((y + sign * 0.49) ** 2).sum())
+            if abs(cur - want_sq) < 40.0:                                 # |x| within 5e-5 of 1
+                break
+            i, j = rng.integers(d, size=2)
+            if i == j:
+                continue
+            grow = cur < want_sq
+            a, b = (i, j) if (y[i] >= y[j]) == grow else (j, i)           # widening the larger / narrowing it
+            if abs(y[a] + 1) <= 120 and abs(y[b] - 1) <= 120:
+                y[a] += 1
+                y[b] -= 1
+        x = (s * ((y * sig) + sign * 0.49 * sig).astype(np.float32)).astype(np.float32)
+        assert float(np.max(np.abs(x))) < float(m)                        # the tile's scale is still the other rows'
+        assert np.array_equal(np.rint(x * inv), y * sig)                  # quantises back to the grid point
+        return x, float(s)
+
+    res = None
+    for r in comp:
+        docs[r], s_r = special(int(r), -1.0, t_c)
+        res = 0.49 * s_r * np.sqrt(d)
+    e_best = None
+    docs[best], s_b = special(best, +1.0, t_c + 0.5 * res)
+    e_best = 0.49 * s_b * np.sqrt(d)
+    true = docs.astype(np.float64) @ q
+    order = np.argsort(-true, kind="stable")
+    assert order[0] == best and set(order[1:11]) == set(comp.tolist())    # the construction: best first, then the competitors
+    assert abs(np.linalg.norm(docs[best].astype(np.float64)) - 1.0) < 2e-4
+    # its filter value under-states by (almost) its whole Cauchy-Schwarz bound, the competitors' over-state by theirs
+    assert true[best] - true[comp].max() < 0.75 * e_best and true[best] - true[comp].max() > 0.25 * e_best
+    qs = rng.standard_normal((70, d))
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    qs[5] = q
+    ix = ei.DeviceIndex.from_host(docs)
+    assert ix.scan_stats()["int8_first_stage"]
+    for metric in ("inner_product", "sqeuclidean_dist", "cosine_sim"):
+        out = ix.search(qs, 10, metric)
+        assert int(out[5].sum()) == 0, out[5]
+        for i in (0, 5, 6):
+            check(metric, qs[i], docs, tuple(o[i] for o in out), 10, f"int8 worst case {metric} q={i}")
+        assert out[2][5][0] == best, (metric, out[2][5])
+    ix.close()
